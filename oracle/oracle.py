@@ -1,0 +1,127 @@
+"""ctypes front-end of the CPU oracle (oracle/savad_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+May be imported only by tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+-- never by the product package ``voice_activity_detection_amd``.
+"""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+_fp = ctypes.POINTER(ctypes.c_float)
+
+
+def build(force: bool = False) -> Path:
+    so = _HERE / "libsavad_oracle.so"
+    src = _HERE / "savad_oracle.c"
+    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-B", "libsavad_oracle.so"], check=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(str(build()))
+        L.savad_oracle_pe.argtypes = [ctypes.c_int, ctypes.c_int, _fp]
+        L.savad_oracle_pe.restype = None
+        L.savad_oracle_forward.argtypes = [ctypes.POINTER(_fp), _fp] + [ctypes.c_int] * 5 + [_fp, ctypes.c_int,
+                                                                                              ctypes.c_int, _fp, _fp, _fp]
+        L.savad_oracle_forward.restype = ctypes.c_int
+        L.savad_oracle_window_offsets.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.savad_oracle_window_offsets.restype = ctypes.c_int
+        L.savad_oracle_gather_windows.argtypes = [_fp] + [ctypes.c_int] * 6 + [_fp, ctypes.POINTER(ctypes.c_int64)]
+        L.savad_oracle_gather_windows.restype = None
+        L.savad_oracle_boost.argtypes = [_fp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         _fp, _fp]
+        L.savad_oracle_boost.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_fp)
+
+
+def pe(T: int, D: int) -> np.ndarray:
+    out = np.empty((T, D), dtype=np.float32)
+    lib().savad_oracle_pe(T, D, _p(out))
+    return out
+
+
+def forward(state: dict, x: np.ndarray, acc64: bool = False, threads: int = 0, taps: bool = False):
+    """state: ordered dict key -> float32 array in state_dict_spec order.  x: [B,T,F] float32."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, T, F = x.shape
+    arrs = [np.ascontiguousarray(v, dtype=np.float32) for v in state.values()]
+    D = arrs[0].shape[0]
+    assert arrs[0].shape[1] == F, "feature size mismatch"
+    L = (len(arrs) - 6) // 16
+    assert len(arrs) == 2 + 16 * L + 4
+    ptrs = (_fp * len(arrs))(*[_p(a) for a in arrs])
+    out = np.empty((B, T, 2), dtype=np.float32)
+    t = [np.empty((B, T, D), dtype=np.float32) for _ in range(3)] if taps else [None] * 3
+    rc = lib().savad_oracle_forward(ptrs, _p(x), B, T, F, L, D, _p(out), int(acc64), int(threads),
+                                    *[(_p(a) if a is not None else None) for a in t])
+    if rc != 0:
+        raise RuntimeError(f"savad_oracle_forward failed rc={rc}")
+    if taps:
+        return out, {"input_layer": t[0], "l0_ctx": t[1], "encoder_out": t[2]}
+    return out
+
+
+def window_offsets(half: int, jump: int) -> np.ndarray:
+    buf = (ctypes.c_int * 64)()
+    w = lib().savad_oracle_window_offsets(half, jump, buf)
+    return np.array(buf[:w], dtype=np.int64)
+
+
+def gather_windows(feature: np.ndarray, half: int, jump: int, first: int, count: int):
+    feature = np.ascontiguousarray(feature, dtype=np.float32)
+    N, F = feature.shape
+    W = len(window_offsets(half, jump))
+    win = np.empty((count, W, F), dtype=np.float32)
+    pos = np.empty((count, W), dtype=np.int64)
+    lib().savad_oracle_gather_windows(_p(feature), N, F, half, jump, first, count, _p(win),
+                                      pos.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+    return win, pos
+
+
+def boost(logp: np.ndarray, positions: np.ndarray, N: int):
+    logp = np.ascontiguousarray(logp, dtype=np.float32)
+    positions = np.ascontiguousarray(positions, dtype=np.int64)
+    count, W, _ = logp.shape
+    probs = np.empty((N, W), dtype=np.float32)
+    mean = np.empty((N,), dtype=np.float32)
+    lib().savad_oracle_boost(_p(logp), positions.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), count, N, W,
+                             _p(probs), _p(mean))
+    return probs, mean
+
+
+def predict_probabilities(state: dict, feature: np.ndarray, half: int = 19, jump: int = 9, chunk: int = 1000,
+                          acc64: bool = False):
+    """Oracle of vad/predictor.py:159-262 for the self-attention model: chunks of <=1000 windows
+    (:180-182) -> forward -> boosted scatter/softmax (:238-258).  Returns (probs[N,W], mean[N])."""
+    N = feature.shape[0]
+    data_length = N - 2 * half  # :169
+    W = len(window_offsets(half, jump))
+    logps, poss = [], []
+    for first in range(0, max(data_length, 0), chunk):
+        count = min(chunk, data_length - first)
+        win, pos = gather_windows(feature, half, jump, first, count)
+        logps.append(forward(state, win, acc64=acc64))
+        poss.append(pos)
+    if logps:
+        logp = np.concatenate(logps, 0)
+        pos = np.concatenate(poss, 0)
+    else:
+        logp = np.zeros((0, W, 2), np.float32)
+        pos = np.zeros((0, W), np.int64)
+    return boost(logp, pos, N)

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE implementation (read-only at
+/root/reference) in this container.  Run from the repo root:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Nothing of the reference travels: only the inputs' seeds and the reference's numeric
+outputs are stored (tests/golden/*.npz).  The GPU box never needs /root/reference.
+
+What is pinned:
+  g1  [4,7,80]    -> log-probs [4,7,2]            (the shape the reference pipeline runs)
+  g2  [2,800,80]  -> log-probs [2,800,2]          (BASELINE config shape, small batch)
+  g3  [32,800,80] -> first/last 2 sequences + per-sequence checksums (config 2)
+  g4  edge lengths T in {1,2,5,10,11,16,17,31,32,33,63,64,65,100,799,801}, B=3
+  g5  predictor level: feature[1022,80] -> probs[1022,7], mean(axis=1)
+      (vad/predictor.py:159-262 run unmodified behind 5 in-memory import shims)
+  g6  intermediate taps on [2,40,80] (input layer, layer-0 attention context, encoder LN)
+  g7  peaked-softmax weights (gain 4) on [2,96,80]
+  pe  rows of the reference's sinusoidal table built for T=801 (vad/modeling/transformer.py:403-414)
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def ref_model(state, feature_size=80, num_layers=3, d_model=128):
+    from vad.models.self_attention import SelfAttentiveVAD  # reference, unmodified
+
+    m = SelfAttentiveVAD(feature_size, num_layers, d_model, 0.5)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    return m.eval()
+
+
+def run(m, x):
+    with torch.no_grad():
+        return m(features=torch.from_numpy(x)).numpy()
+
+
+def main():
+    state = seeded_state_dict(1234)
+    m = ref_model(state)
+    g = {}
+
+    # g1 / g2
+    x1 = seeded_features(101, (4, 7, 80))
+    g["g1_out"] = run(m, x1)
+    x2 = seeded_features(102, (2, 800, 80))
+    g["g2_out"] = run(m, x2)
+    # g3: config-2 shape; input regenerates from seed 0 (BASELINE config 2)
+    x3 = seeded_features(0, (32, 800, 80))
+    y3 = run(m, x3)
+    g["g3_head"] = y3[:2]
+    g["g3_tail"] = y3[-2:]
+    g["g3_seqsum"] = y3.astype(np.float64).sum(axis=(1, 2))
+    g["g3_abssum"] = np.abs(y3.astype(np.float64)).sum(axis=(1, 2))
+    # normal-distributed input, same shape family
+    x2n = seeded_features(103, (3, 200, 80), kind="normal")
+    g["g2n_out"] = run(m, x2n)
+
+    # g4: edge lengths
+    for T in (1, 2, 5, 10, 11, 16, 17, 31, 32, 33, 63, 64, 65, 100, 799, 801):
+        x = seeded_features(400 + T, (3, T, 80))
+        g[f"g4_T{T}"] = run(m, x)
+    # B edge: single window, and B=1000 windows of T=7 (reference chunk size, predictor.py:180)
+    g["g4_B1T7"] = run(m, seeded_features(77, (1, 7, 80)))
+    y = run(m, seeded_features(78, (1000, 7, 80)))
+    g["g4_B1000T7_head"] = y[:8]
+    g["g4_B1000T7_tail"] = y[-8:]
+    g["g4_B1000T7_seqsum"] = y.astype(np.float64).sum(axis=(1, 2))
+
+    # g6: taps via forward hooks
+    taps = {}
+    x6 = seeded_features(600, (2, 40, 80))
+    def tap(name, use_input=False):
+        def hook(mod, i, o):
+            taps[name] = (i[0] if use_input else o).numpy().copy()  # returns None: output untouched
+        return hook
+
+    l0 = m.encoder.layers[0]
+    hooks = [
+        m.input_layer.register_forward_hook(tap("g6_input_layer")),
+        l0.self_attention.final_projection.register_forward_hook(tap("g6_l0_ctx", use_input=True)),
+        l0.self_attention.final_projection.register_forward_hook(tap("g6_l0_attn_out")),
+        l0.register_forward_hook(tap("g6_l0_out")),
+        m.encoder.register_forward_hook(tap("g6_encoder_out")),
+    ]
+    g["g6_out"] = run(m, x6)
+    for h in hooks:
+        h.remove()
+    g.update(taps)
+
+    # g7: peaked softmax (weights x4 -> large score spread), forces online-softmax rescales
+    state7 = seeded_state_dict(4321, gain=4.0)
+    m7 = ref_model(state7)
+    g["g7_out"] = run(m7, seeded_features(700, (2, 96, 80)))
+    g["g7_T800"] = run(m7, seeded_features(701, (1, 800, 80)))
+
+    # other model sizes accepted by the constructor (model_factory.py:42-48)
+    state8 = seeded_state_dict(88, feature_size=40, num_layers=2, d_model=128)
+    m8 = ref_model(state8, 40, 2, 128)
+    g["g8_F40L2"] = run(m8, seeded_features(800, (3, 50, 40)))
+
+    # positional-encoding table of the reference
+    pe = m.input_layer[1].build_positional_encoding(801).numpy()[0]
+    pe_rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(40, 801, 37), np.arange(780, 801)]))
+    g["pe_rows"] = pe_rows.astype(np.int64)
+    g["pe_vals"] = pe[pe_rows]
+
+    # g5: predictor level -------------------------------------------------------------
+    g.update(predictor_golden(m))
+
+    np.savez_compressed(OUT / "golden.npz", **g)
+    total = sum(v.nbytes for v in g.values())
+    print(f"wrote {OUT/'golden.npz'}: {len(g)} arrays, {total/1e3:.1f} kB raw, "
+          f"{(OUT/'golden.npz').stat().st_size/1e3:.1f} kB on disk")
+
+
+def predictor_golden(model):
+    """Run vad/predictor.py:159-262 unmodified.  Its module-level imports need packages
+    absent here (more_itertools, omegaconf, librosa, soundfile, pysrt, cv2): stub them in
+    sys.modules for this process only."""
+    from itertools import islice
+
+    def ichunked(it, n):
+        it = iter(it)
+        while True:
+            chunk = list(islice(it, n))
+            if not chunk:
+                return
+            yield chunk
+
+    mi = types.ModuleType("more_itertools")
+    mi.ichunked = ichunked
+    oc = types.ModuleType("omegaconf")
+    oc.MISSING = "???"
+
+    class _OC:
+        @staticmethod
+        def create(x):
+            return x
+
+        @staticmethod
+        def to_container(x, **kw):
+            return x
+
+        @staticmethod
+        def structured(x):
+            return x
+
+    oc.OmegaConf = _OC
+    oc.DictConfig = dict
+    for name, mod in (("more_itertools", mi), ("omegaconf", oc)):
+        sys.modules.setdefault(name, mod)
+    class _Stub(types.ModuleType):
+        """Import-time placeholder: any attribute is a no-op callable (never used on this path)."""
+
+        def __getattr__(self, item):
+            if item.startswith("__"):
+                raise AttributeError(item)
+            return lambda *a, **k: None
+
+    for name in ("librosa", "librosa.feature", "librosa.core", "librosa.effects", "soundfile", "pysrt", "cv2"):
+        sys.modules.setdefault(name, _Stub(name))
+
+    from vad.predictor import VADFromScratchPredictor  # reference, unmodified
+
+    ns = types.SimpleNamespace
+    fe = ns(config=ns(transform=ns(hop_ms=10, window_ms=25)),
+            extract_with_postprocessing=lambda audio: audio.feat)
+    config = ns(context_resolution=ns(context_window_half_frames=19, context_window_jump_frames=9),
+                model=ns(name="self-attention"))
+    pred = VADFromScratchPredictor(model=model, feature_extractor=fe, device=torch.device("cpu"), config=config)
+    out = {}
+    # N=1022 frames: the reference test clip's length; N=2100 -> 3 chunks
+    for tag, n, seed in (("g5", 1022, 500), ("g5b", 2100, 501), ("g5c", 39, 502)):
+        feat = seeded_features(seed, (n, 80))
+        probs = pred.predict_probabilities(ns(feat=feat, sample_rate=16000))
+        out[f"{tag}_probs"] = np.asarray(probs, dtype=np.float32)
+        out[f"{tag}_mean"] = np.asarray(probs).mean(axis=1)  # vad/predictor.py:95
+    return out
+
+
+if __name__ == "__main__":
+    os.chdir(REPO)
+    main()

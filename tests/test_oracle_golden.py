@@ -1,0 +1,93 @@
+"""The CPU oracle (oracle/savad_oracle.c) against golden vectors captured from the reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
+
+# fp32 oracle vs fp32 torch-CPU reference: both carry ~2e-6 of fp32 noise at T=800
+TOL = 2e-5
+
+
+def test_pe_table(golden):
+    pe = oracle.pe(801, 128)
+    rows = golden["pe_rows"]
+    # 1 ulp of sin/cos plus one 1-ulp frequency (torch's vectorised expf differs from the
+    # correctly-rounded exp in 1 of 64 entries) amplified by t <= 800
+    assert np.abs(pe[rows] - golden["pe_vals"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("tag,seed,shape", [("g1_out", 101, (4, 7, 80)), ("g2_out", 102, (2, 800, 80))])
+def test_forward_golden(golden, state1234, tag, seed, shape):
+    y = oracle.forward(state1234, seeded_features(seed, shape))
+    assert y.shape == golden[tag].shape
+    assert np.abs(y - golden[tag]).max() < TOL
+
+
+def test_forward_golden_fp64_truth(golden, state1234):
+    y = oracle.forward(state1234, seeded_features(102, (2, 800, 80)), acc64=True)
+    assert np.abs(y - golden["g2_out"]).max() < TOL
+
+
+def test_forward_normal_input(golden, state1234):
+    y = oracle.forward(state1234, seeded_features(103, (3, 200, 80), kind="normal"))
+    assert np.abs(y - golden["g2n_out"]).max() < TOL
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 10, 11, 16, 17, 31, 32, 33, 63, 64, 65, 100, 799, 801])
+def test_edge_lengths(golden, state1234, T):
+    y = oracle.forward(state1234, seeded_features(400 + T, (3, T, 80)))
+    assert np.abs(y - golden[f"g4_T{T}"]).max() < TOL
+
+
+def test_batch_edges(golden, state1234):
+    assert np.abs(oracle.forward(state1234, seeded_features(77, (1, 7, 80))) - golden["g4_B1T7"]).max() < TOL
+    y = oracle.forward(state1234, seeded_features(78, (1000, 7, 80)))
+    assert np.abs(y[:8] - golden["g4_B1000T7_head"]).max() < TOL
+    assert np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < TOL
+    assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g4_B1000T7_seqsum"]).max() < 14 * TOL
+    assert oracle.forward(state1234, np.zeros((0, 7, 80), np.float32)).shape == (0, 7, 2)
+
+
+def test_taps(golden, state1234):
+    y, taps = oracle.forward(state1234, seeded_features(600, (2, 40, 80)), taps=True)
+    assert np.abs(y - golden["g6_out"]).max() < TOL
+    assert np.abs(taps["input_layer"] - golden["g6_input_layer"]).max() < TOL
+    assert np.abs(taps["l0_ctx"] - golden["g6_l0_ctx"]).max() < TOL
+    assert np.abs(taps["encoder_out"] - golden["g6_encoder_out"]).max() < TOL
+
+
+def test_peaked_softmax(golden):
+    st = seeded_state_dict(4321, gain=4.0)
+    assert np.abs(oracle.forward(st, seeded_features(700, (2, 96, 80))) - golden["g7_out"]).max() < 5 * TOL
+    assert np.abs(oracle.forward(st, seeded_features(701, (1, 800, 80))) - golden["g7_T800"]).max() < 5 * TOL
+
+
+def test_other_model_size(golden):
+    st = seeded_state_dict(88, feature_size=40, num_layers=2, d_model=128)
+    assert np.abs(oracle.forward(st, seeded_features(800, (3, 50, 40))) - golden["g8_F40L2"]).max() < TOL
+
+
+def test_window_offsets():
+    # vad/predictor.py:57-59,186-212 with the only shipped config (half 19, jump 9)
+    assert oracle.window_offsets(19, 9).tolist() == [-19, -10, -1, 0, 1, 10, 19]
+    assert len(oracle.window_offsets(19, 9)) == 2 * (19 - 1) // 9 + 3
+
+
+@pytest.mark.parametrize("tag,n,seed", [("g5", 1022, 500), ("g5b", 2100, 501), ("g5c", 39, 502)])
+def test_predictor_level(golden, state1234, tag, n, seed):
+    feat = seeded_features(seed, (n, 80))
+    probs, mean = oracle.predict_probabilities(state1234, feat)
+    assert probs.shape == golden[f"{tag}_probs"].shape
+    assert np.abs(probs - golden[f"{tag}_probs"]).max() < TOL
+    assert np.abs(mean - golden[f"{tag}_mean"]).max() < TOL
+    # unfilled slots are exactly 0.5 (softmax([0,0])) and are averaged in (predictor.py:238-258,:95)
+    assert (probs == 0.5).sum() == (golden[f"{tag}_probs"] == 0.5).sum()
+
+
+def test_g3_config2_checksums(golden, state1234):
+    y = oracle.forward(state1234, seeded_features(0, (32, 800, 80)))
+    assert np.abs(y[:2] - golden["g3_head"]).max() < TOL
+    assert np.abs(y[-2:] - golden["g3_tail"]).max() < TOL
+    assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g3_seqsum"]).max() < 1600 * TOL
