@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- audio frames/sec of the self-attentive-VAD forward pass on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic mel frames: forward of
+SelfAttentiveVAD on a device-resident [B, T, F] fp32 tensor -> device-resident [B, T, 2] log-probs
+(N > 1: every rank runs its own B-sequence shard, then ONE RCCL all_gather of the log-probs).
+Default workload = BASELINE.json configs[1]: [32, 800, 80] fp32 per GPU, seeded weights.
+Prints ONE JSON line on rank 0 (contract: see the task statement).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+F_MEL, D_MODEL, N_LAYERS = 80, 128, 3
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+
+
+def flops_per_frame(T: int) -> float:
+    """2FD + L(8D^2 + 4TD + 4D*d_ff) + 4D."""
+    F, D, L = F_MEL, D_MODEL, N_LAYERS
+    return 2 * F * D + L * (8 * D * D + 4 * T * D + 4 * D * 4 * D) + 4 * D
+
+
+def cpu_baseline(state, T: int, seconds: float):
+    """The reference's CPU path cannot travel; time its stand-ins on this host's cores on a bounded
+    sample of the same workload: (a) the stock-PyTorch port (same ATen ops as the reference),
+    (b) the C oracle.  Report the faster one."""
+    from oracle import oracle, torch_port
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    st = {k: torch.from_numpy(v) for k, v in state.items()}
+    Bs = 8
+    x = torch.from_numpy(np.random.default_rng(0).uniform(-13.8, 4.2, (Bs, T, F_MEL)).astype(np.float32))
+    torch_port.forward(st, x)  # warm-up
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        torch_port.forward(st, x)
+        it += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds * 0.6 or it >= 50:
+            break
+    torch_fps = it * Bs * T / dt
+    xn = x.numpy()
+    oracle.forward(state, xn[:1])
+    t0 = time.perf_counter()
+    oracle.forward(state, xn, threads=cores)
+    c_fps = Bs * T / (time.perf_counter() - t0)
+    best = max(torch_fps, c_fps)
+    return {
+        "value": round(best, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"[{Bs},{T},{F_MEL}] fp32 x {it} forwards of the stock-PyTorch CPU port "
+                  f"(torch {torch.__version__}, {cores} threads: {torch_fps:.0f} frames/s) and one pass of the "
+                  f"C oracle with OpenMP ({c_fps:.0f} frames/s); faster one reported",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
+    ap.add_argument("--frames", type=int, default=800, help="T")
+    ap.add_argument("--splits", type=int, default=0, help="attention key splits (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL ("nccl" backend on ROCm)
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict
+
+    B, T = args.batch, args.frames
+    state = seeded_state_dict(1234)
+    model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(dev).eval()
+    model.attention_splits = args.splits
+    # each rank gets its own shard of the global batch (weak scaling: B per GPU fixed)
+    x = torch.from_numpy(np.random.default_rng(rank).uniform(-13.8, 4.2, (B, T, F_MEL)).astype(np.float32)).to(dev)
+    gathered = torch.empty((world, B, T, 2), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            y = model(features=x)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, y)  # the single collective of the path
+        return y
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if not args.no_events:
+        model.set_profiling(args.steps)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ktimes = [] if args.no_events else model.kernel_times()
+    ok = bool(torch.isfinite(y).all().item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        frames = world * B * T
+        value = frames * args.steps / elapsed
+        fwd_tflops = flops_per_frame(T) * B * T / (elapsed / args.steps) / 1e12  # per GPU
+        roof = None
+        if ktimes:
+            att = [t for n, t in ktimes if n == "attention"]
+            att_ms = sum(att) / len(att)
+            att_flops = 4.0 * T * T * D_MODEL * B  # QK^T + PV of one layer's launch
+            ach = att_flops / (att_ms * 1e-3) / 1e12
+            roof = {
+                "bound": "mfma", "kernel": "attention_kernel (1 launch per layer)",
+                "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "ms_per_launch": round(att_ms, 4),
+                "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+                "kernels_ms": {f"{i}:{n}": round(t, 4) for i, (n, t) in enumerate(ktimes)},
+            }
+        line = {
+            "metric": "audio frames/sec (whole node)", "value": round(value, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded U(-13.8,4.2) mel frames, seeded random-init weights)",
+            "config": {"workload": f"BASELINE configs[1]: synthetic [B={B}, T={T}, F={F_MEL}] fp32 per GPU, "
+                                   f"SelfAttentiveVAD(80, 3, 128) forward -> log-probs [B,T,2]",
+                       "global_batch": world * B, "frames_per_sequence": T,
+                       "parallelism": f"batch-shard x{world}" + (" + 1 RCCL all_gather" if world > 1 else "")},
+            "finite": ok,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(state, T, args.cpu_seconds)
+            line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,113 @@
+/*
+ * savad.h -- C ABI of libsavad.so: the MI355X (gfx950) self-attentive-VAD forward pass.
+ *
+ * This is the drop-in boundary for ONE path of voithru/voice-activity-detection: the call
+ *     model_outputs = self.model(features=batch_inputs["feature"])        vad/predictor.py:224
+ * i.e. SelfAttentiveVAD.forward (vad/models/self_attention.py:23-28, blocks in
+ * vad/modeling/transformer.py), plus the two host loops either side of it in
+ * VADFromScratchPredictor.predict_probabilities: the window gather (vad/predictor.py:180-220)
+ * and the boosted-prediction scatter/softmax/mean (vad/predictor.py:238-258 and :95).
+ *
+ * The reference has no FFI (it is pure Python + torch.nn); the reference-side binding a
+ * maintainer would add is the ctypes stub shown in INTEGRATION.md -- in this repo it is
+ * voice_activity_detection_amd/_lib.py + model.py (an nn.Module with the reference's
+ * constructor signature and state_dict keys whose forward() calls savad_forward).
+ *
+ * Conventions: plain pointers and sizes only; all tensor pointers are DEVICE pointers unless
+ * stated; row-major contiguous; fp32.  Every call returns 0 on success or a negative
+ * SAVAD_E_* code, with a thread-local message in savad_last_error().  Kernels are enqueued
+ * on the caller's HIP stream (`stream` is a hipStream_t passed as void*; NULL = default
+ * stream); nothing here synchronises the device or allocates device memory inside
+ * savad_forward (the caller supplies the workspace).
+ */
+#ifndef SAVAD_H
+#define SAVAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAVAD_OK 0
+#define SAVAD_E_INVALID (-1)     /* bad argument / shape */
+#define SAVAD_E_UNSUPPORTED (-2) /* configuration outside what the gfx950 kernels implement */
+#define SAVAD_E_HIP (-3)         /* HIP runtime error (message carries hipGetErrorString) */
+#define SAVAD_E_STATE (-4)       /* e.g. forward before every parameter was set */
+#define SAVAD_E_NOKEY (-5)       /* unknown state_dict key */
+
+typedef struct savad_model* savad_handle;
+
+/* Mirrors SelfAttentiveVAD.__init__(feature_size, num_layers, d_model, dropout)
+ * (vad/models/self_attention.py:7-21; d_ff = 4*d_model :10, n_heads = 1 :18).  dropout is an
+ * inference no-op and is not part of the ABI.  Kernels implement d_model = 128 (the only value
+ * the reference ships: tests/configs/vad/train_config.yaml:7-10), feature_size % 8 == 0. */
+typedef struct savad_config {
+    int32_t feature_size;
+    int32_t num_layers;
+    int32_t d_model;
+} savad_config;
+
+/* Replaces SelfAttentiveVAD(...) construction + .to(device) (vad/predictor.py:277-279).
+ * Allocates the library-owned packed weights on the CURRENT HIP device. */
+int savad_create(const savad_config* cfg, savad_handle* out);
+void savad_destroy(savad_handle h);
+
+/* Replaces load_state_dict(checkpoint["state_dict"]) (vad/predictor.py:278), one tensor per call.
+ * `key` is the reference state_dict key (e.g. "encoder.layers.0.self_attention.query_projection.weight");
+ * `data` may be a host or a device pointer (hipMemcpyDefault); `numel` must match the key's shape.
+ * The copy is enqueued on `stream`; the library keeps its own packed copy (LayerNorm affine
+ * parameters are folded into the following Linear at the next forward). */
+int savad_set_param(savad_handle h, const char* key, const float* data, size_t numel, void* stream);
+/* state_dict introspection: number of keys, i-th key, its element count. */
+int savad_num_params(savad_handle h);
+const char* savad_param_key(savad_handle h, int i);
+size_t savad_param_numel(savad_handle h, int i);
+
+/* Bytes of scratch savad_forward needs for a [B,T,F] batch (activations + attention partials). */
+int savad_workspace_bytes(savad_handle h, int B, int T, size_t* bytes);
+
+/* Replaces self.model(features=x) (vad/predictor.py:224): x [B,T,F] fp32 -> out [B,T,2] fp32
+ * log-probabilities (LogSoftmax(dim=2), vad/models/self_attention.py:26-27).  Asynchronous on
+ * `stream`.  B == 0 or T == 0 is a no-op.  Masks do not exist on this path (always None in the
+ * reference: vad/modeling/transformer.py:24). */
+int savad_forward(savad_handle h, const float* x, int B, int T, float* out, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* Tuning knob: number of key-range splits of the attention stage (0 = automatic). */
+int savad_set_attention_splits(savad_handle h, int splits);
+/* Fills the names/durations of the kernels of the most recent savad_forward when profiling is
+ * enabled with savad_set_profiling(h, 1): the forward then brackets every launch with hipEvents on
+ * `stream` and synchronises at the end (bench.py uses this for the roofline block).
+ * Returns the number of kernels written (<= max). */
+int savad_set_profiling(savad_handle h, int enable);
+int savad_last_kernel_times(savad_handle h, const char** names, float* ms, int max);
+
+/* Window geometry of the predictor: W = 2*(half-1)/jump + 3 (vad/predictor.py:57-59); offsets =
+ * arange(-half,0,jump) ++ [0] ++ arange(1,half+1,jump) (vad/predictor.py:186-212). Returns W;
+ * offsets (host pointer, >= W ints) may be NULL. */
+int savad_window_offsets(int half, int jump, int32_t* offsets);
+
+/* Replaces the per-window python gather loop (vad/predictor.py:182-220): for item i in
+ * [first, first+count): windows[i-first][w][:] = feature[half+i+off[w]][:], positions[i-first][w] =
+ * half+i+off[w].  feature [N,F] fp32, windows [count,W,F] fp32, positions [count,W] int64 (may be NULL). */
+int savad_gather_windows(const float* feature, int N, int F, int half, int jump, int first, int count, float* windows,
+                         int64_t* positions, void* stream);
+
+/* Replaces the boosted prediction (vad/predictor.py:238-258 and :95):
+ *   boosted[N][W][2] = 0; boosted[positions[b][w]][w] = logp[b][w]  (scatter)
+ *   probs[n][w] = softmax(boosted[n][w])[1]  (unfilled slots = exactly 0.5, and averaged in)
+ *   mean[n] = mean_w probs[n][w]
+ * logp [count,W,2] fp32, positions [count,W] int64, boosted_ws [N,W,2] fp32 scratch,
+ * probs [N,W] fp32, mean [N] fp32 (may be NULL). */
+int savad_boost(const float* logp, const int64_t* positions, int count, int N, int W, float* boosted_ws, float* probs,
+                float* mean, void* stream);
+
+const char* savad_last_error(void);
+const char* savad_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAVAD_H */

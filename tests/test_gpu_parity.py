@@ -1,0 +1,269 @@
+"""GPU parity: the HIP path (through the C ABI, via the nn.Module mirror) against
+(a) golden vectors captured from the reference, (b) the CPU oracle on seeded inputs,
+(c) size-independent properties at BASELINE.json's full size.
+
+Tolerance: north_star asks for per-frame log-probabilities within 1e-4 (fp32) of the reference
+PyTorch-CPU path; TOL below is that bar, TIGHT is what the fp32-MFMA path actually holds."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+TIGHT = 3e-5
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (torch.cuda.is_available() is False)")
+    return torch
+
+
+def make_model(torch, state, F=80, L=3, D=128):
+    from voice_activity_detection_amd import SelfAttentiveVAD
+
+    m = SelfAttentiveVAD(F, L, D, 0.5)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    return m.to("cuda").eval()
+
+
+@pytest.fixture(scope="module")
+def model(torch_cuda, state1234):
+    return make_model(torch_cuda, state1234)
+
+
+def run(torch, model, x, splits=0):
+    model.attention_splits = splits
+    with torch.no_grad():
+        y = model(features=torch.from_numpy(x).to("cuda"))
+    torch.cuda.synchronize()
+    model.attention_splits = 0
+    return y.cpu().numpy()
+
+
+def feats(seed, shape, kind="logmel"):
+    from voice_activity_detection_amd.seeded import seeded_features
+
+    return seeded_features(seed, shape, kind)
+
+
+def test_native_library_is_loaded(torch_cuda, model):
+    from voice_activity_detection_amd import _lib
+
+    run(torch_cuda, model, feats(1, (1, 7, 80)))
+    with open("/proc/self/maps") as f:
+        assert "libsavad.so" in f.read()
+    assert b"gfx950" in _lib.load().savad_version()
+
+
+@pytest.mark.parametrize("tag,seed,shape,kind", [
+    ("g1_out", 101, (4, 7, 80), "logmel"),
+    ("g2_out", 102, (2, 800, 80), "logmel"),
+    ("g2n_out", 103, (3, 200, 80), "normal"),
+    ("g6_out", 600, (2, 40, 80), "logmel"),
+    ("g4_B1T7", 77, (1, 7, 80), "logmel"),
+])
+def test_golden(torch_cuda, model, golden, tag, seed, shape, kind):
+    y = run(torch_cuda, model, feats(seed, shape, kind))
+    assert y.shape == golden[tag].shape and y.dtype == np.float32
+    err = np.abs(y - golden[tag]).max()
+    assert err < TIGHT, err
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 10, 11, 16, 17, 31, 32, 33, 63, 64, 65, 100, 799, 801])
+def test_golden_edge_lengths(torch_cuda, model, golden, T):
+    y = run(torch_cuda, model, feats(400 + T, (3, T, 80)))
+    err = np.abs(y - golden[f"g4_T{T}"]).max()
+    assert err < TIGHT, err
+
+
+def test_golden_reference_batch_shape(torch_cuda, model, golden):
+    # [1000, 7, 80]: the only shape the reference pipeline runs (vad/predictor.py:180)
+    y = run(torch_cuda, model, feats(78, (1000, 7, 80)))
+    assert np.abs(y[:8] - golden["g4_B1000T7_head"]).max() < TIGHT
+    assert np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < TIGHT
+    assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g4_B1000T7_seqsum"]).max() < 14 * TIGHT
+
+
+def test_golden_config2_full_size(torch_cuda, model, golden):
+    # BASELINE.json configs[1]: [32, 800, 80] fp32, log-probs vs the reference within 1e-4
+    y = run(torch_cuda, model, feats(0, (32, 800, 80)))
+    assert np.abs(y[:2] - golden["g3_head"]).max() < TIGHT
+    assert np.abs(y[-2:] - golden["g3_tail"]).max() < TIGHT
+    # checksum of checksums over all 32 sequences
+    assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g3_seqsum"]).max() < 1600 * TIGHT
+    assert np.abs(np.abs(y.astype(np.float64)).sum(axis=(1, 2)) - golden["g3_abssum"]).max() < 1600 * TIGHT
+
+
+def test_golden_peaked_softmax(torch_cuda, golden):
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    m = make_model(torch_cuda, seeded_state_dict(4321, gain=4.0))
+    for splits in (0, 1, 3):
+        assert np.abs(run(torch_cuda, m, feats(700, (2, 96, 80)), splits) - golden["g7_out"]).max() < TOL
+        assert np.abs(run(torch_cuda, m, feats(701, (1, 800, 80)), splits) - golden["g7_T800"]).max() < TOL
+
+
+def test_golden_other_model_size(torch_cuda, golden):
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    m = make_model(torch_cuda, seeded_state_dict(88, feature_size=40, num_layers=2), F=40, L=2)
+    assert np.abs(run(torch_cuda, m, feats(800, (3, 50, 40))) - golden["g8_F40L2"]).max() < TIGHT
+
+
+@pytest.mark.parametrize("shape", [(5, 7, 80), (3, 45, 80), (2, 257, 80), (9, 33, 80), (37, 3, 80)])
+def test_against_oracle(torch_cuda, model, state1234, shape):
+    from oracle import oracle
+
+    x = feats(hash(shape) % 10000, shape)
+    ref = oracle.forward(state1234, x, acc64=True)
+    err = np.abs(run(torch_cuda, model, x) - ref).max()
+    assert err < TIGHT, err
+
+
+@pytest.mark.parametrize("splits", [1, 2, 5, 8])
+def test_attention_split_invariance(torch_cuda, model, golden, splits):
+    y = run(torch_cuda, model, feats(102, (2, 800, 80)), splits)
+    assert np.abs(y - golden["g2_out"]).max() < TIGHT
+
+
+def test_properties_full_size(torch_cuda, model):
+    # size-independent properties at config-2 size: normalisation, batch-permutation equivariance
+    # (sequences are independent: bit-exact), determinism
+    x = feats(5, (32, 800, 80))
+    y = run(torch_cuda, model, x)
+    assert np.isfinite(y).all()
+    assert np.abs(np.logaddexp(y[..., 0], y[..., 1])).max() < 2e-6
+    perm = np.random.default_rng(0).permutation(32)
+    yp = run(torch_cuda, model, x[perm])
+    assert np.array_equal(yp, y[perm])
+    assert np.array_equal(run(torch_cuda, model, x), y)
+    # a sequence evaluated alone equals the same sequence inside the batch (bit-exact)
+    assert np.array_equal(run(torch_cuda, model, x[7:8], splits=1), run(torch_cuda, model, x, splits=1)[7:8])
+
+
+def test_empty_and_call_forms(torch_cuda, model):
+    torch = torch_cuda
+    assert run(torch, model, np.zeros((0, 7, 80), np.float32)).shape == (0, 7, 2)
+    x = torch.from_numpy(feats(3, (2, 9, 80))).cuda()
+    with torch.no_grad():
+        a = model(features=x)      # vad/predictor.py:224
+        b = model(x)               # vad/model_runner.py:32
+    assert torch.equal(a, b) and a.is_contiguous() and a.dtype == torch.float32 and a.device == x.device
+    # downstream ops the caller applies (vad/predictor.py:225,247)
+    p = torch.nn.functional.softmax(a, dim=-1).view(-1, 2)[:, 1]
+    assert p.shape == (18,)
+    assert a.cpu().numpy().shape == (2, 9, 2)
+    with pytest.raises(ValueError):
+        model(features=torch.zeros(2, 9, 81, device="cuda"))
+
+
+def test_pe_cache_growth(torch_cuda, state1234):
+    # PE cache starts at 10 frames and regrows on demand (vad/modeling/transformer.py:392-397)
+    from oracle import oracle
+
+    m = make_model(torch_cuda, state1234)
+    for T in (4, 10, 11, 90, 30, 400):
+        x = feats(900 + T, (2, T, 80))
+        assert np.abs(run(torch_cuda, m, x) - oracle.forward(state1234, x)).max() < TIGHT
+
+
+def test_weight_update_is_seen(torch_cuda, state1234):
+    from oracle import oracle
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    torch = torch_cuda
+    m = make_model(torch, state1234)
+    x = feats(11, (3, 20, 80))
+    y0 = run(torch, m, x)
+    st2 = seeded_state_dict(999)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in st2.items()})
+    y1 = run(torch, m, x)
+    assert np.abs(y1 - oracle.forward(st2, x)).max() < TIGHT
+    assert np.abs(y1 - y0).max() > 1e-3
+    with torch.no_grad():
+        m.classifier.bias.add_(1.0)
+    st2["classifier.bias"] = st2["classifier.bias"] + 1.0
+    assert np.abs(run(torch, m, x) - oracle.forward(st2, x)).max() < TIGHT
+
+
+@pytest.mark.parametrize("tag,n,seed", [("g5", 1022, 500), ("g5b", 2100, 501), ("g5c", 39, 502)])
+def test_predictor_level_golden(torch_cuda, model, golden, tag, n, seed):
+    from voice_activity_detection_amd import VADFromScratchPredictor
+
+    pred = VADFromScratchPredictor(model, "cuda")
+    assert pred.context_window_frames == 7
+    feat = feats(seed, (n, 80))
+    probs = pred.predict_probabilities(feat)
+    assert probs.shape == golden[f"{tag}_probs"].shape and probs.dtype == np.float32
+    assert np.abs(probs - golden[f"{tag}_probs"]).max() < TIGHT
+    assert (probs == 0.5).sum() == (golden[f"{tag}_probs"] == 0.5).sum()  # unfilled slots: exactly 0.5
+    assert np.abs(pred.predict_boosted(feat) - golden[f"{tag}_mean"]).max() < TIGHT
+    # chunking is an implementation detail: one big chunk gives the same answer
+    big = VADFromScratchPredictor(model, "cuda", chunk_size=1 << 20)
+    assert np.abs(big.predict_probabilities(feat) - probs).max() < 1e-6
+
+
+def test_gather_and_boost_bit_exact(torch_cuda):
+    """Index/byte work is bit-exact against the oracle."""
+    from oracle import oracle
+    from voice_activity_detection_amd import _lib
+
+    torch = torch_cuda
+    lib = _lib.load()
+    feat = feats(42, (300, 80))
+    win_ref, pos_ref = oracle.gather_windows(feat, 19, 9, 5, 200)
+    d_feat = torch.from_numpy(feat).cuda()
+    win = torch.empty((200, 7, 80), device="cuda")
+    pos = torch.empty((200, 7), dtype=torch.int64, device="cuda")
+    _lib.check(lib.savad_gather_windows(ctypes.c_void_p(d_feat.data_ptr()), 300, 80, 19, 9, 5, 200,
+                                        ctypes.c_void_p(win.data_ptr()), ctypes.c_void_p(pos.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(win.cpu().numpy(), win_ref) and np.array_equal(pos.cpu().numpy(), pos_ref)
+    logp = np.log(np.random.default_rng(1).dirichlet([1, 1], size=(200, 7))).astype(np.float32)
+    probs_ref, mean_ref = oracle.boost(logp, pos_ref, 300)
+    d_logp = torch.from_numpy(logp).cuda()
+    boosted = torch.empty((300, 7, 2), device="cuda")
+    probs = torch.empty((300, 7), device="cuda")
+    mean = torch.empty((300,), device="cuda")
+    _lib.check(lib.savad_boost(ctypes.c_void_p(d_logp.data_ptr()), ctypes.c_void_p(pos.data_ptr()), 200, 300, 7,
+                               ctypes.c_void_p(boosted.data_ptr()), ctypes.c_void_p(probs.data_ptr()),
+                               ctypes.c_void_p(mean.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.abs(probs.cpu().numpy() - probs_ref).max() < 2e-7  # expf on device vs libm: <= 1 ulp
+    assert np.abs(mean.cpu().numpy() - mean_ref).max() < 2e-7
+    # out-of-range windows are rejected, not read
+    rc = lib.savad_gather_windows(ctypes.c_void_p(d_feat.data_ptr()), 300, 80, 19, 9, 100, 200,
+                                  ctypes.c_void_p(win.data_ptr()), ctypes.c_void_p(pos.data_ptr()), None)
+    assert rc == -1 and b"outside" in lib.savad_last_error()
+
+
+def test_c_abi_error_behaviour(torch_cuda):
+    from voice_activity_detection_amd import _lib
+
+    torch = torch_cuda
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.savad_create(ctypes.byref(_lib.savad_config(80, 3, 64)), ctypes.byref(h)) == -2  # unsupported d_model
+    assert lib.savad_create(ctypes.byref(_lib.savad_config(81, 3, 128)), ctypes.byref(h)) == -2
+    _lib.check(lib.savad_create(ctypes.byref(_lib.savad_config(80, 3, 128)), ctypes.byref(h)))
+    assert lib.savad_num_params(h) == 54
+    w = torch.zeros(128 * 80, device="cuda")
+    assert lib.savad_set_param(h, b"no.such.key", ctypes.c_void_p(w.data_ptr()), 128 * 80, None) == -5
+    assert lib.savad_set_param(h, b"input_layer.0.weight", ctypes.c_void_p(w.data_ptr()), 17, None) == -1
+    _lib.check(lib.savad_set_param(h, b"input_layer.0.weight", ctypes.c_void_p(w.data_ptr()), 128 * 80, None))
+    n = ctypes.c_size_t()
+    _lib.check(lib.savad_workspace_bytes(h, 2, 7, ctypes.byref(n)))
+    x = torch.zeros(2, 7, 80, device="cuda")
+    out = torch.zeros(2, 7, 2, device="cuda")
+    ws = torch.empty(n.value, dtype=torch.uint8, device="cuda")
+    args = (ctypes.c_void_p(x.data_ptr()), 2, 7, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()))
+    assert lib.savad_forward(h, *args, n.value, None) == -4  # parameters missing
+    assert b"never set" in lib.savad_last_error()
+    assert lib.savad_forward(h, *args, 16, None) == -1       # workspace too small
+    lib.savad_destroy(h)

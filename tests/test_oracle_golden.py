@@ -91,3 +91,15 @@ def test_g3_config2_checksums(golden, state1234):
     assert np.abs(y[:2] - golden["g3_head"]).max() < TOL
     assert np.abs(y[-2:] - golden["g3_tail"]).max() < TOL
     assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g3_seqsum"]).max() < 1600 * TOL
+
+
+def test_torch_port_matches_golden(golden, state1234):
+    import torch
+
+    from oracle import torch_port
+
+    st = {k: torch.from_numpy(v) for k, v in state1234.items()}
+    y = torch_port.forward(st, torch.from_numpy(seeded_features(102, (2, 800, 80)))).numpy()
+    assert np.abs(y - golden["g2_out"]).max() < TOL
+    y = torch_port.forward(st, torch.from_numpy(seeded_features(101, (4, 7, 80)))).numpy()
+    assert np.abs(y - golden["g1_out"]).max() < TOL

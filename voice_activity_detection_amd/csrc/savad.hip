@@ -1,0 +1,483 @@
+// savad.hip -- host side of libsavad.so: the C ABI declared in include/savad.h.
+// Owns the packed weights, the positional-encoding cache, and the 7-launch forward schedule:
+//   input_qkv -> [attention(l) -> row(l)] x L      (row(L-1) ends in classifier + log-softmax)
+#include "savad_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/savad.h"
+
+#define SAVAD_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(SAVAD_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                        \
+    } while (0)
+
+struct Param {
+    std::string key;
+    size_t numel;
+    size_t off;  // float offset into d_raw
+    bool set;
+};
+
+constexpr int MAX_EVENTS = 64;
+
+}  // namespace
+
+struct savad_model {
+    savad_config cfg;
+    std::vector<Param> params;
+    float* d_raw = nullptr;     // parameters exactly as handed over (state_dict layout)
+    float* d_packed = nullptr;  // LayerNorm-folded weights
+    size_t raw_floats = 0, packed_floats = 0;
+    bool dirty = true;
+    // positional-encoding cache (mirrors SinusoidalPositionalEncoding: rebuilt when T grows,
+    // vad/modeling/transformer.py:392-397; initial length 10: vad/models/self_attention.py:14)
+    float* d_pe = nullptr;
+    int pe_len = 0;
+    std::vector<float> h_pe;
+    int splits = 0;
+    // profiling
+    int prof_capacity = 0, prof_used = 0, prof_nk = 0;
+    std::vector<hipEvent_t> events;  // prof_capacity * MAX_EVENTS
+    std::vector<const char*> knames;
+
+    // raw offsets
+    size_t r_win, r_bin, r_lnf_w, r_lnf_b, r_wc, r_bc;
+    struct LayerRaw {
+        size_t wq, bq, wk, bk, wv, bv, wo, bo, ln1w, ln1b, w1, b1, w2, b2, ln2w, ln2b;
+    };
+    std::vector<LayerRaw> lr;
+    // packed offsets
+    struct LayerPacked {
+        size_t wqkv, bqkv, w1, b1;
+    };
+    std::vector<LayerPacked> lp;
+    size_t p_wc, p_bc;
+};
+
+namespace {
+
+using namespace savad;
+
+size_t add_param(savad_model* m, const std::string& key, size_t numel) {
+    const size_t off = m->raw_floats;
+    m->params.push_back(Param{key, numel, off, false});
+    m->raw_floats += (numel + 3) & ~size_t(3);  // keep every tensor 16-byte aligned
+    return off;
+}
+
+int choose_splits(const savad_model* m, int B, int T) {
+    if (T <= 32) return 1;
+    const int NT = (T + 31) / 32, QB = NT;
+    if (m->splits > 0) return m->splits < NT ? m->splits : NT;
+    // Work quantisation model: 256 CUs, 4-wave workgroups, a wave walks ceil(NT/S) key tiles.
+    // A split costs about half a tile of extra traffic (partials written and re-read); take S > 1
+    // only when it beats the unsplit schedule by more than 7 %.
+    auto cost = [&](int S) {
+        const long wgs = (long)B * ((QB * S + 3) / 4);
+        return (double)((wgs + 255) / 256) * ((NT + S - 1) / S + 0.5);
+    };
+    const double cost1 = cost(1);
+    double best = cost1;
+    int bestS = 1;
+    for (int S = 2; S <= 8 && S <= NT; ++S) {
+        const double cs = cost(S);
+        if (cs < 0.93 * cost1 && cs < best) {
+            best = cs;
+            bestS = S;
+        }
+    }
+    return bestS;
+}
+
+struct Workspace {
+    size_t rows, rows_pad;
+    int S;
+    size_t h, q, k, v, opart, ml, total;  // float offsets
+};
+
+Workspace plan(const savad_model* m, int B, int T) {
+    Workspace w;
+    w.rows = (size_t)B * T;
+    w.rows_pad = (w.rows + TILE - 1) / TILE * TILE;
+    w.S = choose_splits(m, B, T);
+    size_t off = 0;
+    w.h = off;
+    off += w.rows_pad * D;
+    w.q = off;
+    off += (w.rows_pad + TILE) * D;  // +32 rows of slack: key/value tiles may over-read the last block
+    w.k = off;
+    off += (w.rows_pad + TILE) * D;
+    w.v = off;
+    off += (w.rows_pad + TILE) * D;
+    w.opart = off;
+    off += (size_t)w.S * w.rows_pad * D;
+    w.ml = off;
+    off += (size_t)w.S * w.rows_pad * 2;
+    w.total = off;
+    return w;
+}
+
+// a3: vad/modeling/transformer.py:403-414 (fp32 semantics), pre-divided by sqrt(D) (:389,401)
+void build_pe(std::vector<float>& pe, int T) {
+    pe.resize((size_t)T * D);
+    const float cexp = (float)(-(log(10000.0) / (double)D));
+    const float scale = (float)sqrt((double)D);
+    for (int i = 0; i < D / 2; ++i) {
+        const float arg = (float)(2 * i) * cexp;
+        const float wv = (float)exp((double)arg);
+        for (int t = 0; t < T; ++t) {
+            const float a = (float)t * wv;
+            pe[(size_t)t * D + 2 * i] = (float)sin((double)a) / scale;
+            pe[(size_t)t * D + 2 * i + 1] = (float)cos((double)a) / scale;
+        }
+    }
+}
+
+int ensure_pe(savad_model* m, int T, hipStream_t st) {
+    if (T <= m->pe_len) return SAVAD_OK;
+    int cap = m->pe_len > 0 ? m->pe_len : 10;
+    while (cap < T) cap *= 2;
+    if (m->d_pe) {
+        HIP_TRY(hipStreamSynchronize(st));  // kernels of earlier forwards may still read the old table
+        HIP_TRY(hipFree(m->d_pe));
+        m->d_pe = nullptr;
+        m->pe_len = 0;
+    }
+    HIP_TRY(hipMalloc(&m->d_pe, sizeof(float) * (size_t)cap * D));
+    build_pe(m->h_pe, cap);
+    HIP_TRY(hipMemcpyAsync(m->d_pe, m->h_pe.data(), sizeof(float) * (size_t)cap * D, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // h_pe is pageable and reused
+    m->pe_len = cap;
+    return SAVAD_OK;
+}
+
+int fold(savad_model* m, hipStream_t st, size_t w, size_t b, size_t g, size_t be, size_t wout, size_t bout, int N,
+         int K) {
+    hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(128), 0, st, m->d_raw + w, m->d_raw + b, m->d_raw + g,
+                       m->d_raw + be, m->d_packed + wout, m->d_packed + bout, K);
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
+int prepare_weights(savad_model* m, hipStream_t st) {
+    if (!m->dirty) return SAVAD_OK;
+    for (const Param& p : m->params)
+        if (!p.set) return fail(SAVAD_E_STATE, "parameter '%s' was never set", p.key.c_str());
+    const int L = m->cfg.num_layers;
+    for (int l = 0; l < L; ++l) {
+        const auto& r = m->lr[l];
+        const auto& p = m->lp[l];
+        int rc;
+        if ((rc = fold(m, st, r.wq, r.bq, r.ln1w, r.ln1b, p.wqkv, p.bqkv, D, D))) return rc;
+        if ((rc = fold(m, st, r.wk, r.bk, r.ln1w, r.ln1b, p.wqkv + (size_t)D * D, p.bqkv + D, D, D))) return rc;
+        if ((rc = fold(m, st, r.wv, r.bv, r.ln1w, r.ln1b, p.wqkv + (size_t)2 * D * D, p.bqkv + 2 * D, D, D))) return rc;
+        if ((rc = fold(m, st, r.w1, r.b1, r.ln2w, r.ln2b, p.w1, p.b1, DFF, D))) return rc;
+    }
+    int rc = fold(m, st, m->r_wc, m->r_bc, m->r_lnf_w, m->r_lnf_b, m->p_wc, m->p_bc, 2, D);
+    if (rc) return rc;
+    m->dirty = false;
+    return SAVAD_OK;
+}
+
+struct Prof {
+    savad_model* m;
+    hipStream_t st;
+    hipEvent_t* ev;
+    int n;
+    Prof(savad_model* mm, hipStream_t s) : m(mm), st(s), ev(nullptr), n(0) {
+        if (m->prof_capacity > 0 && m->prof_used < m->prof_capacity) {
+            ev = m->events.data() + (size_t)m->prof_used * MAX_EVENTS;
+            m->knames.clear();
+            hipEventRecord(ev[0], st);
+        }
+    }
+    void mark(const char* name) {
+        if (!ev || n + 1 >= MAX_EVENTS) return;
+        ++n;
+        hipEventRecord(ev[n], st);
+        m->knames.push_back(name);
+    }
+    void done() {
+        if (!ev) return;
+        m->prof_nk = n;
+        m->prof_used++;
+    }
+};
+
+}  // namespace
+
+SAVAD_EXPORT const char* savad_last_error(void) { return g_err; }
+SAVAD_EXPORT const char* savad_version(void) { return "savad 0.1 (gfx950, fp32 MFMA)"; }
+
+SAVAD_EXPORT int savad_create(const savad_config* cfg, savad_handle* out) {
+    if (!cfg || !out) return fail(SAVAD_E_INVALID, "null argument");
+    if (cfg->d_model != D)
+        return fail(SAVAD_E_UNSUPPORTED, "d_model=%d: the gfx950 kernels implement d_model=128 (the reference's only config)",
+                    cfg->d_model);
+    if (cfg->feature_size <= 0 || cfg->feature_size % 8)
+        return fail(SAVAD_E_UNSUPPORTED, "feature_size=%d must be a positive multiple of 8", cfg->feature_size);
+    if (cfg->num_layers < 1 || cfg->num_layers > 64) return fail(SAVAD_E_INVALID, "num_layers=%d", cfg->num_layers);
+    savad_model* m = new savad_model();
+    m->cfg = *cfg;
+    const int F = cfg->feature_size, L = cfg->num_layers;
+    // state_dict inventory: SURVEY.md section 8a / vad/models/self_attention.py:7-21
+    m->r_win = add_param(m, "input_layer.0.weight", (size_t)D * F);
+    m->r_bin = add_param(m, "input_layer.0.bias", D);
+    m->lr.resize(L);
+    m->lp.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "encoder.layers." + std::to_string(l) + ".";
+        auto& r = m->lr[l];
+        r.wq = add_param(m, p + "self_attention.query_projection.weight", (size_t)D * D);
+        r.bq = add_param(m, p + "self_attention.query_projection.bias", D);
+        r.wk = add_param(m, p + "self_attention.key_projection.weight", (size_t)D * D);
+        r.bk = add_param(m, p + "self_attention.key_projection.bias", D);
+        r.wv = add_param(m, p + "self_attention.value_projection.weight", (size_t)D * D);
+        r.bv = add_param(m, p + "self_attention.value_projection.bias", D);
+        r.wo = add_param(m, p + "self_attention.final_projection.weight", (size_t)D * D);
+        r.bo = add_param(m, p + "self_attention.final_projection.bias", D);
+        r.ln1w = add_param(m, p + "self_attention_sublayer.layer_norm.weight", D);
+        r.ln1b = add_param(m, p + "self_attention_sublayer.layer_norm.bias", D);
+        r.w1 = add_param(m, p + "feed_forward.feed_forward.0.weight", (size_t)DFF * D);
+        r.b1 = add_param(m, p + "feed_forward.feed_forward.0.bias", DFF);
+        r.w2 = add_param(m, p + "feed_forward.feed_forward.3.weight", (size_t)D * DFF);
+        r.b2 = add_param(m, p + "feed_forward.feed_forward.3.bias", D);
+        r.ln2w = add_param(m, p + "feed_forward_sublayer.layer_norm.weight", D);
+        r.ln2b = add_param(m, p + "feed_forward_sublayer.layer_norm.bias", D);
+        auto& q = m->lp[l];
+        q.wqkv = m->packed_floats;
+        m->packed_floats += (size_t)3 * D * D;
+        q.bqkv = m->packed_floats;
+        m->packed_floats += 3 * D;
+        q.w1 = m->packed_floats;
+        m->packed_floats += (size_t)DFF * D;
+        q.b1 = m->packed_floats;
+        m->packed_floats += DFF;
+    }
+    m->r_lnf_w = add_param(m, "encoder.layer_norm.weight", D);
+    m->r_lnf_b = add_param(m, "encoder.layer_norm.bias", D);
+    m->r_wc = add_param(m, "classifier.weight", 2 * D);
+    m->r_bc = add_param(m, "classifier.bias", 2);
+    m->p_wc = m->packed_floats;
+    m->packed_floats += 2 * D;
+    m->p_bc = m->packed_floats;
+    m->packed_floats += 4;
+    hipError_t e = hipMalloc(&m->d_raw, sizeof(float) * m->raw_floats);
+    if (e == hipSuccess) e = hipMalloc(&m->d_packed, sizeof(float) * m->packed_floats);
+    if (e != hipSuccess) {
+        if (m->d_raw) hipFree(m->d_raw);
+        delete m;
+        return fail(SAVAD_E_HIP, "hipMalloc(weights): %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return SAVAD_OK;
+}
+
+SAVAD_EXPORT void savad_destroy(savad_handle m) {
+    if (!m) return;
+    for (hipEvent_t e : m->events) hipEventDestroy(e);
+    if (m->d_raw) hipFree(m->d_raw);
+    if (m->d_packed) hipFree(m->d_packed);
+    if (m->d_pe) hipFree(m->d_pe);
+    delete m;
+}
+
+SAVAD_EXPORT int savad_num_params(savad_handle m) { return m ? (int)m->params.size() : 0; }
+SAVAD_EXPORT const char* savad_param_key(savad_handle m, int i) {
+    return (m && i >= 0 && i < (int)m->params.size()) ? m->params[i].key.c_str() : nullptr;
+}
+SAVAD_EXPORT size_t savad_param_numel(savad_handle m, int i) {
+    return (m && i >= 0 && i < (int)m->params.size()) ? m->params[i].numel : 0;
+}
+
+SAVAD_EXPORT int savad_set_param(savad_handle m, const char* key, const float* data, size_t numel, void* stream) {
+    if (!m || !key || !data) return fail(SAVAD_E_INVALID, "null argument");
+    for (Param& p : m->params) {
+        if (p.key != key) continue;
+        if (p.numel != numel)
+            return fail(SAVAD_E_INVALID, "size mismatch for '%s': got %zu elements, expected %zu", key, numel, p.numel);
+        HIP_TRY(hipMemcpyAsync(m->d_raw + p.off, data, sizeof(float) * numel, hipMemcpyDefault, (hipStream_t)stream));
+        p.set = true;
+        m->dirty = true;
+        return SAVAD_OK;
+    }
+    return fail(SAVAD_E_NOKEY, "unexpected key '%s' in state_dict", key);
+}
+
+SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
+    if (!m || splits < 0 || splits > 64) return fail(SAVAD_E_INVALID, "splits=%d", splits);
+    m->splits = splits;
+    return SAVAD_OK;
+}
+
+SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* bytes) {
+    if (!m || !bytes || B < 0 || T < 0) return fail(SAVAD_E_INVALID, "bad argument");
+    if ((double)B * T * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "B*T=%ld rows exceed the 32-bit tile index range", (long)B * T);
+    *bytes = (B == 0 || T == 0) ? 0 : plan(m, B, T).total * sizeof(float);
+    return SAVAD_OK;
+}
+
+SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, float* out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!m) return fail(SAVAD_E_INVALID, "null handle");
+    if (B < 0 || T < 0) return fail(SAVAD_E_INVALID, "negative shape B=%d T=%d", B, T);
+    if (B == 0 || T == 0) return SAVAD_OK;
+    if (!x || !out || !workspace) return fail(SAVAD_E_INVALID, "null tensor pointer");
+    if ((double)B * T * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "B*T too large");
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)workspace) & 15)
+        return fail(SAVAD_E_INVALID, "x, out and workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const Workspace ws = plan(m, B, T);
+    if (workspace_bytes < ws.total * sizeof(float))
+        return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, ws.total * sizeof(float));
+    int rc;
+    if ((rc = prepare_weights(m, st))) return rc;
+    if ((rc = ensure_pe(m, T, st))) return rc;
+
+    float* W = (float*)workspace;
+    float *hb = W + ws.h, *q = W + ws.q, *k = W + ws.k, *v = W + ws.v, *op = W + ws.opart, *ml = W + ws.ml;
+    const int F = m->cfg.feature_size, L = m->cfg.num_layers;
+    const int tiles = (int)(ws.rows_pad / TILE);
+    const float c = (float)(1.4426950408889634 / sqrt((double)D));  // log2(e) / sqrt(d_head)
+    const float* R = m->d_raw;
+    const float* P = m->d_packed;
+    Prof prof(m, st);
+
+    hipLaunchKernelGGL(input_qkv_kernel, dim3(tiles), dim3(256), 0, st, x, (int)ws.rows, T, F, R + m->r_win,
+                       R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
+    prof.mark("input_qkv");
+    for (int l = 0; l < L; ++l) {
+        if (T <= 32) {
+            const int G = 32 / T, nblk = (B + G - 1) / G;
+            hipLaunchKernelGGL(attention_kernel<true>, dim3((nblk + 3) / 4), dim3(256), 0, st, q, k, v, op, ml, B, T,
+                               (int)ws.rows, (int)ws.rows_pad, 1, c);
+        } else {
+            const int QB = (T + 31) / 32, wgs = (QB * ws.S + 3) / 4;
+            const int grid = 8 * ((B + 7) / 8) * wgs;
+            hipLaunchKernelGGL(attention_kernel<false>, dim3(grid), dim3(256), 0, st, q, k, v, op, ml, B, T,
+                               (int)ws.rows, (int)ws.rows_pad, ws.S, c);
+        }
+        prof.mark("attention");
+        const auto& r = m->lr[l];
+        const auto& p = m->lp[l];
+        if (l + 1 < L) {
+            hipLaunchKernelGGL(row_kernel<false>, dim3(tiles), dim3(256), 0, st, op, ml, ws.S, (int)ws.rows,
+                               (int)ws.rows_pad, c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2,
+                               P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv, q, k, v, out);
+            prof.mark("row");
+        } else {
+            hipLaunchKernelGGL(row_kernel<true>, dim3(tiles), dim3(256), 0, st, op, ml, ws.S, (int)ws.rows,
+                               (int)ws.rows_pad, c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2,
+                               P + m->p_wc, P + m->p_bc, q, k, v, out);
+            prof.mark("row_last");
+        }
+    }
+    prof.done();
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
+SAVAD_EXPORT int savad_set_profiling(savad_handle m, int capacity) {
+    if (!m || capacity < 0) return fail(SAVAD_E_INVALID, "bad argument");
+    for (hipEvent_t e : m->events) hipEventDestroy(e);
+    m->events.clear();
+    m->prof_capacity = capacity;
+    m->prof_used = 0;
+    m->prof_nk = 0;
+    m->events.resize((size_t)capacity * MAX_EVENTS);
+    for (auto& e : m->events) HIP_TRY(hipEventCreate(&e));
+    return SAVAD_OK;
+}
+
+// Average duration (ms) of each launch position over the profiled forwards recorded since
+// savad_set_profiling; the caller must have synchronised the stream.
+SAVAD_EXPORT int savad_last_kernel_times(savad_handle m, const char** names, float* ms, int max) {
+    if (!m || m->prof_used == 0) return 0;
+    const int nk = m->prof_nk < max ? m->prof_nk : max;
+    for (int i = 0; i < nk; ++i) {
+        double acc = 0;
+        for (int f = 0; f < m->prof_used; ++f) {
+            hipEvent_t* ev = m->events.data() + (size_t)f * MAX_EVENTS;
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) != hipSuccess) return fail(SAVAD_E_HIP, "hipEventElapsedTime failed");
+            acc += t;
+        }
+        ms[i] = (float)(acc / m->prof_used);
+        if (names) names[i] = m->knames[i];
+    }
+    m->prof_used = 0;
+    return nk;
+}
+
+SAVAD_EXPORT int savad_window_offsets(int half, int jump, int32_t* offsets) {
+    if (half < 0 || jump <= 0) return fail(SAVAD_E_INVALID, "half=%d jump=%d", half, jump);
+    int w = 0;
+    for (int o = -half; o < 0; o += jump, ++w)
+        if (offsets) offsets[w] = o;
+    if (offsets) offsets[w] = 0;
+    ++w;
+    for (int o = 1; o < half + 1; o += jump, ++w)
+        if (offsets) offsets[w] = o;
+    return w;
+}
+
+SAVAD_EXPORT int savad_gather_windows(const float* feature, int N, int F, int half, int jump, int first, int count,
+                                      float* windows, int64_t* positions, void* stream) {
+    if (count == 0) return SAVAD_OK;
+    if (!feature || !windows || N <= 0 || F <= 0 || F % 4 || first < 0 || count < 0)
+        return fail(SAVAD_E_INVALID, "bad argument (F must be a multiple of 4)");
+    WindowOffsets wo;
+    int32_t off[256];
+    if (savad_window_offsets(half, jump, nullptr) > 64) return fail(SAVAD_E_UNSUPPORTED, "window longer than 64 frames");
+    wo.w = savad_window_offsets(half, jump, off);
+    for (int i = 0; i < wo.w; ++i) wo.off[i] = off[i];
+    if ((long)half + first + count - 1 + off[wo.w - 1] >= N || half + first + off[0] < 0)
+        return fail(SAVAD_E_INVALID, "window [%d,%d) reaches outside the %d feature frames", first, first + count, N);
+    const size_t total = (size_t)count * wo.w * (F / 4);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gather_windows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feature, F, half, first,
+                       count, wo, windows, positions);
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
+SAVAD_EXPORT int savad_boost(const float* logp, const int64_t* positions, int count, int N, int W, float* boosted_ws,
+                             float* probs, float* mean, void* stream) {
+    if (N <= 0) return SAVAD_OK;
+    if (!boosted_ws || !probs || W <= 0 || count < 0 || (count > 0 && (!logp || !positions)))
+        return fail(SAVAD_E_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(boosted_ws, 0, sizeof(float) * (size_t)N * W * 2, st));
+    if (count > 0) {
+        const size_t cw = (size_t)count * W;
+        const int grid = (int)((cw + 255) / 256 < 2048 ? (cw + 255) / 256 : 2048);
+        hipLaunchKernelGGL(boost_scatter_kernel, dim3(grid), dim3(256), 0, st, logp, positions, cw, W, boosted_ws);
+    }
+    const int grid2 = (N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048;
+    hipLaunchKernelGGL(boost_softmax_kernel, dim3(grid2), dim3(256), 0, st, boosted_ws, N, W, probs, mean);
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}

@@ -1,0 +1,488 @@
+// savad_kernels.h -- gfx950 (MI355X / CDNA4) device code of the self-attentive-VAD forward pass.
+//
+// Everything GEMM-shaped runs on the exact-fp32 matrix core instruction
+// v_mfma_f32_32x32x2_f32 (64 cycles, 4096 FLOP; 157.3 TF chip peak) in the TRANSPOSED form
+//
+//      Out^T[n][m] = sum_k W[n][k] * X[m][k]          A operand = weight rows, B operand = activation rows
+//
+// so that every activation a wave touches lives in ONE register layout, the "row layout":
+//
+//      lane = (m, h) = (lane & 31, lane >> 5);  a 32-feature block is 16 registers r = 4g+s,
+//      register r of lane (m,h) holds X[row m][feature 8g + 4h + s]                     (g,s in 0..3)
+//
+// which is simultaneously (i) the MFMA C/D layout of Out^T (row = (r&3)+8(r>>2)+4h = feature,
+// column = lane&31 = data row), (ii) a legal B-operand k-ordering for the next GEMM (the k-sum is
+// order-free as long as the A operand uses the same permutation: both halves read 4 consecutive
+// floats at 8G+4h, one 16-byte load), and (iii) row-per-lane, so LayerNorm, softmax max/sum, the
+// online-softmax rescale and log-softmax are lane-local plus ONE exchange between lane and lane^32.
+// No transposes, no LDS staging of operands: weights / K / V stream from L2 straight into the
+// A operand, activations stay in registers between chained GEMMs.
+//
+// Reference being restated (paths relative to /root/reference):
+//   vad/models/self_attention.py:23-28, vad/modeling/transformer.py:24-61,227-238,258-363,366-382,385-414.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace savad {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int D = 128;        // d_model (= d_head, n_heads = 1: vad/models/self_attention.py:18)
+constexpr int DFF = 4 * D;    // vad/models/self_attention.py:10
+constexpr int TILE = 32;      // data rows per MFMA tile / per workgroup of the row kernels
+constexpr int XLD = D + 4;    // LDS row stride (floats) of the 32x128 exchange buffer: conflict-free b128
+constexpr int PLD = 32 + 4;   // LDS row stride of one 32x32 split-K partial block
+constexpr float LN_EPS = 1e-5f;
+constexpr float NEG_BIG = -1.0e30f;
+
+#define SAVAD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }  // partner lane (m, 1-h)
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    return z;
+}
+
+// acc(32 features n0.. x 32 rows) += W[n0 + (lane&31)][0..127] . x[row][0..127]
+// wp = W + (n0 + (lane & 31)) * ldw + 4 * h
+__device__ __forceinline__ void gemm_k128(f32x16& acc, const float* __restrict__ wp, const f32x4 (&xg)[16]) {
+#pragma unroll
+    for (int G = 0; G < 16; ++G) {
+        const f32x4 w4 = ld4(wp + 8 * G);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = SAVAD_MFMA(w4[s], xg[G][s], acc);
+    }
+}
+
+// bias for the wave's feature block in row layout: b[n0 + 8g + 4h + s]
+__device__ __forceinline__ void add_bias(f32x16& acc, const float* __restrict__ b, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = ld4(b + 8 * g + 4 * h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[4 * g + s] += b4[s];
+    }
+}
+
+// row-layout 32-feature block <-> memory row (global or LDS): 4 x 16-byte pieces at 8g + 4h
+__device__ __forceinline__ void store_block(float* rowp /* &X[row][n0] */, const f32x16& v, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 t;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) t[s] = v[4 * g + s];
+        st4(rowp + 8 * g + 4 * h, t);
+    }
+}
+__device__ __forceinline__ void add_block(f32x16& v, const float* rowp, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 t = ld4(rowp + 8 * g + 4 * h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[4 * g + s] += t[s];
+    }
+}
+
+// Read full rows back from the LDS exchange buffer and apply LayerNorm WITHOUT the affine part
+// (gamma/beta are folded into the next Linear on the host side of the library, see fold_ln_kernel).
+// nn.LayerNorm: biased variance, eps = 1e-5 (vad/modeling/transformer.py:22,231); two-pass statistics.
+__device__ __forceinline__ void read_rows_layernorm(const float* xbuf, int m, int h, f32x4 (&xg)[16]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int G = 0; G < 16; ++G) {
+        xg[G] = ld4(xbuf + m * XLD + 8 * G + 4 * h);
+        s += (xg[G][0] + xg[G][1]) + (xg[G][2] + xg[G][3]);
+    }
+    s += xhalf(s);
+    const float mean = s * (1.0f / D);
+    float ss = 0.0f;
+#pragma unroll
+    for (int G = 0; G < 16; ++G) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = xg[G][e] - mean;
+            xg[G][e] = d;
+            ss += d * d;
+        }
+    }
+    ss += xhalf(ss);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + LN_EPS);
+#pragma unroll
+    for (int G = 0; G < 16; ++G) xg[G] *= rstd;
+}
+
+// LN1(next layer) + packed QKV projection for the wave's 32-feature block of each of q, k, v.
+// Wqkv: [3*D][D] (rows: query, key, value projection; LN affine folded), bqkv: [3*D].
+__device__ __forceinline__ void qkv_block(const f32x4 (&xg)[16], const float* __restrict__ Wqkv,
+                                          const float* __restrict__ bqkv, float* __restrict__ q,
+                                          float* __restrict__ k, float* __restrict__ v, size_t row, int w, int n, int h) {
+    float* dst[3] = {q, k, v};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        f32x16 acc = zero16();
+        gemm_k128(acc, Wqkv + (size_t)(D * j + 32 * w + n) * D + 4 * h, xg);
+        add_bias(acc, bqkv + D * j + 32 * w, h);
+        store_block(dst[j] + row * D + 32 * w, acc, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 1: input Linear(F, D) + sinusoidal PE / sqrt(D)  (vad/models/self_attention.py:12-16,24;
+// vad/modeling/transformer.py:392-401), then layer-0 LN + QKV (transformer.py:234-237,281-284).
+// One workgroup (4 waves) per 32 data rows; wave w owns output features [32w, 32w+32).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void input_qkv_kernel(
+    const float* __restrict__ x, int rows, int T, int F, const float* __restrict__ Win, const float* __restrict__ bin,
+    const float* __restrict__ pe /* [T][D], already / sqrt(D) */, const float* __restrict__ Wqkv,
+    const float* __restrict__ bqkv, float* __restrict__ hbuf, float* __restrict__ q, float* __restrict__ k,
+    float* __restrict__ v) {
+    __shared__ __attribute__((aligned(16))) float xbuf[TILE * XLD];
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t row = (size_t)blockIdx.x * TILE + m;
+    const bool valid = row < (size_t)rows;
+    const float* xp = x + (valid ? row : 0) * (size_t)F + 4 * h;
+    const float* wp = Win + (size_t)(32 * w + n) * F + 4 * h;
+
+    f32x16 acc = zero16();
+    for (int G = 0; G < F / 8; ++G) {
+        f32x4 x4 = ld4(xp + 8 * G);
+        if (!valid) x4 = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the batch stay finite (they are never stored to `out`)
+        const f32x4 w4 = ld4(wp + 8 * G);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = SAVAD_MFMA(w4[s], x4[s], acc);
+    }
+    add_bias(acc, bin + 32 * w, h);
+    const int t = (int)((valid ? row : 0) % (size_t)T);
+    add_block(acc, pe + (size_t)t * D + 32 * w, h);
+    store_block(hbuf + row * D + 32 * w, acc, h);  // residual stream h0
+    // V's 32 slack rows behind the last tile feed the PV product with probability exactly 0:
+    // they must be finite, so the last workgroup zeroes them once per forward.
+    if (blockIdx.x == gridDim.x - 1) store_block(v + (row + TILE) * D + 32 * w, zero16(), h);
+    store_block(xbuf + m * XLD + 32 * w, acc, h);
+    __syncthreads();
+    f32x4 xg[16];
+    read_rows_layernorm(xbuf, m, h, xg);
+    qkv_block(xg, Wqkv, bqkv, q, k, v, row, w, n, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 2: single-head scaled-dot-product attention, flash style (vad/modeling/transformer.py:
+// 305-346,351-363): S = q k^T / sqrt(d_head), softmax over keys, ctx = A v -- the [T,T] matrix is
+// never materialised (the reference discards it: transformer.py:50).
+// One WAVE per work item = (sequence, 32-query block, key split): Q stays in registers as the
+// B operand; S^T = K Q^T lands in row layout (query row per lane, 16 key scores per lane), so the
+// online softmax is lane-local; P feeds the PV MFMA as B operand unchanged; O^T = V^T P^T
+// accumulates in row layout.  Output: UNNORMALISED O plus (running max, running sum) per row and
+// split; the row kernel combines the splits and divides.
+// PACKED (T <= 32): one item = floor(32/T) whole sequences (block-diagonal mask), one key tile.
+// ---------------------------------------------------------------------------------------------
+template <bool PACKED>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, float* __restrict__ Opart,
+                                                           float* __restrict__ ml, int B, int T, int rows,
+                                                           int rows_pad, int S, float c /* log2(e)/sqrt(d_head) */) {
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    int s = 0, jt0 = 0, jt1 = 1;
+    size_t qrow, kbase;  // flat row of this lane's query; flat row of key 0 of the item
+    bool qvalid;
+    int tq = 0;          // PACKED: sequence slot of this lane's query inside the block
+    int rowsPB = 0;
+    if (PACKED) {
+        const int G = 32 / T;
+        rowsPB = G * T;
+        const int nblk = (B + G - 1) / G;
+        const int blk = blockIdx.x * 4 + w;
+        if (blk >= nblk) return;
+        kbase = (size_t)blk * rowsPB;
+        qrow = kbase + m;
+        qvalid = (m < rowsPB) && (qrow < (size_t)rows);
+        tq = m / T;
+    } else {
+        const int QB = (T + 31) / 32, NT = QB;
+        const int items = QB * S, wgs = (items + 3) / 4;
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;  // all items of a sequence on one XCD (shared K/V in its L2)
+        const int b = (i / wgs) * 8 + xcd;
+        const int item = (i % wgs) * 4 + w;
+        if (b >= B || item >= items) return;
+        s = item / QB;  // the 4 waves of a workgroup walk the same key range
+        const int qb = item % QB;
+        jt0 = (int)(((long)s * NT) / S);
+        jt1 = (int)(((long)(s + 1) * NT) / S);
+        kbase = (size_t)b * T;
+        qrow = kbase + 32 * qb + m;
+        qvalid = (32 * qb + m) < T;
+    }
+    // q/k/v carry 32 rows of slack behind rows_pad, so tiles may over-read without clamping:
+    // over-read K rows only produce masked scores, over-read V rows are zero (host memset).
+    f32x4 qg[16];
+#pragma unroll
+    for (int G = 0; G < 16; ++G) qg[G] = ld4(q + qrow * D + 8 * G + 4 * h);
+
+    f32x16 O[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
+    float m_run = NEG_BIG, l_run = 0.0f;
+
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const size_t k0 = kbase + 32 * (size_t)jt;
+        // ---- S^T tile = K Q^T : A = key rows (lane & 31 = key), B = Q
+        f32x16 sc = zero16();
+        gemm_k128(sc, k + (k0 + n) * D + 4 * h, qg);
+        // lane (m,h), register r: score of query m against key jk = 8(r>>2) + 4h + (r&3)
+        if (PACKED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
+                const bool ok = (jk < rowsPB) && (jk / T == tq) && (k0 + jk < (size_t)rows);
+                sc[r] = ok ? sc[r] : NEG_BIG;
+            }
+        } else if (32 * jt + 32 > T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
+                sc[r] = (32 * jt + jk < T) ? sc[r] : NEG_BIG;
+            }
+        }
+        // ---- online softmax (base-2 domain: p = 2^((s - m) * c))
+        float mx = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+        mx = fmaxf(mx, xhalf(mx));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        float rs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -mc));
+            rs += sc[r];
+        }
+        rs += xhalf(rs);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) O[nb] *= alpha;
+        // ---- O^T += V^T P^T : A = V^T (lane & 31 = output feature d, k index = key), B = P
+        const float* vp = v + (k0 + 4 * h) * D + n;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
+        }
+    }
+    if (qvalid) {
+        float* op = Opart + ((size_t)s * rows_pad + qrow) * D;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) store_block(op + 32 * nb, O[nb], h);
+        if (h == 0) *reinterpret_cast<f32x2*>(ml + ((size_t)s * rows_pad + qrow) * 2) = f32x2{m_run, l_run};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 3 (per layer): everything row-wise between two attention stages, for 32 data rows:
+//   combine attention splits -> final_projection + residual (transformer.py:347,237)
+//   -> LN + Linear(D,4D) + ReLU + Linear(4D,D) + residual (transformer.py:234-237,370-375)
+//   -> !LAST: next layer's LN + QKV (transformer.py:281-284)
+//       LAST: encoder LayerNorm + classifier Linear(D,2) + LogSoftmax (transformer.py:33;
+//             vad/models/self_attention.py:26-27)
+// 4 waves; wave w owns output features [32w,32w+32) of out-proj / QKV (N split) and hidden units
+// [128w,128w+128) of the FFN (K split, partial sums reduce-scattered through LDS once).
+// ---------------------------------------------------------------------------------------------
+template <bool LAST>
+__global__ __launch_bounds__(256, 2) void row_kernel(
+    const float* __restrict__ Opart, const float* __restrict__ ml, int S, int rows, int rows_pad, float c,
+    float* __restrict__ hbuf, const float* __restrict__ Wo, const float* __restrict__ bo,
+    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+    const float* __restrict__ b2, const float* __restrict__ Wn /* LAST ? Wc'[2][D] : Wqkv'[3D][D] */,
+    const float* __restrict__ bn, float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
+    float* __restrict__ out /* [rows][2] */) {
+    __shared__ __attribute__((aligned(16))) float lds[TILE * XLD + 12 * TILE * PLD];
+    float* xbuf = lds;
+    float* pbuf = lds + TILE * XLD;  // [dest block 4][src slot 3][32 rows][PLD]
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t row = (size_t)blockIdx.x * TILE + m;
+
+    // ---- phase 0: ctx = sum_s w_s O_s / sum_s w_s l_s   (rows are lane-local: all scalars per lane)
+    f32x4 xg[16];
+    {
+        float M = NEG_BIG;
+        for (int s = 0; s < S; ++s) M = fmaxf(M, ml[((size_t)s * rows_pad + row) * 2]);
+        float den = 0.0f;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) xg[G] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(ml + ((size_t)s * rows_pad + row) * 2);
+            const float ws = __builtin_amdgcn_exp2f((t[0] - M) * c);
+            den += ws * t[1];
+            const float* op = Opart + ((size_t)s * rows_pad + row) * D + 4 * h;
+#pragma unroll
+            for (int G = 0; G < 16; ++G) xg[G] += ws * ld4(op + 8 * G);
+        }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) xg[G] *= inv;
+    }
+    // ---- phase 1: h1 = ctx Wo^T + bo + h   (wave's 32 features)
+    f32x16 h1 = zero16();
+    gemm_k128(h1, Wo + (size_t)(32 * w + n) * D + 4 * h, xg);
+    add_bias(h1, bo + 32 * w, h);
+    add_block(h1, hbuf + row * D + 32 * w, h);
+    store_block(xbuf + m * XLD + 32 * w, h1, h);
+    __syncthreads();
+    read_rows_layernorm(xbuf, m, h, xg);
+    // ---- phase 2: FFN, hidden units [128w, 128w+128) in 4 chunks of 32; ReLU output feeds the
+    //      second GEMM as B operand straight from the accumulator registers
+    f32x16 o[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) o[nb] = zero16();
+#pragma unroll 1
+    for (int ch = 0; ch < 4; ++ch) {
+        const int hid0 = 128 * w + 32 * ch;
+        f32x16 a = zero16();
+        gemm_k128(a, W1 + (size_t)(hid0 + n) * D + 4 * h, xg);
+        add_bias(a, b1 + hid0, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const float* wp = W2 + (size_t)(32 * nb + n) * DFF + hid0 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w4 = ld4(wp + 8 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) o[nb] = SAVAD_MFMA(w4[s], a[4 * g + s], o[nb]);
+            }
+        }
+    }
+    // reduce-scatter the 4 K-split partials: wave w ends up with feature block w
+    f32x16 own = o[0];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb == w) {
+            own = o[nb];
+        } else {
+            const int slot = (w - nb - 1) & 3;
+            store_block(pbuf + ((nb * 3 + slot) * TILE + m) * PLD, o[nb], h);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int slot = 0; slot < 3; ++slot) add_block(own, pbuf + ((w * 3 + slot) * TILE + m) * PLD, h);
+    add_bias(own, b2 + 32 * w, h);
+    own += h1;  // residual onto the un-normalised stream (transformer.py:235-237)
+    if (!LAST) store_block(hbuf + row * D + 32 * w, own, h);
+    // ---- phase 3
+    store_block(xbuf + m * XLD + 32 * w, own, h);  // xbuf's last readers all passed the barrier above
+    __syncthreads();
+    read_rows_layernorm(xbuf, m, h, xg);
+    if (!LAST) {
+        qkv_block(xg, Wn, bn, q, k, v, row, w, n, h);
+    } else if (w == 0) {
+        float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const f32x4 c0 = ld4(Wn + 8 * G + 4 * h), c1 = ld4(Wn + D + 8 * G + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z0 = __builtin_fmaf(xg[G][e], c0[e], z0);
+                z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
+            }
+        }
+        z0 += xhalf(z0);
+        z1 += xhalf(z1);
+        z0 += bn[0];
+        z1 += bn[1];
+        const float mx = fmaxf(z0, z1);
+        const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+        if (h == 0 && row < (size_t)rows) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight preparation: fold a LayerNorm's affine parameters into the Linear that consumes it:
+//   LN(x) W^T + b = xhat (W diag(gamma))^T + (b + W beta)
+// One block per output row; beta term accumulated in fp64.
+// ---------------------------------------------------------------------------------------------
+__global__ void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, float* __restrict__ Wout, float* __restrict__ bout,
+                               int K) {
+    __shared__ double red[256];
+    const int nrow = blockIdx.x;
+    double acc = 0.0;
+    for (int kk = threadIdx.x; kk < K; kk += blockDim.x) {
+        const float wv = W[(size_t)nrow * K + kk];
+        Wout[(size_t)nrow * K + kk] = wv * gamma[kk];
+        acc += (double)wv * (double)beta[kk];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bout[nrow] = (float)((double)b[nrow] + red[0]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a13: window gather (vad/predictor.py:180-220).  One thread per output float4.
+// ---------------------------------------------------------------------------------------------
+struct WindowOffsets {
+    int w;
+    int off[64];
+};
+__global__ void gather_windows_kernel(const float* __restrict__ feature, int F, int half, int first, int count,
+                                      WindowOffsets wo, float* __restrict__ windows, int64_t* __restrict__ positions) {
+    const int f4 = F / 4;
+    const size_t total = (size_t)count * wo.w * f4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % f4);
+        const size_t iw = i / f4;
+        const int wi = (int)(iw % wo.w);
+        const size_t item = iw / wo.w;
+        const size_t pos = (size_t)half + first + item + wo.off[wi];
+        st4(windows + iw * F + 4 * c, ld4(feature + pos * F + 4 * c));
+        if (c == 0 && positions) positions[iw] = (int64_t)pos;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a14: boosted prediction (vad/predictor.py:238-258, :95): scatter, then softmax[...,1] and mean.
+// ---------------------------------------------------------------------------------------------
+__global__ void boost_scatter_kernel(const float* __restrict__ logp, const int64_t* __restrict__ positions,
+                                     size_t count_w, int W, float* __restrict__ boosted) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count_w; i += (size_t)gridDim.x * blockDim.x) {
+        const int wi = (int)(i % W);
+        const size_t p = (size_t)positions[i];
+        *reinterpret_cast<f32x2*>(boosted + (p * W + wi) * 2) = *reinterpret_cast<const f32x2*>(logp + i * 2);
+    }
+}
+__global__ void boost_softmax_kernel(const float* __restrict__ boosted, int N, int W, float* __restrict__ probs,
+                                     float* __restrict__ mean) {
+    for (int nrow = blockIdx.x * blockDim.x + threadIdx.x; nrow < N; nrow += gridDim.x * blockDim.x) {
+        float acc = 0.0f;
+        for (int wi = 0; wi < W; ++wi) {
+            const f32x2 z = *reinterpret_cast<const f32x2*>(boosted + ((size_t)nrow * W + wi) * 2);
+            const float mx = fmaxf(z[0], z[1]);
+            const float e0 = expf(z[0] - mx), e1 = expf(z[1] - mx);
+            const float p = e1 / (e0 + e1);
+            probs[(size_t)nrow * W + wi] = p;
+            acc += p;
+        }
+        if (mean) mean[nrow] = acc / (float)W;
+    }
+}
+
+}  // namespace savad

@@ -1,0 +1,180 @@
+"""`SelfAttentiveVAD` -- the reference's nn.Module surface over the MI355X forward pass.
+
+Drop-in for ``vad.models.self_attention.SelfAttentiveVAD`` (reference
+``vad/models/self_attention.py:6-28``): same constructor signature
+``(feature_size, num_layers, d_model, dropout)`` (``vad/models/model_factory.py:42-48``), same
+``state_dict`` keys (so ``load_state_dict(checkpoint["state_dict"])`` of
+``vad/predictor.py:278`` is strict-clean), same call forms ``model(features=x)``
+(``vad/predictor.py:224``) and ``model(x)`` (``vad/model_runner.py:32``), same result: a
+contiguous fp32 ``[B, T, 2]`` tensor of log-probabilities on the input's device.
+
+The submodules below are PARAMETER CONTAINERS only (they give the state_dict its reference
+key names); ``forward`` never calls them.  It hands raw device pointers to ``savad_forward``
+in ``libsavad.so`` (C ABI ``include/savad.h``), which runs hand-written gfx950 kernels on the
+caller's current HIP stream.  There is no CPU / eager fallback: a non-GPU input raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+
+class _Holder(nn.Module):
+    """Namespace module: only holds children so that state_dict keys match the reference."""
+
+
+def _attention_params(d_model: int) -> nn.Module:
+    m = _Holder()  # reference: MultiHeadAttention, vad/modeling/transformer.py:241-252
+    m.query_projection = nn.Linear(d_model, d_model)
+    m.key_projection = nn.Linear(d_model, d_model)
+    m.value_projection = nn.Linear(d_model, d_model)
+    m.final_projection = nn.Linear(d_model, d_model)
+    return m
+
+
+def _sublayer_params(d_model: int) -> nn.Module:
+    m = _Holder()  # reference: Sublayer, vad/modeling/transformer.py:227-232
+    m.layer_norm = nn.LayerNorm(d_model)
+    return m
+
+
+def _ffn_params(d_model: int, d_ff: int) -> nn.Module:
+    m = _Holder()  # reference: PositionwiseFeedForwardNetwork, vad/modeling/transformer.py:366-375
+    # indices 0 and 3 carry parameters (1 = ReLU, 2 = Dropout in the reference Sequential)
+    m.feed_forward = nn.ModuleDict({"0": nn.Linear(d_model, d_ff), "3": nn.Linear(d_ff, d_model)})
+    return m
+
+
+def _layer_params(d_model: int, d_ff: int) -> nn.Module:
+    m = _Holder()  # reference: TransformerEncoderLayer, vad/modeling/transformer.py:37-47
+    m.self_attention = _attention_params(d_model)
+    m.self_attention_sublayer = _sublayer_params(d_model)
+    m.feed_forward = _ffn_params(d_model, d_ff)
+    m.feed_forward_sublayer = _sublayer_params(d_model)
+    return m
+
+
+class SelfAttentiveVAD(nn.Module):
+    def __init__(self, feature_size: int, num_layers: int, d_model: int, dropout: float = 0.0):
+        super().__init__()
+        self.feature_size = int(feature_size)
+        self.num_layers = int(num_layers)
+        self.d_model = int(d_model)
+        self.dropout_p = float(dropout)  # inference path: Dropout is the identity in .eval()
+        d_ff = 4 * d_model  # vad/models/self_attention.py:10
+
+        self.input_layer = nn.ModuleDict({"0": nn.Linear(feature_size, d_model)})  # key "input_layer.0.*"
+        encoder = _Holder()
+        encoder.layers = nn.ModuleList([_layer_params(d_model, d_ff) for _ in range(num_layers)])
+        encoder.layer_norm = nn.LayerNorm(d_model)
+        self.encoder = encoder
+        self.classifier = nn.Linear(d_model, 2)
+
+        self._handle: Optional[ctypes.c_void_p] = None
+        self._handle_device: Optional[torch.device] = None
+        self._synced_versions = None
+        self._workspace: Optional[Tensor] = None
+        self.attention_splits = 0  # 0 = automatic
+
+    # ---- library handle / weights -----------------------------------------------------------
+    def _ensure_handle(self, device: torch.device):
+        if self._handle is not None and self._handle_device == device:
+            return
+        self._release()
+        lib = _lib.load()
+        cfg = _lib.savad_config(self.feature_size, self.num_layers, self.d_model)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.savad_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._handle, self._handle_device = h, device
+        self._synced_versions = None
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.load().savad_destroy(self._handle)
+            self._handle = None
+            self._synced_versions = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _param_versions(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def sync_weights(self, force: bool = False):
+        """Push the module's parameters into the library's packed weight store when they changed
+        (load_state_dict / .to() / in-place edits all bump data_ptr or _version)."""
+        versions = self._param_versions()
+        if not force and versions == self._synced_versions:
+            return
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(self._handle_device).cuda_stream
+        for key, p in self.state_dict(keep_vars=True).items():
+            t = p.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.to(torch.float32).contiguous()
+            _lib.check(lib.savad_set_param(self._handle, key.encode(), ctypes.c_void_p(t.data_ptr()), t.numel(),
+                                           ctypes.c_void_p(stream)))
+            if t.device.type != "cuda":
+                torch.cuda.current_stream(self._handle_device).synchronize()  # host source must outlive the copy
+        self._synced_versions = versions
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, features: Tensor) -> Tensor:
+        if features.dim() != 3 or features.size(2) != self.feature_size:
+            raise ValueError(f"features must be [B, T, {self.feature_size}], got {tuple(features.shape)}")
+        if features.device.type != "cuda":
+            raise _lib.SavadError(
+                "SelfAttentiveVAD (MI355X build) runs only on a HIP device tensor; there is no CPU fallback. "
+                "Move the model and the features to the GPU (model.to('cuda'), features.to('cuda')).")
+        if self.training and self.dropout_p > 0:
+            raise _lib.SavadError("training-mode dropout is outside this build's scope: call model.eval()")
+        device = features.device
+        x = features.detach()
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        B, T, _ = x.shape
+        out = torch.empty((B, T, 2), dtype=torch.float32, device=device)
+        if B == 0 or T == 0:
+            return out
+        lib = _lib.load()
+        with torch.cuda.device(device):
+            self._ensure_handle(device)
+            first = next(self.parameters())
+            if first.device != device:
+                raise _lib.SavadError(f"model parameters are on {first.device}, features on {device}")
+            self.sync_weights()
+            _lib.check(lib.savad_set_attention_splits(self._handle, int(self.attention_splits)))
+            nbytes = ctypes.c_size_t()
+            _lib.check(lib.savad_workspace_bytes(self._handle, B, T, ctypes.byref(nbytes)))
+            ws = self._workspace
+            if ws is None or ws.device != device or ws.numel() < nbytes.value:
+                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)  # caching allocator owns it
+                self._workspace = ws
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.savad_forward(self._handle, ctypes.c_void_p(x.data_ptr()), B, T,
+                                         ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                         ws.numel(), ctypes.c_void_p(stream)))
+        return out
+
+    # ---- profiling hooks used by bench.py -------------------------------------------------------
+    def set_profiling(self, capacity: int):
+        _lib.check(_lib.load().savad_set_profiling(self._handle, int(capacity)))
+
+    def kernel_times(self):
+        """[(kernel name, average ms)] per launch position since set_profiling; sync the stream first."""
+        names = (ctypes.c_char_p * 64)()
+        ms = (ctypes.c_float * 64)()
+        n = _lib.load().savad_last_kernel_times(self._handle, names, ms, 64)
+        if n < 0:
+            _lib.check(n)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]

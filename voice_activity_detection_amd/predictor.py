@@ -1,0 +1,94 @@
+"""Device-side mirror of the hot half of ``VADFromScratchPredictor.predict_probabilities``
+(reference ``vad/predictor.py:159-262``): sliding-window gather (:180-220), model forward
+(:221-224) and the boosted-prediction scatter / softmax / mean (:238-258, :95).
+
+The feature matrix ``[N, F]`` (log-mel frames; the librosa front-end that produces it is
+outside this path) is uploaded ONCE; windows are gathered, evaluated and boosted on the GPU;
+only ``probs [N, W]`` (and the per-frame mean) come back.  The reference instead builds every
+window in a Python loop, pushes ``[B, 7, 80]`` (7x read amplification) per chunk and scatters
+with numpy on the host.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import SelfAttentiveVAD
+
+
+def window_offsets(half: int, jump: int) -> np.ndarray:
+    """arange(-half, 0, jump) ++ [0] ++ arange(1, half+1, jump)  (vad/predictor.py:186-212)."""
+    buf = (ctypes.c_int32 * 64)()
+    w = _lib.load().savad_window_offsets(half, jump, buf)
+    if w < 0:
+        _lib.check(w)
+    return np.array(buf[:w], dtype=np.int64)
+
+
+@dataclass
+class ContextResolution:
+    """config.context_resolution of the reference (vad/configs/dataset_config.py:7-10)."""
+    context_window_half_frames: int = 19
+    context_window_jump_frames: int = 9
+
+
+class VADFromScratchPredictor:
+    """Hot-path subset of the reference class of the same name (vad/predictor.py:41-75,159-262)."""
+
+    def __init__(self, model: SelfAttentiveVAD, device: torch.device, context: ContextResolution = ContextResolution(),
+                 chunk_size: int = 1000):
+        self.model = model
+        self.device = torch.device(device)
+        self.context_window_half_frames = context.context_window_half_frames
+        self.context_window_jump_frames = context.context_window_jump_frames
+        # vad/predictor.py:57-59
+        self.context_window_frames = 2 * (self.context_window_half_frames - 1) // self.context_window_jump_frames + 3
+        self.chunk_size = int(chunk_size)  # reference: 1000 (vad/predictor.py:180); any value gives the same result
+
+    def predict_probabilities(self, feature) -> np.ndarray:
+        """feature [N, F] (numpy or tensor) -> positive-class probabilities [N, W] (float32 numpy),
+        exactly the array the reference returns from predict_probabilities (:257-260)."""
+        probs, _ = self.predict_probabilities_device(feature)
+        return probs.cpu().numpy()
+
+    def predict_boosted(self, feature) -> np.ndarray:
+        """Per-frame boosted probability = probs.mean(axis=1) (vad/predictor.py:95)."""
+        _, mean = self.predict_probabilities_device(feature)
+        return mean.cpu().numpy()
+
+    @torch.no_grad()
+    def predict_probabilities_device(self, feature):
+        lib = _lib.load()
+        if self.device.type != "cuda":
+            raise _lib.SavadError("the MI355X predictor needs a HIP device (no CPU fallback)")
+        feat = torch.as_tensor(feature, dtype=torch.float32).to(self.device).contiguous()
+        if feat.dim() != 2:
+            raise ValueError("feature must be [N, F]")
+        N, F = feat.shape
+        half, jump, W = self.context_window_half_frames, self.context_window_jump_frames, self.context_window_frames
+        data_length = N - 2 * half  # vad/predictor.py:169
+        self.model.eval()
+        with torch.cuda.device(self.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            n_items = max(data_length, 0)
+            logp = torch.empty((n_items, W, 2), dtype=torch.float32, device=self.device)
+            pos = torch.empty((n_items, W), dtype=torch.int64, device=self.device)
+            for first in range(0, n_items, self.chunk_size):
+                count = min(self.chunk_size, n_items - first)
+                win = torch.empty((count, W, F), dtype=torch.float32, device=self.device)
+                _lib.check(lib.savad_gather_windows(ctypes.c_void_p(feat.data_ptr()), N, F, half, jump, first, count,
+                                                    ctypes.c_void_p(win.data_ptr()),
+                                                    ctypes.c_void_p(pos[first:first + count].data_ptr()), stream))
+                logp[first:first + count] = self.model(features=win)
+            probs = torch.empty((N, W), dtype=torch.float32, device=self.device)
+            mean = torch.empty((N,), dtype=torch.float32, device=self.device)
+            if N > 0:
+                boosted = torch.empty((N, W, 2), dtype=torch.float32, device=self.device)
+                _lib.check(lib.savad_boost(ctypes.c_void_p(logp.data_ptr()), ctypes.c_void_p(pos.data_ptr()), n_items, N,
+                                           W, ctypes.c_void_p(boosted.data_ptr()), ctypes.c_void_p(probs.data_ptr()),
+                                           ctypes.c_void_p(mean.data_ptr()), stream))
+        return probs, mean
