@@ -316,20 +316,31 @@ __global__ __launch_bounds__(256, 2) void row_kernel(
     const size_t row = (size_t)blockIdx.x * TILE + m;
 
     // ---- phase 0: ctx = sum_s w_s O_s / sum_s w_s l_s   (rows are lane-local: all scalars per lane)
+    // Pad rows (row >= rows) were never written by the attention stage: give them ctx = 0 so the
+    // whole pipeline stays finite (their V rows are multiplied by probability 0 downstream).
     f32x4 xg[16];
     {
+        const bool valid = row < (size_t)rows;
         float M = NEG_BIG;
-        for (int s = 0; s < S; ++s) M = fmaxf(M, ml[((size_t)s * rows_pad + row) * 2]);
+        for (int s = 0; s < S; ++s) {
+            const float ms = ml[((size_t)s * rows_pad + row) * 2];
+            M = fmaxf(M, valid ? ms : 0.0f);
+        }
         float den = 0.0f;
 #pragma unroll
         for (int G = 0; G < 16; ++G) xg[G] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < S; ++s) {
-            const f32x2 t = *reinterpret_cast<const f32x2*>(ml + ((size_t)s * rows_pad + row) * 2);
+            f32x2 t = *reinterpret_cast<const f32x2*>(ml + ((size_t)s * rows_pad + row) * 2);
+            if (!valid) t = f32x2{0.0f, 1.0f};
             const float ws = __builtin_amdgcn_exp2f((t[0] - M) * c);
             den += ws * t[1];
             const float* op = Opart + ((size_t)s * rows_pad + row) * D + 4 * h;
 #pragma unroll
-            for (int G = 0; G < 16; ++G) xg[G] += ws * ld4(op + 8 * G);
+            for (int G = 0; G < 16; ++G) {
+                f32x4 o4 = ld4(op + 8 * G);
+                if (!valid) o4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                xg[G] += ws * o4;
+            }
         }
         const float inv = 1.0f / den;
 #pragma unroll
