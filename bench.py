@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
     ap.add_argument("--frames", type=int, default=800, help="T")
     ap.add_argument("--splits", type=int, default=0, help="attention key splits (0 = auto)")
+    ap.add_argument("--row-mode", type=int, default=0, help="0 auto, 1 N-split 32-row tiles, 2 M-split 128-row tiles")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
@@ -125,6 +126,7 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(dev).eval()
     model.attention_splits = args.splits
+    model.row_mode = args.row_mode
     # each rank gets its own shard of the global batch (weak scaling: B per GPU fixed)
     x = torch.from_numpy(np.random.default_rng(rank).uniform(-13.8, 4.2, (B, T, F_MEL)).astype(np.float32)).to(dev)
     gathered = torch.empty((world, B, T, 2), dtype=torch.float32, device=dev) if world > 1 else None

@@ -77,6 +77,10 @@ int savad_forward(savad_handle h, const float* x, int B, int T, float* out, void
 
 /* Tuning knob: number of key-range splits of the attention stage (0 = automatic). */
 int savad_set_attention_splits(savad_handle h, int splits);
+/* Tuning knob: tiling of the row-wise stages: 0 = automatic, 1 = 32-row tiles with the output
+ * features split over the workgroup's waves, 2 = 128-row tiles with the weight stream shared
+ * through LDS. */
+int savad_set_row_mode(savad_handle h, int mode);
 /* Fills the names/durations of the kernels of the most recent savad_forward when profiling is
  * enabled with savad_set_profiling(h, 1): the forward then brackets every launch with hipEvents on
  * `stream` and synchronises at the end (bench.py uses this for the roofline block).

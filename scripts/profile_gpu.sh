@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs ON the GPU box (via gpurun): kernel trace + PMC passes of the default bench workload.
+# Usage: scripts/profile_gpu.sh <tag> [extra bench args]
+set -u
+TAG=${1:-r1}; shift || true
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline $*"
+cd /tmp
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+echo "trace rc=$?"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -f csv -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1
+echo "pmc_sq rc=$?"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
+echo "pmc_fetch rc=$?"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
+echo "pmc_write rc=$?"
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -f csv -d $OUT/pmc_l2 -o pmc -- $BENCH > $OUT/pmc_l2.log 2>&1
+echo "pmc_l2 rc=$?"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 -f csv -d $OUT/pmc_inst -o pmc -- $BENCH > $OUT/pmc_inst.log 2>&1
+echo "pmc_inst rc=$?"
+cd $REPO
+python scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
+# keep the merged-back payload small
+find $OUT -name "*.csv" -size +4M -delete

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 csv output (kernel trace stats + PMC passes) into a short text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+def short(name):
+    for key in ("input_qkv_kernel", "attention_kernel", "row_kernel<true>", "row_kernel<false>", "row_kernel",
+                "fold_ln_kernel", "gather_windows", "boost"):
+        if key.replace("<true>", "ILb1").replace("<false>", "ILb0") in name or key in name:
+            return key
+    return name[:60]
+
+
+print(f"# rocprofv3 summary for {out}")
+for f in find("trace/**/*kernel_stats.csv"):
+    print(f"\n## kernel stats ({os.path.relpath(f, out)})")
+    with open(f) as fh:
+        for i, row in enumerate(csv.DictReader(fh)):
+            if i >= 12:
+                break
+            print(f"{short(row['Name']):28s} calls={row['Calls']:>5s} total_ns={row['TotalDurationNs']:>12s} "
+                  f"avg_ns={float(row['AverageNs']):>12.0f} min={row['MinNs']:>9s} max={row['MaxNs']:>9s} pct={row['Percentage']}")
+
+for f in find("trace/**/*kernel_trace.csv"):
+    # per-kernel resource columns
+    seen = {}
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = short(row["Kernel_Name"])
+            if k not in seen:
+                seen[k] = row
+    print("\n## dispatch resources")
+    for k, row in seen.items():
+        cols = {c: row.get(c) for c in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                                         "Workgroup_Size", "Grid_Size")}
+        print(f"{k:28s} {cols}")
+
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_l2", "pmc_inst"):
+    files = find(f"{sub}/**/*counter_collection.csv")
+    if not files:
+        continue
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = short(row["Kernel_Name"])
+                acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                cnt[k][row["Counter_Name"]] += 1
+    print(f"\n## {sub}: per-dispatch averages")
+    for k in acc:
+        vals = {c: acc[k][c] / max(cnt[k][c], 1) for c in acc[k]}
+        print(f"{k:28s} " + "  ".join(f"{c}={v:.4g}" for c, v in sorted(vals.items())))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "SQ_BUSY_CYCLES" in vals and vals["SQ_BUSY_CYCLES"] > 0:
+            # MFMA busy is summed over SIMDs(4/CU x 256), SQ_BUSY_CYCLES over XCD-level SQs: report raw ratio + per-GUI ratio
+            if "GRBM_GUI_ACTIVE" in vals and vals["GRBM_GUI_ACTIVE"] > 0:
+                print(f"{'':28s} mfma_busy/(GRBM_GUI_ACTIVE*1024 SIMDs) = "
+                      f"{vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (vals['GRBM_GUI_ACTIVE'] * 1024):.3f}")

@@ -1,0 +1,22 @@
+import ctypes, os, sys
+sys.path.insert(0, os.getcwd())
+os.environ["SAVAD_LIB"] = os.path.abspath("scripts/ubench/libsavad_timing.so")
+import numpy as np, torch
+from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, _lib
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+m = SelfAttentiveVAD(80, 3, 128, 0.5)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()})
+m = m.cuda().eval(); m.row_mode = 2; m.attention_splits = 1
+x = torch.randn(B, 800, 80, device="cuda")
+for _ in range(3): m(x)
+torch.cuda.synchronize()
+lib = _lib.load()
+lib.savad_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
+buf = (ctypes.c_longlong * 16)()
+lib.savad_debug_stamps(buf, 16)
+t = list(buf[:9])
+names = ["prologue+combine", "out-proj(4 blk)", "LN1", "park stores", "FFN(32 blk)", "resid+store", "LN2", "QKV(12 blk)"]
+print("B", B, "row_last kernel stamps (ticks @100MHz?):")
+for i, nme in enumerate(names):
+    print(f"  {nme:18s} {t[i+1]-t[i]:8d}")
+print("  total", t[8] - t[0] if t[8] else t[7]-t[0])

@@ -37,12 +37,14 @@ def model(torch_cuda, state1234):
     return make_model(torch_cuda, state1234)
 
 
-def run(torch, model, x, splits=0):
+def run(torch, model, x, splits=0, row_mode=0):
     model.attention_splits = splits
+    model.row_mode = row_mode
     with torch.no_grad():
         y = model(features=torch.from_numpy(x).to("cuda"))
     torch.cuda.synchronize()
     model.attention_splits = 0
+    model.row_mode = 0
     return y.cpu().numpy()
 
 
@@ -132,6 +134,22 @@ def test_attention_split_invariance(torch_cuda, model, golden, splits):
     assert np.abs(y - golden["g2_out"]).max() < TIGHT
 
 
+@pytest.mark.parametrize("row_mode", [1, 2])
+def test_row_tilings_agree_with_golden(torch_cuda, model, golden, row_mode):
+    # both tilings of the row-wise stages (32-row N-split, 128-row M-split with the LDS weight ring)
+    for tag, seed, shape in (("g2_out", 102, (2, 800, 80)), ("g1_out", 101, (4, 7, 80)), ("g6_out", 600, (2, 40, 80))):
+        y = run(torch_cuda, model, feats(seed, shape), row_mode=row_mode)
+        assert np.abs(y - golden[tag]).max() < TIGHT
+    for T in (1, 33, 65, 100, 801):
+        y = run(torch_cuda, model, feats(400 + T, (3, T, 80)), row_mode=row_mode)
+        assert np.abs(y - golden[f"g4_T{T}"]).max() < TIGHT
+    y = run(torch_cuda, model, feats(78, (1000, 7, 80)), row_mode=row_mode)
+    assert np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < TIGHT
+    y = run(torch_cuda, model, feats(0, (32, 800, 80)), row_mode=row_mode)
+    assert np.abs(y[-2:] - golden["g3_tail"]).max() < TIGHT
+    assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g3_seqsum"]).max() < 1600 * TIGHT
+
+
 def test_properties_full_size(torch_cuda, model):
     # size-independent properties at config-2 size: normalisation, batch-permutation equivariance
     # (sequences are independent: bit-exact), determinism
@@ -143,8 +161,11 @@ def test_properties_full_size(torch_cuda, model):
     yp = run(torch_cuda, model, x[perm])
     assert np.array_equal(yp, y[perm])
     assert np.array_equal(run(torch_cuda, model, x), y)
-    # a sequence evaluated alone equals the same sequence inside the batch (bit-exact)
-    assert np.array_equal(run(torch_cuda, model, x[7:8], splits=1), run(torch_cuda, model, x, splits=1)[7:8])
+    # a sequence evaluated alone equals the same sequence inside the batch (bit-exact, for a fixed
+    # choice of tiling / key split: those change the fp32 summation order, not the math)
+    for row_mode in (1, 2):
+        alone = run(torch_cuda, model, x[7:8], splits=1, row_mode=row_mode)
+        assert np.array_equal(alone, run(torch_cuda, model, x, splits=1, row_mode=row_mode)[7:8])
 
 
 def test_empty_and_call_forms(torch_cuda, model):

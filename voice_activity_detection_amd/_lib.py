@@ -7,7 +7,9 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libsavad.so"
+import os
+
+LIB_PATH = Path(os.environ.get("SAVAD_LIB", _PKG / "libsavad.so"))  # override only for kernel experiments
 
 
 class SavadError(RuntimeError):
@@ -29,6 +31,7 @@ SYMBOLS = {
     "savad_workspace_bytes": (c_int, [c_void_p, c_int, c_int, POINTER(c_size_t)]),
     "savad_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "savad_set_attention_splits": (c_int, [c_void_p, c_int]),
+    "savad_set_row_mode": (c_int, [c_void_p, c_int]),
     "savad_set_profiling": (c_int, [c_void_p, c_int]),
     "savad_last_kernel_times": (c_int, [c_void_p, POINTER(c_char_p), POINTER(c_float), c_int]),
     "savad_window_offsets": (c_int, [c_int, c_int, POINTER(c_int32)]),

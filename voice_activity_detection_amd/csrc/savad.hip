@@ -58,6 +58,7 @@ struct savad_model {
     int pe_len = 0;
     std::vector<float> h_pe;
     int splits = 0;
+    int row_mode = 0;  // 0 auto, 1 N-split (32-row tiles), 2 M-split (128-row tiles)
     // profiling
     int prof_capacity = 0, prof_used = 0, prof_nk = 0;
     std::vector<hipEvent_t> events;  // prof_capacity * MAX_EVENTS
@@ -96,8 +97,8 @@ int choose_splits(const savad_model* m, int B, int T) {
     // A split costs about half a tile of extra traffic (partials written and re-read); take S > 1
     // only when it beats the unsplit schedule by more than 7 %.
     auto cost = [&](int S) {
-        const long wgs = (long)B * ((QB * S + 3) / 4);
-        return (double)((wgs + 255) / 256) * ((NT + S - 1) / S + 0.5);
+        const long wgs = (long)B * ((QB + 3) / 4) * S;
+        return (double)((wgs + 511) / 512) * ((NT + S - 1) / S + 0.5);  // 2 workgroups resident per CU
     };
     const double cost1 = cost(1);
     double best = cost1;
@@ -121,7 +122,7 @@ struct Workspace {
 Workspace plan(const savad_model* m, int B, int T) {
     Workspace w;
     w.rows = (size_t)B * T;
-    w.rows_pad = (w.rows + TILE - 1) / TILE * TILE;
+    w.rows_pad = (w.rows + 127) / 128 * 128;  // whole 128-row tiles (M-split kernels); also a multiple of TILE
     w.S = choose_splits(m, B, T);
     size_t off = 0;
     w.h = off;
@@ -333,6 +334,12 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
     return SAVAD_OK;
 }
 
+SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
+    if (!m || mode < 0 || mode > 2) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    m->row_mode = mode;
+    return SAVAD_OK;
+}
+
 SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* bytes) {
     if (!m || !bytes || B < 0 || T < 0) return fail(SAVAD_E_INVALID, "bad argument");
     if ((double)B * T * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "B*T=%ld rows exceed the 32-bit tile index range", (long)B * T);
@@ -366,34 +373,53 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     const float* P = m->d_packed;
     Prof prof(m, st);
 
-    hipLaunchKernelGGL(input_qkv_kernel, dim3(tiles), dim3(256), 0, st, x, (int)ws.rows, T, F, R + m->r_win,
-                       R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
+    // Row-wise stages: 128-row tiles with the weight stream shared through LDS (M split) when that
+    // fills the chip; 32-row tiles with the output features split over the 4 waves (N split) when
+    // the batch is small and the critical path per workgroup matters more than weight traffic.
+    const int tiles_m = (int)(ws.rows_pad / 128);
+    // Measured crossover on MI355X at T=800: B=24 (150 tiles) N-split 105 us vs M-split 119 us per
+    // layer; B=32 (200 tiles) 134 vs 120.
+    const bool msplit = m->row_mode == 2 || (m->row_mode == 0 && tiles_m >= 192);
+    if (msplit)
+        hipLaunchKernelGGL(input_qkv_kernel_m, dim3(tiles_m), dim3(256), 0, st, x, (int)ws.rows, T, F, R + m->r_win,
+                           R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
+    else
+        hipLaunchKernelGGL(input_qkv_kernel, dim3(tiles), dim3(256), 0, st, x, (int)ws.rows, T, F, R + m->r_win,
+                           R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
     prof.mark("input_qkv");
     for (int l = 0; l < L; ++l) {
         if (T <= 32) {
             const int G = 32 / T, nblk = (B + G - 1) / G;
-            hipLaunchKernelGGL(attention_kernel<true>, dim3((nblk + 3) / 4), dim3(256), 0, st, q, k, v, op, ml, B, T,
-                               (int)ws.rows, (int)ws.rows_pad, 1, c);
+            hipLaunchKernelGGL(attention_packed_kernel, dim3((nblk + 3) / 4), dim3(256), 0, st, q, k, v, op, ml, B, T,
+                               (int)ws.rows, c);
         } else {
-            const int QB = (T + 31) / 32, wgs = (QB * ws.S + 3) / 4;
-            const int grid = 8 * ((B + 7) / 8) * wgs;
-            hipLaunchKernelGGL(attention_kernel<false>, dim3(grid), dim3(256), 0, st, q, k, v, op, ml, B, T,
-                               (int)ws.rows, (int)ws.rows_pad, ws.S, c);
+            const int QB = (T + 31) / 32, NG = (QB + 3) / 4;
+            const int grid = 8 * ((B + 7) / 8) * NG * ws.S;
+            hipLaunchKernelGGL(attention_kernel, dim3(grid), dim3(256), 0, st, q, k, v, op, ml, B, T, (int)ws.rows_pad,
+                               ws.S, NG, c);
         }
         prof.mark("attention");
         const auto& r = m->lr[l];
         const auto& p = m->lp[l];
+#define SAVAD_ROW_ARGS(WN, BN) op, ml, ws.S, (int)ws.rows, (int)ws.rows_pad, c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, \
+                               R + r.w2, R + r.b2, WN, BN, q, k, v, out
         if (l + 1 < L) {
-            hipLaunchKernelGGL(row_kernel<false>, dim3(tiles), dim3(256), 0, st, op, ml, ws.S, (int)ws.rows,
-                               (int)ws.rows_pad, c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2,
-                               P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv, q, k, v, out);
+            if (msplit)
+                hipLaunchKernelGGL(row_kernel_m<false>, dim3(tiles_m), dim3(256), 0, st,
+                                   SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv));
+            else
+                hipLaunchKernelGGL(row_kernel<false>, dim3(tiles), dim3(256), 0, st,
+                                   SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv));
             prof.mark("row");
         } else {
-            hipLaunchKernelGGL(row_kernel<true>, dim3(tiles), dim3(256), 0, st, op, ml, ws.S, (int)ws.rows,
-                               (int)ws.rows_pad, c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2,
-                               P + m->p_wc, P + m->p_bc, q, k, v, out);
+            if (msplit)
+                hipLaunchKernelGGL(row_kernel_m<true>, dim3(tiles_m), dim3(256), 0, st,
+                                   SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc));
+            else
+                hipLaunchKernelGGL(row_kernel<true>, dim3(tiles), dim3(256), 0, st, SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc));
             prof.mark("row_last");
         }
+#undef SAVAD_ROW_ARGS
     }
     prof.done();
     HIP_TRY(hipGetLastError());
@@ -481,3 +507,12 @@ SAVAD_EXPORT int savad_boost(const float* logp, const int64_t* positions, int co
     HIP_TRY(hipGetLastError());
     return SAVAD_OK;
 }
+
+#ifdef SAVAD_TIMING
+// experiments only: read the phase stamps of the last row_kernel_m launch
+SAVAD_EXPORT int savad_debug_stamps(long long* out, int n) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(savad::g_savad_dbg), sizeof(long long) * n));
+    return SAVAD_OK;
+}
+#endif

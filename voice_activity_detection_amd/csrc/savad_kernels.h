@@ -178,116 +178,223 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel(
 // Kernel 2: single-head scaled-dot-product attention, flash style (vad/modeling/transformer.py:
 // 305-346,351-363): S = q k^T / sqrt(d_head), softmax over keys, ctx = A v -- the [T,T] matrix is
 // never materialised (the reference discards it: transformer.py:50).
-// One WAVE per work item = (sequence, 32-query block, key split): Q stays in registers as the
-// B operand; S^T = K Q^T lands in row layout (query row per lane, 16 key scores per lane), so the
-// online softmax is lane-local; P feeds the PV MFMA as B operand unchanged; O^T = V^T P^T
-// accumulates in row layout.  Output: UNNORMALISED O plus (running max, running sum) per row and
-// split; the row kernel combines the splits and divides.
-// PACKED (T <= 32): one item = floor(32/T) whole sequences (block-diagonal mask), one key tile.
+// One WAVE per (sequence, 32-query block, key split): Q stays in registers as the B operand;
+// S^T = K Q^T lands in row layout (query row per lane, 16 key scores per lane), so the online
+// softmax is lane-local; P feeds the PV MFMA as B operand unchanged; O^T = V^T P^T accumulates in
+// row layout.  Output: UNNORMALISED O plus (running max, running sum) per row and split; the row
+// kernel combines the splits and divides.
 // ---------------------------------------------------------------------------------------------
-template <bool PACKED>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                           const float* __restrict__ v, float* __restrict__ Opart,
-                                                           float* __restrict__ ml, int B, int T, int rows,
-                                                           int rows_pad, int S, float c /* log2(e)/sqrt(d_head) */) {
+
+// One 32-key tile of the flash loop, K and V tiles supplied by functors (LDS or global).
+// sc in/out: raw scores S^T (already masked) -> probabilities p.
+__device__ __forceinline__ void online_softmax(f32x16& sc, float& m_run, float& l_run, f32x16 (&O)[4], float c) {
+    float mx = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+    mx = fmaxf(mx, xhalf(mx));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);  // base-2 domain: p = 2^((s - m) c)
+    const float mc = m_new * c;
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -mc));
+        rs += sc[r];
+    }
+    rs += xhalf(rs);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) O[nb] *= alpha;
+}
+
+__device__ __forceinline__ void store_attention_partial(float* __restrict__ Opart, float* __restrict__ ml, size_t prow,
+                                                        const f32x16 (&O)[4], float m_run, float l_run, int h) {
+    float* op = Opart + prow * D;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) store_block(op + 32 * nb, O[nb], h);
+    if (h == 0) *reinterpret_cast<f32x2*>(ml + prow * 2) = f32x2{m_run, l_run};
+}
+
+// ---- T <= 32: one item = floor(32/T) whole sequences (block-diagonal mask), one key tile, K and V
+// straight from global memory (nothing to share or pipeline).
+__global__ __launch_bounds__(256, 2) void attention_packed_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                  const float* __restrict__ v, float* __restrict__ Opart,
+                                                                  float* __restrict__ ml, int B, int T, int rows, float c) {
     const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    int s = 0, jt0 = 0, jt1 = 1;
-    size_t qrow, kbase;  // flat row of this lane's query; flat row of key 0 of the item
-    bool qvalid;
-    int tq = 0;          // PACKED: sequence slot of this lane's query inside the block
-    int rowsPB = 0;
-    if (PACKED) {
-        const int G = 32 / T;
-        rowsPB = G * T;
-        const int nblk = (B + G - 1) / G;
-        const int blk = blockIdx.x * 4 + w;
-        if (blk >= nblk) return;
-        kbase = (size_t)blk * rowsPB;
-        qrow = kbase + m;
-        qvalid = (m < rowsPB) && (qrow < (size_t)rows);
-        tq = m / T;
-    } else {
-        const int QB = (T + 31) / 32, NT = QB;
-        const int items = QB * S, wgs = (items + 3) / 4;
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;  // all items of a sequence on one XCD (shared K/V in its L2)
-        const int b = (i / wgs) * 8 + xcd;
-        const int item = (i % wgs) * 4 + w;
-        if (b >= B || item >= items) return;
-        s = item / QB;  // the 4 waves of a workgroup walk the same key range
-        const int qb = item % QB;
-        jt0 = (int)(((long)s * NT) / S);
-        jt1 = (int)(((long)(s + 1) * NT) / S);
-        kbase = (size_t)b * T;
-        qrow = kbase + 32 * qb + m;
-        qvalid = (32 * qb + m) < T;
-    }
-    // q/k/v carry 32 rows of slack behind rows_pad, so tiles may over-read without clamping:
-    // over-read K rows only produce masked scores, over-read V rows are zero (host memset).
+    const int G = 32 / T, rowsPB = G * T;
+    const int nblk = (B + G - 1) / G;
+    const int blk = blockIdx.x * 4 + w;
+    if (blk >= nblk) return;
+    const size_t k0 = (size_t)blk * rowsPB;
+    const size_t qrow = k0 + m;
+    const bool qvalid = (m < rowsPB) && (qrow < (size_t)rows);
+    const int tq = m / T;
+    // q/k/v carry 32 rows of slack behind rows_pad, so the tile may over-read without clamping:
+    // over-read K rows only produce masked scores, over-read V rows are zero (input_qkv_kernel).
     f32x4 qg[16];
 #pragma unroll
-    for (int G = 0; G < 16; ++G) qg[G] = ld4(q + qrow * D + 8 * G + 4 * h);
+    for (int G8 = 0; G8 < 16; ++G8) qg[G8] = ld4(q + qrow * D + 8 * G8 + 4 * h);
+    f32x16 O[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
+    float m_run = NEG_BIG, l_run = 0.0f;
+    f32x16 sc = zero16();
+    gemm_k128(sc, k + (k0 + n) * D + 4 * h, qg);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
+        const bool ok = (jk < rowsPB) && (jk / T == tq) && (k0 + jk < (size_t)rows);
+        sc[r] = ok ? sc[r] : NEG_BIG;
+    }
+    online_softmax(sc, m_run, l_run, O, c);
+    const float* vp = v + (k0 + 4 * h) * D + n;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
+    }
+    if (qvalid) store_attention_partial(Opart, ml, qrow, O, m_run, l_run, h);
+}
 
+// ---- T > 32: a workgroup = (sequence, key split, group of up to 4 query blocks); its 4 waves walk
+// the SAME key tiles, which are staged ONCE per workgroup into LDS by asynchronous global->LDS DMA
+// (global_load_lds_dwordx4, no VGPR round trip), double-buffered one tile ahead: the DMA of tile
+// j+1 is issued right after the barrier that publishes tile j, so its latency hides under the 128
+// MFMAs (8192 cycles) of tile j and the barrier's vmcnt(0) is free.
+//   K tile [32 keys][128] : A operand of S^T = K Q^T, read with ds_read_b128 (lane = key row); the
+//                           16-byte chunk c of row r sits at chunk position c ^ (r & 15), which
+//                           makes every 16-lane read group hit 16 distinct 16-byte slots.  The DMA
+//                           writes LDS linearly (base + lane*16), so the swizzle is applied to the
+//                           per-lane SOURCE address.
+//   V tile [32 keys][128] : A operand of O^T = V^T P^T, read with ds_read_b32 (lane = feature d;
+//                           32 consecutive floats of one key row: conflict-free), row-major.
+constexpr int KV_TILE_FLOATS = 32 * D;
+
+// Phase timing (experiments only, scripts/ablate.sh -DSAVAD_TIMING): wave 0 of workgroup 0 stamps
+// s_memtime at phase boundaries into g_savad_dbg.
+#ifdef SAVAD_TIMING
+__device__ long long g_savad_dbg[64];
+#define SAVAD_STAMP(i)                                                                  \
+    do {                                                                                \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_savad_dbg[i] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define SAVAD_STAMP(i) \
+    do {               \
+    } while (0)
+#endif
+#ifndef SAVAD_ABLATE
+#define SAVAD_ABLATE 0  // experiment switch (scripts/ablate.sh): 1 = no DMA, 2 = no ring barrier, 4 = no softmax
+#endif
+__device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
+    if (SAVAD_ABLATE & 1) return;
+    // global_load_lds_dwordx4: 64 lanes x 16 B from per-lane global addresses to LDS at M0 + lane*16.
+    // Issued as inline asm ON PURPOSE: with the builtin, hipcc (ROCm 7.2) degrades every LDS wait
+    // in a region where an LDS-DMA may be outstanding to lgkmcnt(0) -- each ds_read -> MFMA wait
+    // then also drains the ds_read issued just before it (a full LDS latency exposed per 8 MFMAs,
+    // measured -25 %).  The asm form is invisible to that bookkeeping; completion is tracked by
+    // hand (ring_acquire / the attention loop: s_waitcnt vmcnt(0), then the workgroup barrier).
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(m0v)
+        : "memory");
+}
+
+// stage rows [k0, k0+32) of K and V: 32 wave-instructions of 1 KiB, 8 per wave
+__device__ __forceinline__ void stage_kv_tile(const float* __restrict__ k, const float* __restrict__ v, size_t k0,
+                                              float* kbuf, float* vbuf, int w, int lane) {
+    const int sub = lane >> 5, p = lane & 31;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+        const int i = 4 * i4 + w;  // instruction index 0..15 -> rows 2i, 2i+1
+        const int r = 2 * i + sub;
+        dma16(k + (k0 + r) * D + 4 * (p ^ (r & 15)), kbuf + i * 256);
+        dma16(v + (k0 + r) * D + 4 * p, vbuf + i * 256);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, float* __restrict__ Opart,
+                                                           float* __restrict__ ml, int B, int T, int rows_pad, int S,
+                                                           int NG /* query-block groups per sequence */, float c) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * KV_TILE_FLOATS];  // [buffer 2][K, V]
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int QB = (T + 31) / 32, NT = QB;
+    const int per_seq = NG * S;
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;  // all workgroups of a sequence on one XCD (its K/V stay in that L2)
+    const int b = (i / per_seq) * 8 + xcd;
+    if (b >= B) return;
+    const int rr = i % per_seq;
+    const int s = rr / NG, g = rr % NG;
+    const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;
+    const int qb = qb0 + w;
+    const bool active = qb < qb1;  // wave-uniform
+    const int jt0 = (int)(((long)s * NT) / S), jt1 = (int)(((long)(s + 1) * NT) / S);
+    const size_t kbase = (size_t)b * T;
+    const size_t qrow = kbase + 32 * (size_t)(active ? qb : qb0) + m;
+    const bool qvalid = active && (32 * qb + m) < T;
+
+    f32x4 qg[16];
+#pragma unroll
+    for (int G8 = 0; G8 < 16; ++G8) qg[G8] = ld4(q + qrow * D + 8 * G8 + 4 * h);
     f32x16 O[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
     float m_run = NEG_BIG, l_run = 0.0f;
 
+    stage_kv_tile(k, v, kbase + 32 * (size_t)jt0, lds, lds + KV_TILE_FLOATS, w, lane);
     for (int jt = jt0; jt < jt1; ++jt) {
-        const size_t k0 = kbase + 32 * (size_t)jt;
-        // ---- S^T tile = K Q^T : A = key rows (lane & 31 = key), B = Q
+        float* kb = lds + ((jt - jt0) & 1) * 2 * KV_TILE_FLOATS;
+        float* vb = kb + KV_TILE_FLOATS;
+        // Explicit drain of this wave's DMA before the barrier: hipcc (ROCm 7.2) does NOT emit the
+        // vmcnt(0) for LDS-DMA issued in the previous loop iteration (checked in the ISA), so the
+        // publish "my part of tile jt is in LDS" must be stated by hand.  It is free: the DMA was
+        // issued a whole tile (8192+ MFMA cycles) ago.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile jt has landed for every wave; everyone is done reading the other buffer
+        if (jt + 1 < jt1) {
+            float* kn = lds + ((jt + 1 - jt0) & 1) * 2 * KV_TILE_FLOATS;
+            stage_kv_tile(k, v, kbase + 32 * (size_t)(jt + 1), kn, kn + KV_TILE_FLOATS, w, lane);
+        }
+        if (!active) continue;
+        // ---- S^T tile = K Q^T
         f32x16 sc = zero16();
-        gemm_k128(sc, k + (k0 + n) * D + 4 * h, qg);
-        // lane (m,h), register r: score of query m against key jk = 8(r>>2) + 4h + (r&3)
-        if (PACKED) {
+        const float* krow = kb + n * D;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
-                const bool ok = (jk < rowsPB) && (jk / T == tq) && (k0 + jk < (size_t)rows);
-                sc[r] = ok ? sc[r] : NEG_BIG;
-            }
-        } else if (32 * jt + 32 > T) {
+        for (int G8 = 0; G8 < 16; ++G8) {
+            const f32x4 k4 = ld4(krow + 4 * ((2 * G8 + h) ^ (n & 15)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc = SAVAD_MFMA(k4[e], qg[G8][e], sc);
+        }
+        // lane (m,h), register r: score of query m against key jk = 8(r>>2) + 4h + (r&3)
+        if (32 * jt + 32 > T) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
                 sc[r] = (32 * jt + jk < T) ? sc[r] : NEG_BIG;
             }
         }
-        // ---- online softmax (base-2 domain: p = 2^((s - m) * c))
-        float mx = sc[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-        mx = fmaxf(mx, xhalf(mx));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        float rs = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -mc));
-            rs += sc[r];
-        }
-        rs += xhalf(rs);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) O[nb] *= alpha;
-        // ---- O^T += V^T P^T : A = V^T (lane & 31 = output feature d, k index = key), B = P
-        const float* vp = v + (k0 + 4 * h) * D + n;
+        online_softmax(sc, m_run, l_run, O, c);
+        // ---- O^T += V^T P^T
+        const float* vp = vb + 4 * h * D + n;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
+            for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
         }
     }
-    if (qvalid) {
-        float* op = Opart + ((size_t)s * rows_pad + qrow) * D;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) store_block(op + 32 * nb, O[nb], h);
-        if (h == 0) *reinterpret_cast<f32x2*>(ml + ((size_t)s * rows_pad + qrow) * 2) = f32x2{m_run, l_run};
-    }
+    if (qvalid) store_attention_partial(Opart, ml, (size_t)s * rows_pad + qrow, O, m_run, l_run, h);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -402,6 +509,301 @@ __global__ __launch_bounds__(256, 2) void row_kernel(
     if (!LAST) {
         qkv_block(xg, Wn, bn, q, k, v, row, w, n, h);
     } else if (w == 0) {
+        float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const f32x4 c0 = ld4(Wn + 8 * G + 4 * h), c1 = ld4(Wn + D + 8 * G + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z0 = __builtin_fmaf(xg[G][e], c0[e], z0);
+                z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
+            }
+        }
+        z0 += xhalf(z0);
+        z1 += xhalf(z1);
+        z0 += bn[0];
+        z1 += bn[1];
+        const float mx = fmaxf(z0, z1);
+        const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+        if (h == 0 && row < (size_t)rows) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+    }
+}
+
+// =============================================================================================
+// M-split row kernels (used when the batch is large enough to fill the chip with 128-row tiles).
+// A workgroup = 128 data rows = 4 waves x 32 rows; every wave runs the WHOLE row-wise chain for
+// its own rows register-to-register (row layout in, row layout out: no activation ever touches
+// LDS, LayerNorm is lane-local, the FFN's ReLU output feeds the second GEMM straight from the
+// accumulators).  The only shared operand is the weight stream (768 KB per layer): it is staged
+// ONCE per workgroup into a 2 x 16 KB LDS ring by asynchronous global->LDS DMA, one 16 KB block
+// (= 64 MFMAs per wave = 4096 cycles) ahead of its use, and read by all four waves with
+// conflict-free ds_read_b128.  Block kinds:
+//   A: 32 output features x 128 k   (Wo / W1 chunk / Wqkv block); chunk c of row r at c ^ (r & 15)
+//   B: 128 output features x 32 k   (column slice of W2 [128][512]); chunk c of row r at c ^ ((r >> 1) & 7)
+// =============================================================================================
+constexpr int WBLK = 4096;  // floats per ring buffer (16 KB)
+
+__device__ __forceinline__ void stage_block_a(const float* __restrict__ W, int ld, float* buf, int w, int lane) {
+    const int sub = lane >> 5, p = lane & 31;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+        const int i = 4 * i4 + w, r = 2 * i + sub;  // 1 KiB = rows 2i, 2i+1
+        dma16(W + (size_t)r * ld + 4 * (p ^ (r & 15)), buf + i * 256);
+    }
+}
+__device__ __forceinline__ void stage_block_b(const float* __restrict__ W, int ld, float* buf, int w, int lane) {
+    const int sub = lane >> 3, p = lane & 7;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+        const int i = 4 * i4 + w, r = 8 * i + sub;  // 1 KiB = rows 8i .. 8i+7 (128 B each)
+        dma16(W + (size_t)r * ld + 4 * (p ^ ((r >> 1) & 7)), buf + i * 256);
+    }
+}
+// publish / acquire one ring block: my DMA has landed, everybody's has, and everybody is done with
+// the previous block (so its buffer may be refilled right after this returns)
+__device__ __forceinline__ void ring_acquire() {
+    if (SAVAD_ABLATE & 2) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // hipcc does not count LDS-DMA across the loop back-edge
+    __syncthreads();
+}
+__device__ __forceinline__ void gemm_lds_a(f32x16& acc, const float* buf, int n, int h, const f32x4 (&xg)[16]) {
+    const float* row = buf + n * D;
+#pragma unroll
+    for (int G = 0; G < 16; ++G) {
+        const f32x4 w4 = ld4(row + 4 * ((2 * G + h) ^ (n & 15)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = SAVAD_MFMA(w4[e], xg[G][e], acc);
+    }
+}
+__device__ __forceinline__ void gemm_lds_b(f32x16 (&o)[4], const float* buf, int n, int h, const f32x16& a) {
+    const int sw = (n >> 1) & 7;  // ((32 nb + n) >> 1) & 7
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const float* row = buf + (32 * nb + n) * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w4 = ld4(row + 4 * ((2 * g + h) ^ sw));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[nb] = SAVAD_MFMA(w4[e], a[4 * g + e], o[nb]);
+        }
+    }
+}
+// LayerNorm (no affine) of full rows held as 4 row-layout blocks -> B-operand registers
+__device__ __forceinline__ void layernorm_regs(const f32x16 (&x)[4], f32x4 (&xg)[16]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += x[nb][r];
+    s += xhalf(s);
+    const float mean = s * (1.0f / D);
+    float ss = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = x[nb][r] - mean;
+            xg[4 * nb + (r >> 2)][r & 3] = d;
+            ss += d * d;
+        }
+    ss += xhalf(ss);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + LN_EPS);
+#pragma unroll
+    for (int G = 0; G < 16; ++G) xg[G] *= rstd;
+}
+
+// Biases live in LDS for the whole kernel (loaded once, published by the first ring barrier): a
+// global load inside the block loop would be drained by the ring's vmcnt(0) at full L2 latency,
+// once per block.  For the same reason results are stored one block LATE (after the next block's
+// barrier), so that a store's write-ack is never waited for.
+__device__ __forceinline__ void stage_bias(float* dst, const float* __restrict__ src, int count) {
+    for (int i = threadIdx.x * 4; i < count; i += 256 * 4) st4(dst + i, ld4(src + i));
+}
+__device__ __forceinline__ f32x16 bias_block(const float* lds_bias /* &bias[n0] */, int h) {
+    f32x16 r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = ld4(lds_bias + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[4 * g + e] = b4[e];
+    }
+    return r;
+}
+
+// QKV tail shared by both M-split kernels: 12 ring blocks (Wqkv rows 32j .. 32j+31); block 0 must
+// already be in flight into ring buffer 0; bq = LDS copy of the packed QKV bias [384].
+__device__ __forceinline__ void qkv_tail_m(const f32x4 (&xg)[16], const float* __restrict__ Wqkv, const float* bq,
+                                           float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
+                                           size_t row, float* ring, int w, int lane, int n, int h) {
+    float* dst[3] = {q, k, v};
+    f32x16 prev = zero16();
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        ring_acquire();
+        if (j + 1 < 12) stage_block_a(Wqkv + (size_t)(32 * (j + 1)) * D, D, ring + ((j + 1) & 1) * WBLK, w, lane);
+        if (j > 0) store_block(dst[(j - 1) >> 2] + row * D + 32 * ((j - 1) & 3), prev, h);
+        f32x16 acc = bias_block(bq + 32 * j, h);
+        gemm_lds_a(acc, ring + (j & 1) * WBLK, n, h, xg);
+        prev = acc;
+    }
+    store_block(dst[2] + row * D + 96, prev, h);
+}
+
+__global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
+    const float* __restrict__ x, int rows, int T, int F, const float* __restrict__ Win, const float* __restrict__ bin,
+    const float* __restrict__ pe, const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
+    float* __restrict__ hbuf, float* __restrict__ q, float* __restrict__ k, float* __restrict__ v) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * WBLK + 3 * D];
+    float* ring = lds;
+    float* bq = lds + 2 * WBLK;
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t row = (size_t)blockIdx.x * 128 + 32 * w + m;
+    const bool valid = row < (size_t)rows;
+    stage_block_a(Wqkv, D, ring, w, lane);  // first QKV block flies while the input projection runs
+    stage_bias(bq, bqkv, 3 * D);
+    const float* xp = x + (valid ? row : 0) * (size_t)F + 4 * h;
+    const float* wp = Win + (size_t)n * F + 4 * h;
+    const int t = (int)((valid ? row : 0) % (size_t)T);
+    f32x16 h0[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {  // accumulators start at bias + PE (issued first, consumed last)
+        h0[nb] = zero16();
+        add_bias(h0[nb], bin + 32 * nb, h);
+        add_block(h0[nb], pe + (size_t)t * D + 32 * nb, h);
+    }
+    for (int G = 0; G < F / 8; ++G) {  // the input weights (40 KB) come straight from L2: 2.6 % of the MFMAs
+        f32x4 x4 = ld4(xp + 8 * G);
+        if (!valid) x4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const f32x4 w4 = ld4(wp + (size_t)(32 * nb) * F + 8 * G);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h0[nb] = SAVAD_MFMA(w4[e], x4[e], h0[nb]);
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        store_block(hbuf + row * D + 32 * nb, h0[nb], h);
+        if (blockIdx.x == gridDim.x - 1 && w == 3) store_block(v + (row + TILE) * D + 32 * nb, zero16(), h);  // V slack
+    }
+    f32x4 xg[16];
+    layernorm_regs(h0, xg);
+    qkv_tail_m(xg, Wqkv, bq, q, k, v, row, ring, w, lane, n, h);
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(256, 2) void row_kernel_m(
+    const float* __restrict__ Opart, const float* __restrict__ ml, int S, int rows, int rows_pad, float c,
+    float* __restrict__ hbuf, const float* __restrict__ Wo, const float* __restrict__ bo,
+    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+    const float* __restrict__ b2, const float* __restrict__ Wn, const float* __restrict__ bn, float* __restrict__ q,
+    float* __restrict__ k, float* __restrict__ v, float* __restrict__ out) {
+    // LDS: weight ring 2 x 16 KB, then biases bo[128] b1[512] b2[128] bqkv[384]
+    __shared__ __attribute__((aligned(16))) float lds[2 * WBLK + 9 * D];
+    float* ring = lds;
+    float* lbo = lds + 2 * WBLK;
+    float* lb1 = lbo + D;
+    float* lb2 = lb1 + DFF;
+    float* lbn = lb2 + D;
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t row = (size_t)blockIdx.x * 128 + 32 * w + m;
+    SAVAD_STAMP(0);
+    stage_block_a(Wo, D, ring, w, lane);
+    stage_bias(lbo, bo, D);
+    stage_bias(lb1, b1, DFF);
+    stage_bias(lb2, b2, D);
+    if (!LAST) stage_bias(lbn, bn, 3 * D);
+    // the out-projection accumulators start at the residual stream (loads issued now, consumed after phase 0)
+    f32x16 h1[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        h1[nb] = zero16();
+        add_block(h1[nb], hbuf + row * D + 32 * nb, h);
+    }
+    // ---- combine the attention splits: ctx = sum_s w_s O_s / sum_s w_s l_s (lane-local)
+    f32x4 xg[16];
+    {
+        const bool valid = row < (size_t)rows;
+        float M = NEG_BIG;
+        for (int s = 0; s < S; ++s) {
+            const float ms = ml[((size_t)s * rows_pad + row) * 2];
+            M = fmaxf(M, valid ? ms : 0.0f);
+        }
+        float den = 0.0f;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) xg[G] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            f32x2 t = *reinterpret_cast<const f32x2*>(ml + ((size_t)s * rows_pad + row) * 2);
+            if (!valid) t = f32x2{0.0f, 1.0f};
+            const float ws = __builtin_amdgcn_exp2f((t[0] - M) * c);
+            den += ws * t[1];
+            const float* op = Opart + ((size_t)s * rows_pad + row) * D + 4 * h;
+#pragma unroll
+            for (int G = 0; G < 16; ++G) {
+                f32x4 o4 = ld4(op + 8 * G);
+                if (!valid) o4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                xg[G] += ws * o4;
+            }
+        }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) xg[G] *= inv;
+    }
+    SAVAD_STAMP(1);
+    // ---- h1 = h + bo + ctx Wo^T  (ring blocks 0..3)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        ring_acquire();
+        if (nb < 3)
+            stage_block_a(Wo + (size_t)(32 * (nb + 1)) * D, D, ring + ((nb + 1) & 1) * WBLK, w, lane);
+        else
+            stage_block_a(W1, D, ring, w, lane);
+        h1[nb] += bias_block(lbo + 32 * nb, h);
+        gemm_lds_a(h1[nb], ring + (nb & 1) * WBLK, n, h, xg);
+    }
+    SAVAD_STAMP(2);
+    layernorm_regs(h1, xg);
+    SAVAD_STAMP(3);
+    // park the residual stream in hbuf (this wave owns its rows; L2-resident) instead of holding 64
+    // more registers across the FFN: keeps the kernel spill-free at 2 waves per SIMD
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) store_block(hbuf + row * D + 32 * nb, h1[nb], h);
+    // ---- FFN: 16 hidden chunks of 32; W1 chunk in ring buffer 0, W2 column slice in buffer 1
+    f32x16 o[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) o[nb] = zero16();
+    SAVAD_STAMP(4);
+#pragma unroll 1
+    for (int ch = 0; ch < 16; ++ch) {
+        ring_acquire();
+        stage_block_b(W2 + 32 * ch, DFF, ring + WBLK, w, lane);
+        f32x16 a = bias_block(lb1 + 32 * ch, h);
+        gemm_lds_a(a, ring, n, h, xg);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
+        ring_acquire();
+        if (ch + 1 < 16)
+            stage_block_a(W1 + (size_t)(32 * (ch + 1)) * D, D, ring, w, lane);
+        else if (!LAST)
+            stage_block_a(Wn, D, ring, w, lane);
+        gemm_lds_b(o, ring + WBLK, n, h, a);
+    }
+    SAVAD_STAMP(5);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        o[nb] += bias_block(lb2 + 32 * nb, h);
+        add_block(o[nb], hbuf + row * D + 32 * nb, h);  // residual onto the un-normalised stream (transformer.py:235-237)
+        if (!LAST) store_block(hbuf + row * D + 32 * nb, o[nb], h);
+    }
+    SAVAD_STAMP(6);
+    layernorm_regs(o, xg);
+    SAVAD_STAMP(7);
+    if (!LAST) {
+        qkv_tail_m(xg, Wn, lbn, q, k, v, row, ring, w, lane, n, h);
+        SAVAD_STAMP(8);
+    } else {
         float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
         for (int G = 0; G < 16; ++G) {

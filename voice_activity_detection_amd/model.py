@@ -80,6 +80,7 @@ class SelfAttentiveVAD(nn.Module):
         self._synced_versions = None
         self._workspace: Optional[Tensor] = None
         self.attention_splits = 0  # 0 = automatic
+        self.row_mode = 0  # 0 = automatic, 1 = N-split 32-row tiles, 2 = M-split 128-row tiles
 
     # ---- library handle / weights -----------------------------------------------------------
     def _ensure_handle(self, device: torch.device):
@@ -154,6 +155,7 @@ class SelfAttentiveVAD(nn.Module):
                 raise _lib.SavadError(f"model parameters are on {first.device}, features on {device}")
             self.sync_weights()
             _lib.check(lib.savad_set_attention_splits(self._handle, int(self.attention_splits)))
+            _lib.check(lib.savad_set_row_mode(self._handle, int(self.row_mode)))
             nbytes = ctypes.c_size_t()
             _lib.check(lib.savad_workspace_bytes(self._handle, B, T, ctypes.byref(nbytes)))
             ws = self._workspace
