@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 csv output (kernel trace stats + PMC passes) into a short text summary."""
 import csv
+import re
 import glob
 import os
 import sys
@@ -14,10 +15,9 @@ def find(pattern):
 
 
 def short(name):
-    for key in ("input_qkv_kernel", "attention_kernel", "row_kernel<true>", "row_kernel<false>", "row_kernel",
-                "fold_ln_kernel", "gather_windows", "boost"):
-        if key.replace("<true>", "ILb1").replace("<false>", "ILb0") in name or key in name:
-            return key
+    m = re.search(r"savad::(\w+)(<[^>]*>)?", name)
+    if m:
+        return m.group(1) + (m.group(2) or "")
     return name[:60]
 
 
@@ -64,5 +64,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_l2", "pmc_inst"):
         if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "SQ_BUSY_CYCLES" in vals and vals["SQ_BUSY_CYCLES"] > 0:
             # MFMA busy is summed over SIMDs(4/CU x 256), SQ_BUSY_CYCLES over XCD-level SQs: report raw ratio + per-GUI ratio
             if "GRBM_GUI_ACTIVE" in vals and vals["GRBM_GUI_ACTIVE"] > 0:
-                print(f"{'':28s} mfma_busy/(GRBM_GUI_ACTIVE*1024 SIMDs) = "
-                      f"{vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (vals['GRBM_GUI_ACTIVE'] * 1024):.3f}")
+                # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; MFMA busy is summed over all 1024 SIMDs
+                cyc = vals["GRBM_GUI_ACTIVE"] / 8
+                print(f"{'':28s} cycles/XCD = {cyc:.4g}; MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 1024 SIMDs) = "
+                      f"{vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024):.3f}")

@@ -93,12 +93,14 @@ int choose_splits(const savad_model* m, int B, int T) {
     if (T <= 32) return 1;
     const int NT = (T + 31) / 32, QB = NT;
     if (m->splits > 0) return m->splits < NT ? m->splits : NT;
-    // Work quantisation model: 256 CUs, 4-wave workgroups, a wave walks ceil(NT/S) key tiles.
-    // A split costs about half a tile of extra traffic (partials written and re-read); take S > 1
-    // only when it beats the unsplit schedule by more than 7 %.
+    // Work quantisation model (MFMA-bound): a workgroup puts one wave on each SIMD of a CU, so a
+    // CU that receives n workgroups needs n * ceil(NT/S) tile-times whether or not they are
+    // co-resident; prologue + epilogue + partial write/re-read cost about 1.5 tile-times per
+    // workgroup.  Measured at B=32, T=800: S=1 120 us, S=2 119 us (+4 us in the row kernel), S=5
+    // 121 us (+25 us): splitting only pays when it fills idle CUs (small batches).
     auto cost = [&](int S) {
         const long wgs = (long)B * ((QB + 3) / 4) * S;
-        return (double)((wgs + 511) / 512) * ((NT + S - 1) / S + 0.5);  // 2 workgroups resident per CU
+        return (double)((wgs + 255) / 256) * ((NT + S - 1) / S + 1.5);
     };
     const double cost1 = cost(1);
     double best = cost1;
