@@ -20,3 +20,10 @@ print("B", B, "row_last kernel stamps (ticks @100MHz?):")
 for i, nme in enumerate(names):
     print(f"  {nme:18s} {t[i+1]-t[i]:8d}")
 print("  total", t[8] - t[0] if t[8] else t[7]-t[0])
+buf2 = (ctypes.c_longlong * 32)()
+lib.savad_debug_stamps(buf2, 32)
+a = list(buf2[16:22])
+print("attention (wave 0 of WG 0), cycles summed over its key tiles:")
+for nme, val in zip(["wait+barrier", "dma issue", "S=KQ^T (64 MFMA)", "mask+softmax+rescale", "PV (64 MFMA)", "loop overhead"], a):
+    print(f"  {nme:22s} {val:9d}")
+print("  sum", sum(a))

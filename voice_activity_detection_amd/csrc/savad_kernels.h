@@ -42,7 +42,27 @@ constexpr float NEG_BIG = -1.0e30f;
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }  // partner lane (m, 1-h)
+// A data row lives in lanes m and m+32: one v_permlane32_swap hands every lane both halves' values
+// (no LDS round trip as with ds_bpermute), in the same order on both lanes (bit-identical results).
+// NB: copy the two results into scalars before __builtin_bit_cast -- bit_cast applied directly to a
+// vector-element lvalue (r[1]) reads element 0 (clang quirk; it cost a parity failure to find).
+__device__ __forceinline__ void both_halves(float v, float& lo, float& hi) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0] = low half's value, r[1] = high half's
+    const unsigned a = r[0], b = r[1];
+    lo = __builtin_bit_cast(float, a);
+    hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float half_sum(float v) {
+    float lo, hi;
+    both_halves(v, lo, hi);
+    return lo + hi;
+}
+__device__ __forceinline__ float half_max(float v) {
+    float lo, hi;
+    both_halves(v, lo, hi);
+    return fmaxf(lo, hi);
+}
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -101,7 +121,7 @@ __device__ __forceinline__ void read_rows_layernorm(const float* xbuf, int m, in
         xg[G] = ld4(xbuf + m * XLD + 8 * G + 4 * h);
         s += (xg[G][0] + xg[G][1]) + (xg[G][2] + xg[G][3]);
     }
-    s += xhalf(s);
+    s = half_sum(s);
     const float mean = s * (1.0f / D);
     float ss = 0.0f;
 #pragma unroll
@@ -113,7 +133,7 @@ __device__ __forceinline__ void read_rows_layernorm(const float* xbuf, int m, in
             ss += d * d;
         }
     }
-    ss += xhalf(ss);
+    ss = half_sum(ss);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + LN_EPS);
 #pragma unroll
     for (int G = 0; G < 16; ++G) xg[G] *= rstd;
@@ -191,7 +211,7 @@ __device__ __forceinline__ void online_softmax(f32x16& sc, float& m_run, float& 
     float mx = sc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-    mx = fmaxf(mx, xhalf(mx));
+    mx = half_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);  // base-2 domain: p = 2^((s - m) c)
     const float mc = m_new * c;
@@ -201,11 +221,13 @@ __device__ __forceinline__ void online_softmax(f32x16& sc, float& m_run, float& 
         sc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -mc));
         rs += sc[r];
     }
-    rs += xhalf(rs);
+    rs = half_sum(rs);
     l_run = l_run * alpha + rs;
     m_run = m_new;
+    if (__any(alpha != 1.0f)) {  // wave-uniform: skip the 64-register rescale when no row's maximum moved
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) O[nb] *= alpha;
+        for (int nb = 0; nb < 4; ++nb) O[nb] *= alpha;
+    }
 }
 
 __device__ __forceinline__ void store_attention_partial(float* __restrict__ Opart, float* __restrict__ ml, size_t prow,
@@ -288,39 +310,63 @@ __device__ long long g_savad_dbg[64];
 #ifndef SAVAD_ABLATE
 #define SAVAD_ABLATE 0  // experiment switch (scripts/ablate.sh): 1 = no DMA, 2 = no ring barrier, 4 = no softmax
 #endif
-__device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
-    if (SAVAD_ABLATE & 1) return;
-    // global_load_lds_dwordx4: 64 lanes x 16 B from per-lane global addresses to LDS at M0 + lane*16.
-    // Issued as inline asm ON PURPOSE: with the builtin, hipcc (ROCm 7.2) degrades every LDS wait
-    // in a region where an LDS-DMA may be outstanding to lgkmcnt(0) -- each ds_read -> MFMA wait
-    // then also drains the ds_read issued just before it (a full LDS latency exposed per 8 MFMAs,
-    // measured -25 %).  The asm form is invisible to that bookkeeping; completion is tracked by
-    // hand (ring_acquire / the attention loop: s_waitcnt vmcnt(0), then the workgroup barrier).
-    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base;
-    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(m0v)
-        : "memory");
-}
-
-// stage rows [k0, k0+32) of K and V: 32 wave-instructions of 1 KiB, 8 per wave
-__device__ __forceinline__ void stage_kv_tile(const float* __restrict__ k, const float* __restrict__ v, size_t k0,
-                                              float* kbuf, float* vbuf, int w, int lane) {
+// ---- asynchronous global -> LDS DMA (global_load_lds_dwordx4): 64 lanes x 16 B from
+// base (SGPR pair, wave-uniform) + per-lane byte offset (VGPR) to LDS at M0 + lane*16.
+// A 16 KB block is 16 such instructions; each of the 4 waves issues 4 of them (instruction index
+// i = 4*i4 + w, LDS destination block_base + i KiB).  The per-lane offsets depend only on the block
+// KIND, so they are computed once per kernel (DmaLanes) and every block costs 4 DMA + 6 SALU.
+// Issued as inline asm ON PURPOSE: with the builtin, hipcc (ROCm 7.2) degrades every LDS wait in a
+// region where an LDS-DMA may be outstanding to lgkmcnt(0); the asm form is invisible to that
+// bookkeeping and completion is tracked by hand (s_waitcnt vmcnt(0), then the workgroup barrier).
+struct DmaLanes {
+    unsigned off[4];
+};
+// kind A / K tile: 32 rows x 128 floats, row stride ld floats; chunk c of row r stored at c ^ (r & 15)
+__device__ __forceinline__ DmaLanes dma_lanes_rows32(int ld, bool swizzle, int w, int lane) {
+    DmaLanes L;
     const int sub = lane >> 5, p = lane & 31;
 #pragma unroll
     for (int i4 = 0; i4 < 4; ++i4) {
-        const int i = 4 * i4 + w;  // instruction index 0..15 -> rows 2i, 2i+1
-        const int r = 2 * i + sub;
-        dma16(k + (k0 + r) * D + 4 * (p ^ (r & 15)), kbuf + i * 256);
-        dma16(v + (k0 + r) * D + 4 * p, vbuf + i * 256);
+        const int r = 2 * (4 * i4 + w) + sub;  // 1 KiB = rows 2i, 2i+1
+        L.off[i4] = (unsigned)(r * ld + 4 * (swizzle ? (p ^ (r & 15)) : p)) * 4u;
     }
+    return L;
+}
+// kind B: 128 rows x 32 floats (column slice, row stride ld); chunk c of row r stored at c ^ ((r >> 1) & 7)
+__device__ __forceinline__ DmaLanes dma_lanes_rows128(int ld, int w, int lane) {
+    DmaLanes L;
+    const int sub = lane >> 3, p = lane & 7;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+        const int r = 8 * (4 * i4 + w) + sub;  // 1 KiB = rows 8i .. 8i+7 (128 B each)
+        L.off[i4] = (unsigned)(r * ld + 4 * (p ^ ((r >> 1) & 7))) * 4u;
+    }
+    return L;
+}
+__device__ __forceinline__ void dma_block(const float* __restrict__ base /* wave-uniform */, const DmaLanes& L,
+                                          float* lds_block, int w) {
+    if (SAVAD_ABLATE & 1) return;
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_block;
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr) + 1024u * (unsigned)w;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, m0, 4096\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_add_u32 m0, m0, 4096\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %5\n\t"
+        "s_add_u32 m0, m0, 4096\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(L.off[0]), "v"(L.off[1]), "v"(L.off[2]), "v"(L.off[3]), "s"(base), "s"(m0v)
+        : "memory");
 }
 
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -353,8 +399,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
     float m_run = NEG_BIG, l_run = 0.0f;
 
-    stage_kv_tile(k, v, kbase + 32 * (size_t)jt0, lds, lds + KV_TILE_FLOATS, w, lane);
+    const DmaLanes LK = dma_lanes_rows32(D, true, w, lane), LV = dma_lanes_rows32(D, false, w, lane);
+    dma_block(k + (kbase + 32 * (size_t)jt0) * D, LK, lds, w);
+    dma_block(v + (kbase + 32 * (size_t)jt0) * D, LV, lds + KV_TILE_FLOATS, w);
+#ifdef SAVAD_TIMING
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tp = __builtin_readcyclecounter(), tn;
+#define SAVAD_TACC(i) do { tn = __builtin_readcyclecounter(); tacc[i] += tn - tp; tp = tn; } while (0)
+#else
+#define SAVAD_TACC(i) do {} while (0)
+#endif
     for (int jt = jt0; jt < jt1; ++jt) {
+        SAVAD_TACC(5);
         float* kb = lds + ((jt - jt0) & 1) * 2 * KV_TILE_FLOATS;
         float* vb = kb + KV_TILE_FLOATS;
         // Explicit drain of this wave's DMA before the barrier: hipcc (ROCm 7.2) does NOT emit the
@@ -363,10 +418,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         // issued a whole tile (8192+ MFMA cycles) ago.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile jt has landed for every wave; everyone is done reading the other buffer
+        SAVAD_TACC(0);
         if (jt + 1 < jt1) {
             float* kn = lds + ((jt + 1 - jt0) & 1) * 2 * KV_TILE_FLOATS;
-            stage_kv_tile(k, v, kbase + 32 * (size_t)(jt + 1), kn, kn + KV_TILE_FLOATS, w, lane);
+            dma_block(k + (kbase + 32 * (size_t)(jt + 1)) * D, LK, kn, w);
+            dma_block(v + (kbase + 32 * (size_t)(jt + 1)) * D, LV, kn + KV_TILE_FLOATS, w);
         }
+        SAVAD_TACC(1);
         if (!active) continue;
         // ---- S^T tile = K Q^T
         f32x16 sc = zero16();
@@ -377,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) sc = SAVAD_MFMA(k4[e], qg[G8][e], sc);
         }
+        SAVAD_TACC(2);
         // lane (m,h), register r: score of query m against key jk = 8(r>>2) + 4h + (r&3)
         if (32 * jt + 32 > T) {
 #pragma unroll
@@ -386,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
             }
         }
         online_softmax(sc, m_run, l_run, O, c);
+        SAVAD_TACC(3);
         // ---- O^T += V^T P^T
         const float* vp = vb + 4 * h * D + n;
 #pragma unroll
@@ -393,7 +453,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
         }
+        SAVAD_TACC(4);
     }
+#ifdef SAVAD_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) g_savad_dbg[16 + i] = tacc[i];
+#endif
     if (qvalid) store_attention_partial(Opart, ml, (size_t)s * rows_pad + qrow, O, m_run, l_run, h);
 }
 
@@ -519,8 +584,8 @@ __global__ __launch_bounds__(256, 2) void row_kernel(
                 z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
             }
         }
-        z0 += xhalf(z0);
-        z1 += xhalf(z1);
+        z0 = half_sum(z0);
+        z1 = half_sum(z1);
         z0 += bn[0];
         z1 += bn[1];
         const float mx = fmaxf(z0, z1);
@@ -543,22 +608,6 @@ __global__ __launch_bounds__(256, 2) void row_kernel(
 // =============================================================================================
 constexpr int WBLK = 4096;  // floats per ring buffer (16 KB)
 
-__device__ __forceinline__ void stage_block_a(const float* __restrict__ W, int ld, float* buf, int w, int lane) {
-    const int sub = lane >> 5, p = lane & 31;
-#pragma unroll
-    for (int i4 = 0; i4 < 4; ++i4) {
-        const int i = 4 * i4 + w, r = 2 * i + sub;  // 1 KiB = rows 2i, 2i+1
-        dma16(W + (size_t)r * ld + 4 * (p ^ (r & 15)), buf + i * 256);
-    }
-}
-__device__ __forceinline__ void stage_block_b(const float* __restrict__ W, int ld, float* buf, int w, int lane) {
-    const int sub = lane >> 3, p = lane & 7;
-#pragma unroll
-    for (int i4 = 0; i4 < 4; ++i4) {
-        const int i = 4 * i4 + w, r = 8 * i + sub;  // 1 KiB = rows 8i .. 8i+7 (128 B each)
-        dma16(W + (size_t)r * ld + 4 * (p ^ ((r >> 1) & 7)), buf + i * 256);
-    }
-}
 // publish / acquire one ring block: my DMA has landed, everybody's has, and everybody is done with
 // the previous block (so its buffer may be refilled right after this returns)
 __device__ __forceinline__ void ring_acquire() {
@@ -595,7 +644,7 @@ __device__ __forceinline__ void layernorm_regs(const f32x16 (&x)[4], f32x4 (&xg)
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += x[nb][r];
-    s += xhalf(s);
+    s = half_sum(s);
     const float mean = s * (1.0f / D);
     float ss = 0.0f;
 #pragma unroll
@@ -606,7 +655,7 @@ __device__ __forceinline__ void layernorm_regs(const f32x16 (&x)[4], f32x4 (&xg)
             xg[4 * nb + (r >> 2)][r & 3] = d;
             ss += d * d;
         }
-    ss += xhalf(ss);
+    ss = half_sum(ss);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + LN_EPS);
 #pragma unroll
     for (int G = 0; G < 16; ++G) xg[G] *= rstd;
@@ -634,13 +683,13 @@ __device__ __forceinline__ f32x16 bias_block(const float* lds_bias /* &bias[n0] 
 // already be in flight into ring buffer 0; bq = LDS copy of the packed QKV bias [384].
 __device__ __forceinline__ void qkv_tail_m(const f32x4 (&xg)[16], const float* __restrict__ Wqkv, const float* bq,
                                            float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
-                                           size_t row, float* ring, int w, int lane, int n, int h) {
+                                           size_t row, float* ring, const DmaLanes& LA, int w, int n, int h) {
     float* dst[3] = {q, k, v};
     f32x16 prev = zero16();
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         ring_acquire();
-        if (j + 1 < 12) stage_block_a(Wqkv + (size_t)(32 * (j + 1)) * D, D, ring + ((j + 1) & 1) * WBLK, w, lane);
+        if (j + 1 < 12) dma_block(Wqkv + (size_t)(32 * (j + 1)) * D, LA, ring + ((j + 1) & 1) * WBLK, w);
         if (j > 0) store_block(dst[(j - 1) >> 2] + row * D + 32 * ((j - 1) & 3), prev, h);
         f32x16 acc = bias_block(bq + 32 * j, h);
         gemm_lds_a(acc, ring + (j & 1) * WBLK, n, h, xg);
@@ -660,7 +709,8 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t row = (size_t)blockIdx.x * 128 + 32 * w + m;
     const bool valid = row < (size_t)rows;
-    stage_block_a(Wqkv, D, ring, w, lane);  // first QKV block flies while the input projection runs
+    const DmaLanes LA = dma_lanes_rows32(D, true, w, lane);
+    dma_block(Wqkv, LA, ring, w);  // first QKV block flies while the input projection runs
     stage_bias(bq, bqkv, 3 * D);
     const float* xp = x + (valid ? row : 0) * (size_t)F + 4 * h;
     const float* wp = Win + (size_t)n * F + 4 * h;
@@ -689,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
     }
     f32x4 xg[16];
     layernorm_regs(h0, xg);
-    qkv_tail_m(xg, Wqkv, bq, q, k, v, row, ring, w, lane, n, h);
+    qkv_tail_m(xg, Wqkv, bq, q, k, v, row, ring, LA, w, n, h);
 }
 
 template <bool LAST>
@@ -710,7 +760,8 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t row = (size_t)blockIdx.x * 128 + 32 * w + m;
     SAVAD_STAMP(0);
-    stage_block_a(Wo, D, ring, w, lane);
+    const DmaLanes LA = dma_lanes_rows32(D, true, w, lane), LB = dma_lanes_rows128(DFF, w, lane);
+    dma_block(Wo, LA, ring, w);
     stage_bias(lbo, bo, D);
     stage_bias(lb1, b1, DFF);
     stage_bias(lb2, b2, D);
@@ -757,9 +808,9 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
     for (int nb = 0; nb < 4; ++nb) {
         ring_acquire();
         if (nb < 3)
-            stage_block_a(Wo + (size_t)(32 * (nb + 1)) * D, D, ring + ((nb + 1) & 1) * WBLK, w, lane);
+            dma_block(Wo + (size_t)(32 * (nb + 1)) * D, LA, ring + ((nb + 1) & 1) * WBLK, w);
         else
-            stage_block_a(W1, D, ring, w, lane);
+            dma_block(W1, LA, ring, w);
         h1[nb] += bias_block(lbo + 32 * nb, h);
         gemm_lds_a(h1[nb], ring + (nb & 1) * WBLK, n, h, xg);
     }
@@ -778,16 +829,16 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
 #pragma unroll 1
     for (int ch = 0; ch < 16; ++ch) {
         ring_acquire();
-        stage_block_b(W2 + 32 * ch, DFF, ring + WBLK, w, lane);
+        dma_block(W2 + 32 * ch, LB, ring + WBLK, w);
         f32x16 a = bias_block(lb1 + 32 * ch, h);
         gemm_lds_a(a, ring, n, h, xg);
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
         ring_acquire();
         if (ch + 1 < 16)
-            stage_block_a(W1 + (size_t)(32 * (ch + 1)) * D, D, ring, w, lane);
+            dma_block(W1 + (size_t)(32 * (ch + 1)) * D, LA, ring, w);
         else if (!LAST)
-            stage_block_a(Wn, D, ring, w, lane);
+            dma_block(Wn, LA, ring, w);
         gemm_lds_b(o, ring + WBLK, n, h, a);
     }
     SAVAD_STAMP(5);
@@ -801,7 +852,7 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
     layernorm_regs(o, xg);
     SAVAD_STAMP(7);
     if (!LAST) {
-        qkv_tail_m(xg, Wn, lbn, q, k, v, row, ring, w, lane, n, h);
+        qkv_tail_m(xg, Wn, lbn, q, k, v, row, ring, LA, w, n, h);
         SAVAD_STAMP(8);
     } else {
         float z0 = 0.0f, z1 = 0.0f;
@@ -814,8 +865,8 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
                 z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
             }
         }
-        z0 += xhalf(z0);
-        z1 += xhalf(z1);
+        z0 = half_sum(z0);
+        z1 = half_sum(z1);
         z0 += bn[0];
         z1 += bn[1];
         const float mx = fmaxf(z0, z1);
