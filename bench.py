@@ -36,6 +36,21 @@ def flops_per_frame(T: int) -> float:
     return 2 * F * D + L * (8 * D * D + 4 * T * D + 4 * D * 4 * D) + 4 * D
 
 
+def measured_traffic(kernel: str, B: int, T: int):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, produced by scripts/profile_gpu.sh on the default workload; FETCH_SIZE
+    doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be collected from
+    inside this process, so the number is only reported when the workload matches the profiled one."""
+    if (B, T) != (32, 800):
+        return None
+    files = sorted((REPO / "profiles").glob("*_traffic.json"))
+    if not files:
+        return None
+    data = json.loads(files[-1].read_text())
+    entry = data.get(kernel)
+    return round(entry["hbm_bytes_per_launch"]) if entry else None
+
+
 def cpu_baseline(state, T: int, seconds: float):
     """The reference's CPU path cannot travel; time its stand-ins on this host's cores on a bounded
     sample of the same workload: (a) the stock-PyTorch port (same ATen ops as the reference),
@@ -176,7 +191,9 @@ def main():
             roof = {
                 "bound": "mfma", "kernel": "attention_kernel (1 launch per layer)",
                 "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": measured_traffic("attention_kernel", B, T), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                "algorithmic_bytes": 4 * T * D_MODEL * 4 * B,
                 "ms_per_launch": round(att_ms, 4),
                 "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                 "kernels_ms": {f"{i}:{n}": round(t, 4) for i, (n, t) in enumerate(ktimes)},

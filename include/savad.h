@@ -108,6 +108,17 @@ int savad_gather_windows(const float* feature, int N, int F, int half, int jump,
 int savad_boost(const float* logp, const int64_t* positions, int count, int N, int W, float* boosted_ws, float* probs,
                 float* mean, void* stream);
 
+/* Streaming long-form mode (BASELINE.json configs[4]: sliding windows T=800, hop=400; NOT a mode of
+ * the reference, whose predictor only cuts 7-frame windows -- the rule below is this build's):
+ * window w covers frames [hop*w, hop*w+T) of feature[N,F], zero-padded past N; the number of windows
+ * is savad_stream_window_count = N <= T ? 1 : ceil((N-T)/hop) + 1.  After savad_forward on the
+ * windows, savad_overlap_merge gives probs[n] = mean over the windows covering frame n of
+ * softmax(logp[w][n-hop*w])[1] (mirrors the averaging of vad/predictor.py:95). */
+int savad_stream_window_count(int N, int T, int hop);
+int savad_gather_strided(const float* feature, int N, int F, int T, int hop, int first, int count, float* windows,
+                         void* stream);
+int savad_overlap_merge(const float* logp, int W, int N, int T, int hop, float* probs, void* stream);
+
 const char* savad_last_error(void);
 const char* savad_version(void);
 

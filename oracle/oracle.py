@@ -42,6 +42,12 @@ def lib():
         L.savad_oracle_boost.argtypes = [_fp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          _fp, _fp]
         L.savad_oracle_boost.restype = None
+        L.savad_oracle_stream_window_count.argtypes = [ctypes.c_int] * 3
+        L.savad_oracle_stream_window_count.restype = ctypes.c_int
+        L.savad_oracle_gather_strided.argtypes = [_fp] + [ctypes.c_int] * 6 + [_fp]
+        L.savad_oracle_gather_strided.restype = None
+        L.savad_oracle_overlap_merge.argtypes = [_fp] + [ctypes.c_int] * 4 + [_fp]
+        L.savad_oracle_overlap_merge.restype = None
         _LIB = L
     return _LIB
 
@@ -125,3 +131,16 @@ def predict_probabilities(state: dict, feature: np.ndarray, half: int = 19, jump
         logp = np.zeros((0, W, 2), np.float32)
         pos = np.zeros((0, W), np.int64)
     return boost(logp, pos, N)
+
+
+def predict_streaming(state: dict, feature: np.ndarray, T: int = 800, hop: int = 400, acc64: bool = False):
+    """Oracle of the streaming long-form mode (include/savad.h: savad_gather_strided / savad_overlap_merge)."""
+    feature = np.ascontiguousarray(feature, dtype=np.float32)
+    N, F = feature.shape
+    W = lib().savad_oracle_stream_window_count(N, T, hop)
+    win = np.empty((W, T, F), dtype=np.float32)
+    lib().savad_oracle_gather_strided(_p(feature), N, F, T, hop, 0, W, _p(win))
+    logp = forward(state, win, acc64=acc64)
+    probs = np.empty((N,), dtype=np.float32)
+    lib().savad_oracle_overlap_merge(_p(logp), W, N, T, hop, _p(probs))
+    return probs, logp

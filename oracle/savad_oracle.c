@@ -350,3 +350,38 @@ SAVAD_ORACLE_API void savad_oracle_boost(const float* logp, const int64_t* posit
     }
     free(boosted);
 }
+
+/* Streaming long-form mode (BASELINE.json configs[4]) -- the build's own definition (include/savad.h),
+ * not a reference mode: windows [hop*w, hop*w+T) zero-padded past N; probs[n] = mean over covering
+ * windows of softmax(logp[w][n-hop*w])[1]. */
+SAVAD_ORACLE_API int savad_oracle_stream_window_count(int N, int T, int hop) { return N <= T ? 1 : (N - T + hop - 1) / hop + 1; }
+
+SAVAD_ORACLE_API void savad_oracle_gather_strided(const float* feature, int N, int F, int T, int hop, int first, int count,
+                                                  float* windows) {
+    for (int w = 0; w < count; ++w)
+        for (int t = 0; t < T; ++t) {
+            const long frame = (long)hop * (first + w) + t;
+            float* dst = windows + ((size_t)w * T + t) * F;
+            if (frame < N)
+                memcpy(dst, feature + (size_t)frame * F, sizeof(float) * F);
+            else
+                memset(dst, 0, sizeof(float) * F);
+        }
+}
+
+SAVAD_ORACLE_API void savad_oracle_overlap_merge(const float* logp, int W, int N, int T, int hop, float* probs) {
+    for (int n = 0; n < N; ++n) {
+        int w_hi = n / hop;
+        if (w_hi > W - 1) w_hi = W - 1;
+        float acc = 0.0f;
+        int cnt = 0;
+        for (int w = w_hi; w >= 0 && n - hop * w < T; --w) {
+            const float a = logp[((size_t)w * T + (n - hop * w)) * 2], c = logp[((size_t)w * T + (n - hop * w)) * 2 + 1];
+            const float m = a > c ? a : c;
+            const float ea = expf(a - m), ec = expf(c - m);
+            acc += ec / (ea + ec);
+            ++cnt;
+        }
+        probs[n] = cnt ? acc / (float)cnt : 0.5f;
+    }
+}

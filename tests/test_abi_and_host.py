@@ -83,3 +83,23 @@ def test_seeded_weights_are_stable():
     a = seeded_features(0, (2, 3, 80))
     assert a.dtype == np.float32 and a.min() >= -13.8 and a.max() <= 4.2
     assert np.array_equal(a, seeded_features(0, (2, 3, 80)))
+
+
+def test_roc_auc_matches_definition():
+    from voice_activity_detection_amd.metrics import roc_auc
+
+    rng = np.random.default_rng(0)
+    for n in (10, 200):
+        y = rng.integers(0, 2, n)
+        y[0], y[1] = 0, 1
+        s = np.round(rng.random(n), 1)  # many ties
+        pos, neg = s[y == 1], s[y == 0]
+        brute = ((pos[:, None] > neg[None, :]).sum() + 0.5 * (pos[:, None] == neg[None, :]).sum()) / (len(pos) * len(neg))
+        assert abs(roc_auc(y, s) - brute) < 1e-12
+    try:
+        from sklearn.metrics import roc_auc_score  # what vad/evaluate.py:65 calls
+    except Exception:
+        return
+    y = rng.integers(0, 2, 500)
+    s = rng.random(500)
+    assert abs(roc_auc(y, s) - roc_auc_score(y, s)) < 1e-12

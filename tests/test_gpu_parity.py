@@ -288,3 +288,15 @@ def test_c_abi_error_behaviour(torch_cuda):
     assert b"never set" in lib.savad_last_error()
     assert lib.savad_forward(h, *args, 16, None) == -1       # workspace too small
     lib.savad_destroy(h)
+
+
+@pytest.mark.parametrize("n,T,hop", [(3000, 800, 400), (801, 800, 400), (500, 800, 400), (1234, 96, 32), (1601, 800, 400)])
+def test_streaming_long_form(torch_cuda, model, state1234, n, T, hop):
+    """BASELINE configs[4] (sliding windows T=800 hop=400, overlap-averaged): HIP path vs the oracle."""
+    from oracle import oracle
+    from voice_activity_detection_amd import StreamingPredictor
+
+    feat = feats(1000 + n, (n, 80))
+    ref, _ = oracle.predict_streaming(state1234, feat, T, hop)
+    got = StreamingPredictor(model, "cuda", T, hop, max_batch=3).predict(feat)
+    assert got.shape == (n,) and np.abs(got - ref).max() < TIGHT

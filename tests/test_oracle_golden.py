@@ -103,3 +103,17 @@ def test_torch_port_matches_golden(golden, state1234):
     assert np.abs(y - golden["g2_out"]).max() < TOL
     y = torch_port.forward(st, torch.from_numpy(seeded_features(101, (4, 7, 80)))).numpy()
     assert np.abs(y - golden["g1_out"]).max() < TOL
+
+
+def test_streaming_mode_definition(state1234):
+    # windows [hop*w, hop*w+T), zero-padded tail; every frame covered by 1..T/hop windows
+    feat = seeded_features(9, (2100, 80))
+    probs, logp = oracle.predict_streaming(state1234, feat, 800, 400)
+    assert logp.shape == (5, 800, 2) and probs.shape == (2100,)
+    assert oracle.lib().savad_oracle_stream_window_count(3600 * 100 + 1, 800, 400) == 900  # 1 h of audio @100 fps
+    # a frame covered by one window only reproduces that window's probability
+    p0 = np.exp(logp[0, :400, 1])
+    assert np.abs(probs[:400] - p0).max() < 1e-6
+    # interior frames: mean of the two covering windows
+    p01 = 0.5 * (np.exp(logp[0, 400:800, 1]) + np.exp(logp[1, 0:400, 1]))
+    assert np.abs(probs[400:800] - p01).max() < 1e-6

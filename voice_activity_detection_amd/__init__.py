@@ -3,7 +3,7 @@ voithru/voice-activity-detection: ``SelfAttentiveVAD.forward`` as driven by
 ``VADFromScratchPredictor.predict_probabilities``).  See DESIGN.md / INTEGRATION.md."""
 from .seeded import seeded_features, seeded_state_dict, state_dict_spec  # noqa: F401
 
-__all__ = ["SelfAttentiveVAD", "VADFromScratchPredictor", "ContextResolution", "seeded_state_dict",
+__all__ = ["SelfAttentiveVAD", "VADFromScratchPredictor", "ContextResolution", "StreamingPredictor", "seeded_state_dict",
            "seeded_features", "state_dict_spec"]
 
 
@@ -11,7 +11,7 @@ def __getattr__(name):  # torch / libsavad are imported lazily (seeded.py is num
     if name == "SelfAttentiveVAD":
         from .model import SelfAttentiveVAD
         return SelfAttentiveVAD
-    if name in ("VADFromScratchPredictor", "ContextResolution", "window_offsets"):
+    if name in ("VADFromScratchPredictor", "ContextResolution", "window_offsets", "StreamingPredictor"):
         from . import predictor
         return getattr(predictor, name)
     raise AttributeError(name)

@@ -37,6 +37,9 @@ SYMBOLS = {
     "savad_window_offsets": (c_int, [c_int, c_int, POINTER(c_int32)]),
     "savad_gather_windows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "savad_boost": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "savad_stream_window_count": (c_int, [c_int, c_int, c_int]),
+    "savad_gather_strided": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "savad_overlap_merge": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "savad_last_error": (c_char_p, []),
     "savad_version": (c_char_p, []),
 }

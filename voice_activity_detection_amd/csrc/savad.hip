@@ -510,6 +510,33 @@ SAVAD_EXPORT int savad_boost(const float* logp, const int64_t* positions, int co
     return SAVAD_OK;
 }
 
+SAVAD_EXPORT int savad_stream_window_count(int N, int T, int hop) {
+    if (N <= 0 || T <= 0 || hop <= 0) return fail(SAVAD_E_INVALID, "N=%d T=%d hop=%d", N, T, hop);
+    return N <= T ? 1 : (N - T + hop - 1) / hop + 1;
+}
+
+SAVAD_EXPORT int savad_gather_strided(const float* feature, int N, int F, int T, int hop, int first, int count,
+                                      float* windows, void* stream) {
+    if (count == 0) return SAVAD_OK;
+    if (!feature || !windows || N <= 0 || F <= 0 || F % 4 || T <= 0 || hop <= 0 || first < 0 || count < 0)
+        return fail(SAVAD_E_INVALID, "bad argument (F must be a multiple of 4)");
+    const size_t total = (size_t)count * T * (F / 4);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gather_strided_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feature, N, F, T, hop, first,
+                       count, windows);
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
+SAVAD_EXPORT int savad_overlap_merge(const float* logp, int W, int N, int T, int hop, float* probs, void* stream) {
+    if (N <= 0) return SAVAD_OK;
+    if (!logp || !probs || W <= 0 || T <= 0 || hop <= 0) return fail(SAVAD_E_INVALID, "bad argument");
+    const int grid = (N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048;
+    hipLaunchKernelGGL(overlap_merge_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logp, W, N, T, hop, probs);
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
 #ifdef SAVAD_TIMING
 // experiments only: read the phase stamps of the last row_kernel_m launch
 SAVAD_EXPORT int savad_debug_stamps(long long* out, int n) {

@@ -949,4 +949,43 @@ __global__ void boost_softmax_kernel(const float* __restrict__ boosted, int N, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming long-form mode (BASELINE configs[4]; not a reference mode -- the reference would cut
+// 7-frame windows): window w covers frames [hop*w, hop*w + T) of feature[N][F], zero-padded past N.
+// ---------------------------------------------------------------------------------------------
+__global__ void gather_strided_kernel(const float* __restrict__ feature, int N, int F, int T, int hop, int first,
+                                      int count, float* __restrict__ windows) {
+    const int f4 = F / 4;
+    const size_t total = (size_t)count * T * f4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % f4);
+        const size_t wt = i / f4;
+        const int t = (int)(wt % T);
+        const size_t wi = wt / T;
+        const long frame = (long)hop * (long)(first + wi) + t;
+        f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (frame < N) val = ld4(feature + (size_t)frame * F + 4 * c);
+        st4(windows + wt * F + 4 * c, val);
+    }
+}
+// probs[n] = mean over the windows w covering frame n (hop*w <= n < hop*w + T, 0 <= w < W) of
+// softmax(logp[w][n - hop*w])[1]
+__global__ void overlap_merge_kernel(const float* __restrict__ logp, int W, int N, int T, int hop,
+                                     float* __restrict__ probs) {
+    for (int nrow = blockIdx.x * blockDim.x + threadIdx.x; nrow < N; nrow += gridDim.x * blockDim.x) {
+        int w_hi = nrow / hop;
+        if (w_hi > W - 1) w_hi = W - 1;
+        float acc = 0.0f;
+        int cnt = 0;
+        for (int wi = w_hi; wi >= 0 && nrow - hop * wi < T; --wi) {
+            const f32x2 z = *reinterpret_cast<const f32x2*>(logp + ((size_t)wi * T + (nrow - hop * wi)) * 2);
+            const float mx = fmaxf(z[0], z[1]);
+            const float e0 = expf(z[0] - mx), e1 = expf(z[1] - mx);
+            acc += e1 / (e0 + e1);
+            ++cnt;
+        }
+        probs[nrow] = cnt ? acc / (float)cnt : 0.5f;
+    }
+}
+
 }  // namespace savad

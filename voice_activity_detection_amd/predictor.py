@@ -92,3 +92,50 @@ class VADFromScratchPredictor:
                                            W, ctypes.c_void_p(boosted.data_ptr()), ctypes.c_void_p(probs.data_ptr()),
                                            ctypes.c_void_p(mean.data_ptr()), stream))
         return probs, mean
+
+
+class StreamingPredictor:
+    """Long-form mode of BASELINE.json configs[4]: sliding windows of T frames every `hop` frames over
+    a long feature matrix [N, F]; each window is one sequence of the self-attentive model; per-frame
+    speech probability = mean over the (<= T/hop) windows covering the frame.  Not a mode of the
+    reference (its predictor only cuts 7-frame windows); semantics defined in include/savad.h.
+    With torch.distributed initialised, windows are sharded contiguously over the ranks and the
+    log-probs are exchanged with ONE all_gather (voice_activity_detection_amd.distributed)."""
+
+    def __init__(self, model: SelfAttentiveVAD, device, T: int = 800, hop: int = 400, max_batch: int = 256):
+        self.model, self.device, self.T, self.hop, self.max_batch = model, torch.device(device), int(T), int(hop), int(max_batch)
+
+    @torch.no_grad()
+    def predict_device(self, feature):
+        import torch.distributed as dist
+
+        from .distributed import all_gather_rows, shard_bounds
+
+        lib = _lib.load()
+        feat = torch.as_tensor(feature, dtype=torch.float32).to(self.device).contiguous()
+        N, F = feat.shape
+        T, hop = self.T, self.hop
+        W = lib.savad_stream_window_count(N, T, hop)
+        if W < 0:
+            _lib.check(W)
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        lo, hi = shard_bounds(W, rank, world)
+        self.model.eval()
+        with torch.cuda.device(self.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            local = torch.empty((hi - lo, T, 2), dtype=torch.float32, device=self.device)
+            for first in range(lo, hi, self.max_batch):
+                count = min(self.max_batch, hi - first)
+                win = torch.empty((count, T, F), dtype=torch.float32, device=self.device)
+                _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), N, F, T, hop, first, count,
+                                                    ctypes.c_void_p(win.data_ptr()), stream))
+                local[first - lo:first - lo + count] = self.model(features=win)
+            logp = all_gather_rows(local, W) if world > 1 else local
+            probs = torch.empty((N,), dtype=torch.float32, device=self.device)
+            _lib.check(lib.savad_overlap_merge(ctypes.c_void_p(logp.contiguous().data_ptr()), W, N, T, hop,
+                                               ctypes.c_void_p(probs.data_ptr()), stream))
+        return probs
+
+    def predict(self, feature) -> np.ndarray:
+        return self.predict_device(feature).cpu().numpy()
