@@ -28,6 +28,7 @@ sys.path.insert(0, str(REPO))
 
 F_MEL, D_MODEL, N_LAYERS = 80, 128, 3
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: bf16 MFMA, dense (AMD's 5 PF figure includes 2:1 sparsity)
 
 
 def flops_per_frame(T: int) -> float:
@@ -110,6 +111,8 @@ def main():
     ap.add_argument("--frames", type=int, default=800, help="T")
     ap.add_argument("--splits", type=int, default=0, help="attention key splits (0 = auto)")
     ap.add_argument("--row-mode", type=int, default=0, help="0 auto, 1 N-split 32-row tiles, 2 M-split 128-row tiles")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = BASELINE configs[1] (default); bf16 = configs[2]: bf16 MFMA operands, bf16 features")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
@@ -142,8 +145,11 @@ def main():
     model = model.to(dev).eval()
     model.attention_splits = args.splits
     model.row_mode = args.row_mode
+    model.precision = args.precision
     # each rank gets its own shard of the global batch (weak scaling: B per GPU fixed)
     x = torch.from_numpy(np.random.default_rng(rank).uniform(-13.8, 4.2, (B, T, F_MEL)).astype(np.float32)).to(dev)
+    if args.precision == "bf16":
+        x = x.to(torch.bfloat16)
     gathered = torch.empty((world, B, T, 2), dtype=torch.float32, device=dev) if world > 1 else None
 
     def step():
@@ -184,26 +190,27 @@ def main():
         fwd_tflops = flops_per_frame(T) * B * T / (elapsed / args.steps) / 1e12  # per GPU
         roof = None
         if ktimes:
-            att = [t for n, t in ktimes if n == "attention"]
+            peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
+            att = [t for n, t in ktimes if n.startswith("attention")]
             att_ms = sum(att) / len(att)
             att_flops = 4.0 * T * T * D_MODEL * B  # QK^T + PV of one layer's launch
             ach = att_flops / (att_ms * 1e-3) / 1e12
             roof = {
                 "bound": "mfma", "kernel": "attention_kernel (1 launch per layer)",
-                "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": measured_traffic("attention_kernel", B, T), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4),
+                "traffic": measured_traffic("attention_kernel", B, T) if args.precision == "fp32" else None, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                 "algorithmic_bytes": 4 * T * D_MODEL * 4 * B,
                 "ms_per_launch": round(att_ms, 4),
-                "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+                "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / peak, 4),
                 "kernels_ms": {f"{i}:{n}": round(t, 4) for i, (n, t) in enumerate(ktimes)},
             }
         line = {
             "metric": "audio frames/sec (whole node)", "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate",
             "data": "synthetic (seeded U(-13.8,4.2) mel frames, seeded random-init weights)",
-            "config": {"workload": f"BASELINE configs[1]: synthetic [B={B}, T={T}, F={F_MEL}] fp32 per GPU, "
+            "config": {"workload": f"BASELINE configs[{1 if args.precision == 'fp32' else 2}]: synthetic [B={B}, T={T}, F={F_MEL}] {args.precision} per GPU, "
                                    f"SelfAttentiveVAD(80, 3, 128) forward -> log-probs [B,T,2]",
                        "global_batch": world * B, "frames_per_sequence": T,
                        "parallelism": f"batch-shard x{world}" + (" + 1 RCCL all_gather" if world > 1 else "")},

@@ -75,6 +75,16 @@ int savad_workspace_bytes(savad_handle h, int B, int T, size_t* bytes);
 int savad_forward(savad_handle h, const float* x, int B, int T, float* out, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* Arithmetic of the forward pass: 0 = fp32 operands on the exact-fp32 MFMA (default; log-probs within
+ * 1e-4 of the reference), 1 = bf16 operands (weights, Q/K/V, probabilities, FFN activations) with fp32
+ * accumulation, fp32 softmax / LayerNorm statistics and an fp32 residual stream (BASELINE.json
+ * configs[2..3]; judged on AUC, not on 1e-4).  Needs feature_size % 16 == 0. */
+int savad_set_precision(savad_handle h, int precision);
+/* savad_forward with an explicit feature dtype: x_dtype 0 = fp32 [B,T,F], 1 = bf16 [B,T,F] (bf16
+ * precision only).  Output is always fp32 log-probabilities. */
+int savad_forward_ex(savad_handle h, const void* x, int x_dtype, int B, int T, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* Tuning knob: number of key-range splits of the attention stage (0 = automatic). */
 int savad_set_attention_splits(savad_handle h, int splits);
 /* Tuning knob: tiling of the row-wise stages: 0 = automatic, 1 = 32-row tiles with the output

@@ -300,3 +300,78 @@ def test_streaming_long_form(torch_cuda, model, state1234, n, T, hop):
     ref, _ = oracle.predict_streaming(state1234, feat, T, hop)
     got = StreamingPredictor(model, "cuda", T, hop, max_batch=3).predict(feat)
     assert got.shape == (n,) and np.abs(got - ref).max() < TIGHT
+
+
+# ---- bf16 operands (BASELINE configs[2..3]): judged on AUC and a loose log-prob bound, not on 1e-4 ----------
+BF16_TOL = 2e-2  # measured 5.6e-3 max-abs log-prob error (fp32 residual stream + statistics); torch-CPU bf16 end-to-end shows 1.5e-2
+
+
+def run_bf16(torch, model, x, bf16_input=False):
+    model.precision = "bf16"
+    try:
+        t = torch.from_numpy(x).to("cuda")
+        if bf16_input:
+            t = t.to(torch.bfloat16)
+        with torch.no_grad():
+            y = model(features=t)
+        torch.cuda.synchronize()
+    finally:
+        model.precision = "fp32"
+    return y.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [(4, 7, 80), (1000, 7, 80), (3, 33, 80), (2, 96, 80), (3, 800, 80), (2, 801, 80), (5, 16, 80),
+                                   (1, 1, 80), (37, 3, 80)])
+def test_bf16_close_to_fp32_oracle(torch_cuda, model, state1234, shape):
+    from oracle import oracle
+
+    x = feats(sum(shape), shape)
+    ref = oracle.forward(state1234, x)
+    y = run_bf16(torch_cuda, model, x)
+    assert y.shape == ref.shape and np.isfinite(y).all()
+    err = np.abs(y - ref).max()
+    assert err < BF16_TOL, err
+    assert np.abs(np.logaddexp(y[..., 0], y[..., 1])).max() < 1e-5
+    # and it really is a different arithmetic, not the fp32 path relabelled
+    if np.prod(shape[:2]) > 64:
+        assert err > 1e-5
+
+
+def test_bf16_input_tensor(torch_cuda, model, state1234):
+    from oracle import oracle
+
+    torch = torch_cuda
+    x = feats(5, (4, 64, 80))
+    xb = torch.from_numpy(x).to(torch.bfloat16).float().numpy()  # what the kernel sees
+    ref = oracle.forward(state1234, xb)
+    y = run_bf16(torch, model, x, bf16_input=True)
+    assert np.abs(y - ref).max() < BF16_TOL
+
+
+def test_bf16_auc_matches_fp32(torch_cuda, model, state1234):
+    """north_star: per-frame AUC equal to the reference within 1e-3.  No trained checkpoint or labelled
+    features exist here, so labels come from a noisy teacher built on the fp32 oracle's own scores
+    (AUC around 0.8): the bf16 path must rank the frames like the fp32 reference does."""
+    from oracle import oracle
+    from voice_activity_detection_amd.metrics import roc_auc
+
+    x = feats(321, (24, 800, 80))
+    ref = oracle.forward(state1234, x)
+    y = run_bf16(torch_cuda, model, x)
+    s_ref, s_bf = ref[..., 1].ravel(), y[..., 1].ravel()
+    rng = np.random.default_rng(0)
+    labels = (s_ref + rng.normal(0, s_ref.std(), s_ref.shape)) > np.median(s_ref)
+    a_ref, a_bf = roc_auc(labels, s_ref), roc_auc(labels, s_bf)
+    assert 0.6 < a_ref < 0.95
+    assert abs(a_ref - a_bf) < 1e-3, (a_ref, a_bf)
+    # hard decisions at the reference's threshold 0.5 (vad/predictor.py:96) agree almost everywhere
+    agree = ((np.exp(s_ref) > 0.5) == (np.exp(s_bf) > 0.5)).mean()
+    assert agree > 0.995, agree
+
+
+def test_bf16_permutation_and_determinism(torch_cuda, model):
+    x = feats(6, (16, 800, 80))
+    y = run_bf16(torch_cuda, model, x)
+    perm = np.random.default_rng(1).permutation(16)
+    assert np.array_equal(run_bf16(torch_cuda, model, x[perm]), y[perm])
+    assert np.array_equal(run_bf16(torch_cuda, model, x), y)

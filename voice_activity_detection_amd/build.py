@@ -9,7 +9,7 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 SRC = PKG / "csrc" / "savad.hip"
-DEPS = [SRC, PKG / "csrc" / "savad_kernels.h", PKG.parent / "include" / "savad.h"]
+DEPS = sorted((PKG / "csrc").glob("*.h")) + sorted((PKG / "csrc").glob("*.hip")) + [PKG.parent / "include" / "savad.h"]
 LIB = PKG / "libsavad.so"
 
 

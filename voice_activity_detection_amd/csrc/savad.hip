@@ -2,6 +2,7 @@
 // Owns the packed weights, the positional-encoding cache, and the 7-launch forward schedule:
 //   input_qkv -> [attention(l) -> row(l)] x L      (row(L-1) ends in classifier + log-softmax)
 #include "savad_kernels.h"
+#include "savad_kernels_bf16.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -59,6 +60,15 @@ struct savad_model {
     std::vector<float> h_pe;
     int splits = 0;
     int row_mode = 0;  // 0 auto, 1 N-split (32-row tiles), 2 M-split (128-row tiles)
+    int precision = 0;  // 0 = fp32 MFMA, 1 = bf16 MFMA operands (fp32 accumulate / statistics / residual stream)
+    char* d_frag = nullptr;  // bf16 weight fragments (savad_kernels_bf16.h), filled when precision == 1
+    size_t frag_bytes = 0;
+    bool frag_dirty = true;
+    size_t f_win = 0;
+    struct LayerFrag {
+        size_t wqkv, wo, w1, w2;
+    };
+    std::vector<LayerFrag> lf;
     // profiling
     int prof_capacity = 0, prof_used = 0, prof_nk = 0;
     std::vector<hipEvent_t> events;  // prof_capacity * MAX_EVENTS
@@ -205,6 +215,64 @@ int prepare_weights(savad_model* m, hipStream_t st) {
     return SAVAD_OK;
 }
 
+int pack_frags(savad_model* m, hipStream_t st, const float* W, int N, int K, size_t off) {
+    const size_t total = (size_t)N * K;
+    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(bf::pack_weight_frags_kernel, dim3(grid), dim3(256), 0, st, W, N, K,
+                       reinterpret_cast<__bf16*>(m->d_frag + off));
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
+int prepare_frags(savad_model* m, hipStream_t st) {
+    if (!m->frag_dirty) return SAVAD_OK;
+    const int F = m->cfg.feature_size, L = m->cfg.num_layers;
+    int rc;
+    if ((rc = pack_frags(m, st, m->d_raw + m->r_win, D, F, m->f_win))) return rc;
+    for (int l = 0; l < L; ++l) {
+        if ((rc = pack_frags(m, st, m->d_packed + m->lp[l].wqkv, 3 * D, D, m->lf[l].wqkv))) return rc;
+        if ((rc = pack_frags(m, st, m->d_raw + m->lr[l].wo, D, D, m->lf[l].wo))) return rc;
+        if ((rc = pack_frags(m, st, m->d_packed + m->lp[l].w1, DFF, D, m->lf[l].w1))) return rc;
+        if ((rc = pack_frags(m, st, m->d_raw + m->lr[l].w2, D, DFF, m->lf[l].w2))) return rc;
+    }
+    m->frag_dirty = false;
+    return SAVAD_OK;
+}
+
+// block space of the bf16 path (savad_kernels_bf16.h)
+struct BlockPlan {
+    int nblk, nblk_pad;
+    size_t h, q, k, vt, ctx, total;  // byte offsets
+};
+BlockPlan plan_blocks(int B, int T) {
+    BlockPlan p;
+    if (T > 32)
+        p.nblk = B * ((T + 31) / 32);
+    else
+        p.nblk = (B + (32 / T) - 1) / (32 / T);
+    p.nblk_pad = (p.nblk + 3) / 4 * 4;
+    size_t off = 0;
+    p.h = off;
+    off += (size_t)p.nblk_pad * bf::HBLK_FLOATS * sizeof(float);
+    const size_t fb = (size_t)(p.nblk_pad + 1) * bf::BLK_BYTES;  // +1 block: a 2-block key stage may over-read
+    p.q = off;
+    off += fb;
+    p.k = off;
+    off += fb;
+    p.vt = off;
+    off += fb;
+    p.ctx = off;
+    off += fb;
+    p.total = off;
+    return p;
+}
+
+template <typename KernelT>
+int allow_lds(KernelT kernel, int bytes) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return SAVAD_OK;
+}
+
 struct Prof {
     savad_model* m;
     hipStream_t st;
@@ -288,7 +356,22 @@ SAVAD_EXPORT int savad_create(const savad_config* cfg, savad_handle* out) {
     m->packed_floats += 2 * D;
     m->p_bc = m->packed_floats;
     m->packed_floats += 4;
+    m->lf.resize(L);
+    m->f_win = 0;
+    m->frag_bytes = (size_t)D * F * 2;
+    for (int l = 0; l < L; ++l) {
+        auto& fl = m->lf[l];
+        fl.wqkv = m->frag_bytes;
+        m->frag_bytes += (size_t)3 * D * D * 2;
+        fl.wo = m->frag_bytes;
+        m->frag_bytes += (size_t)D * D * 2;
+        fl.w1 = m->frag_bytes;
+        m->frag_bytes += (size_t)DFF * D * 2;
+        fl.w2 = m->frag_bytes;
+        m->frag_bytes += (size_t)D * DFF * 2;
+    }
     hipError_t e = hipMalloc(&m->d_raw, sizeof(float) * m->raw_floats);
+    if (e == hipSuccess) e = hipMalloc(&m->d_frag, m->frag_bytes);
     if (e == hipSuccess) e = hipMalloc(&m->d_packed, sizeof(float) * m->packed_floats);
     if (e != hipSuccess) {
         if (m->d_raw) hipFree(m->d_raw);
@@ -304,6 +387,7 @@ SAVAD_EXPORT void savad_destroy(savad_handle m) {
     for (hipEvent_t e : m->events) hipEventDestroy(e);
     if (m->d_raw) hipFree(m->d_raw);
     if (m->d_packed) hipFree(m->d_packed);
+    if (m->d_frag) hipFree(m->d_frag);
     if (m->d_pe) hipFree(m->d_pe);
     delete m;
 }
@@ -325,6 +409,7 @@ SAVAD_EXPORT int savad_set_param(savad_handle m, const char* key, const float* d
         HIP_TRY(hipMemcpyAsync(m->d_raw + p.off, data, sizeof(float) * numel, hipMemcpyDefault, (hipStream_t)stream));
         p.set = true;
         m->dirty = true;
+        m->frag_dirty = true;
         return SAVAD_OK;
     }
     return fail(SAVAD_E_NOKEY, "unexpected key '%s' in state_dict", key);
@@ -345,8 +430,107 @@ SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
 SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* bytes) {
     if (!m || !bytes || B < 0 || T < 0) return fail(SAVAD_E_INVALID, "bad argument");
     if ((double)B * T * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "B*T=%ld rows exceed the 32-bit tile index range", (long)B * T);
-    *bytes = (B == 0 || T == 0) ? 0 : plan(m, B, T).total * sizeof(float);
+    if (B == 0 || T == 0)
+        *bytes = 0;
+    else if (m->precision == 1)
+        *bytes = plan_blocks(B, T).total;
+    else
+        *bytes = plan(m, B, T).total * sizeof(float);
     return SAVAD_OK;
+}
+
+SAVAD_EXPORT int savad_set_precision(savad_handle m, int precision) {
+    if (!m || precision < 0 || precision > 1) return fail(SAVAD_E_INVALID, "precision %d (0 = fp32, 1 = bf16)", precision);
+    if (precision == 1 && m->cfg.feature_size % 16)
+        return fail(SAVAD_E_UNSUPPORTED, "bf16 path needs feature_size %% 16 == 0 (got %d)", m->cfg.feature_size);
+    m->precision = precision;
+    return SAVAD_OK;
+}
+
+namespace {
+
+// bf16-operand forward: input_qkv -> [attention -> row] x L on fragment-major buffers
+int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, float* out, void* workspace,
+                 size_t workspace_bytes, hipStream_t st) {
+    const BlockPlan bp = plan_blocks(B, T);
+    if (workspace_bytes < bp.total) return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, bp.total);
+    int rc;
+    if ((rc = prepare_weights(m, st))) return rc;
+    if ((rc = prepare_frags(m, st))) return rc;
+    if ((rc = ensure_pe(m, T, st))) return rc;
+    char* W = (char*)workspace;
+    float* hb = (float*)(W + bp.h);
+    char *qf = W + bp.q, *kf = W + bp.k, *vtf = W + bp.vt, *ctxf = W + bp.ctx;
+    const int F = m->cfg.feature_size, L = m->cfg.num_layers;
+    const float c = (float)(1.4426950408889634 / sqrt((double)D));
+    const float* R = m->d_raw;
+    const float* P = m->d_packed;
+    const char* Fr = m->d_frag;
+    const int grid_rows = bp.nblk_pad / 4;
+    const int lds_in = 2 * bf::RING_BYTES + 3 * D * 4, lds_att = 8 * bf::BLK_BYTES, lds_row = 2 * bf::RING_BYTES + 9 * D * 4;
+    static bool attrs_done = false;
+    if (!attrs_done) {
+        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float>, lds_in))) return rc;
+        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16>, lds_in))) return rc;
+        if ((rc = allow_lds(bf::attention_kernel_bf16, lds_att))) return rc;
+        if ((rc = allow_lds(bf::row_kernel_bf16<false>, lds_row))) return rc;
+        if ((rc = allow_lds(bf::row_kernel_bf16<true>, lds_row))) return rc;
+        attrs_done = true;
+    }
+    Prof prof(m, st);
+    if (x_is_bf16)
+        hipLaunchKernelGGL(bf::input_qkv_kernel_bf16<__bf16>, dim3(grid_rows), dim3(256), lds_in, st, (const __bf16*)x, B, T, F,
+                           bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf, kf, vtf);
+    else
+        hipLaunchKernelGGL(bf::input_qkv_kernel_bf16<float>, dim3(grid_rows), dim3(256), lds_in, st, (const float*)x, B, T, F,
+                           bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf, kf, vtf);
+    prof.mark("input_qkv_bf16");
+    for (int l = 0; l < L; ++l) {
+        if (T <= 32) {
+            hipLaunchKernelGGL(bf::attention_packed_kernel_bf16, dim3((bp.nblk + 3) / 4), dim3(256), 0, st, qf, kf, vtf, ctxf, B,
+                               T, bp.nblk, c);
+        } else {
+            const int QB = (T + 31) / 32, NG = (QB + 3) / 4;
+            hipLaunchKernelGGL(bf::attention_kernel_bf16, dim3(8 * ((B + 7) / 8) * NG), dim3(256), lds_att, st, qf, kf, vtf, ctxf,
+                               B, T, NG, c);
+        }
+        prof.mark("attention_bf16");
+        const auto& r = m->lr[l];
+        const auto& p = m->lp[l];
+        const auto& f = m->lf[l];
+        if (l + 1 < L) {
+            hipLaunchKernelGGL(bf::row_kernel_bf16<false>, dim3(grid_rows), dim3(256), lds_row, st, ctxf, B, T, bp.nblk, hb,
+                               Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, Fr + m->lf[l + 1].wqkv,
+                               (const float*)nullptr, P + m->lp[l + 1].bqkv, qf, kf, vtf, out);
+            prof.mark("row_bf16");
+        } else {
+            hipLaunchKernelGGL(bf::row_kernel_bf16<true>, dim3(grid_rows), dim3(256), lds_row, st, ctxf, B, T, bp.nblk, hb,
+                               Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, (const char*)nullptr,
+                               P + m->p_wc, P + m->p_bc, qf, kf, vtf, out);
+            prof.mark("row_last_bf16");
+        }
+    }
+    prof.done();
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
+}  // namespace
+
+// x_dtype: 0 = fp32 features, 1 = bf16 features (bf16 precision only)
+SAVAD_EXPORT int savad_forward_ex(savad_handle m, const void* x, int x_dtype, int B, int T, float* out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!m) return fail(SAVAD_E_INVALID, "null handle");
+    if (x_dtype == 0 && m->precision == 0) return savad_forward(m, (const float*)x, B, T, out, workspace, workspace_bytes, stream);
+    if (x_dtype < 0 || x_dtype > 1) return fail(SAVAD_E_INVALID, "x_dtype %d", x_dtype);
+    if (m->precision != 1) return fail(SAVAD_E_UNSUPPORTED, "bf16 features need savad_set_precision(h, 1)");
+    if (B < 0 || T < 0) return fail(SAVAD_E_INVALID, "negative shape B=%d T=%d", B, T);
+    if (B == 0 || T == 0) return SAVAD_OK;
+    if (!x || !out || !workspace) return fail(SAVAD_E_INVALID, "null tensor pointer");
+    if ((double)B * T * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "B*T too large");
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)workspace) & 15)
+        return fail(SAVAD_E_INVALID, "x, out and workspace must be 16-byte aligned");
+    return forward_bf16(m, x, x_dtype, B, T, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, float* out, void* workspace,
@@ -359,6 +543,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)workspace) & 15)
         return fail(SAVAD_E_INVALID, "x, out and workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (m->precision == 1) return forward_bf16(m, x, 0, B, T, out, workspace, workspace_bytes, st);
     const Workspace ws = plan(m, B, T);
     if (workspace_bytes < ws.total * sizeof(float))
         return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, ws.total * sizeof(float));

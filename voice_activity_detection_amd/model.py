@@ -81,6 +81,9 @@ class SelfAttentiveVAD(nn.Module):
         self._workspace: Optional[Tensor] = None
         self.attention_splits = 0  # 0 = automatic
         self.row_mode = 0  # 0 = automatic, 1 = N-split 32-row tiles, 2 = M-split 128-row tiles
+        # "fp32": exact-fp32 MFMA (default, log-probs within 1e-4 of the reference).
+        # "bf16": bf16 MFMA operands, fp32 accumulation / statistics / residual stream (BASELINE configs[2..3]).
+        self.precision = "fp32"
 
     # ---- library handle / weights -----------------------------------------------------------
     def _ensure_handle(self, device: torch.device):
@@ -139,8 +142,13 @@ class SelfAttentiveVAD(nn.Module):
         if self.training and self.dropout_p > 0:
             raise _lib.SavadError("training-mode dropout is outside this build's scope: call model.eval()")
         device = features.device
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.precision!r}")
         x = features.detach()
-        if x.dtype != torch.float32:
+        x_dtype = 0
+        if self.precision == "bf16" and x.dtype == torch.bfloat16:
+            x_dtype = 1  # bf16 features are consumed as they are
+        elif x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
         B, T, _ = x.shape
@@ -156,6 +164,7 @@ class SelfAttentiveVAD(nn.Module):
             self.sync_weights()
             _lib.check(lib.savad_set_attention_splits(self._handle, int(self.attention_splits)))
             _lib.check(lib.savad_set_row_mode(self._handle, int(self.row_mode)))
+            _lib.check(lib.savad_set_precision(self._handle, 1 if self.precision == "bf16" else 0))
             nbytes = ctypes.c_size_t()
             _lib.check(lib.savad_workspace_bytes(self._handle, B, T, ctypes.byref(nbytes)))
             ws = self._workspace
@@ -163,9 +172,9 @@ class SelfAttentiveVAD(nn.Module):
                 ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)  # caching allocator owns it
                 self._workspace = ws
             stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(lib.savad_forward(self._handle, ctypes.c_void_p(x.data_ptr()), B, T,
-                                         ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                                         ws.numel(), ctypes.c_void_p(stream)))
+            _lib.check(lib.savad_forward_ex(self._handle, ctypes.c_void_p(x.data_ptr()), x_dtype, B, T,
+                                            ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                            ws.numel(), ctypes.c_void_p(stream)))
         return out
 
     # ---- profiling hooks used by bench.py -------------------------------------------------------
