@@ -15,7 +15,7 @@ def find(pattern):
 
 
 def short(name):
-    m = re.search(r"savad::(\w+)(<[^>]*>)?", name)
+    m = re.search(r"savad::(?:bf::)?(\w+)(<[^>]*>)?", name)
     if m:
         return m.group(1) + (m.group(2) or "")
     return name[:60]
