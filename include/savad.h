@@ -129,6 +129,17 @@ int savad_gather_strided(const float* feature, int N, int F, int T, int hop, int
                          void* stream);
 int savad_overlap_merge(const float* logp, int W, int N, int T, int hop, float* probs, void* stream);
 
+/* Log-mel front-end (next-row 1 of the scope table): replaces, for the reference's only transform
+ * configuration (n_fft 512, hop 160, window 400, 80 mels, 16 kHz: tests/configs/vad/train_config.yaml:
+ * 18-26), FeatureExtractor.extract_with_postprocessing = librosa.feature.melspectrogram(...) ->
+ * log(x + 1e-6) -> transpose (vad/acoustics/transforms/log_mel_spectrogram.py:19-32,
+ * vad/acoustics/feature_extractor.py:71-80).  audio: n_samples fp32 mono 16 kHz (device);
+ * features: [savad_logmel_frames(n_samples) = 1 + n_samples/160][80] fp32 (device), ready to be the
+ * model's / predictor's feature matrix; workspace: savad_logmel_workspace_bytes(n_samples) bytes. */
+int savad_logmel_frames(int n_samples);
+size_t savad_logmel_workspace_bytes(int n_samples);
+int savad_logmel(const float* audio, int n_samples, float* workspace, float* features, void* stream);
+
 const char* savad_last_error(void);
 const char* savad_version(void);
 

@@ -375,3 +375,46 @@ def test_bf16_permutation_and_determinism(torch_cuda, model):
     perm = np.random.default_rng(1).permutation(16)
     assert np.array_equal(run_bf16(torch_cuda, model, x[perm]), y[perm])
     assert np.array_equal(run_bf16(torch_cuda, model, x), y)
+
+
+# ---- log-mel front-end (next-row 1; parity UNPINNED: librosa is absent, the oracle restates its defaults) ----
+@pytest.mark.parametrize("n", [163414, 16000, 1600, 513, 160, 159, 1])
+def test_logmel_matches_oracle(torch_cuda, n):
+    from oracle import logmel
+    from voice_activity_detection_amd.features import log_mel
+
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / 16000.0
+    y = (0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t * (1 + 0.1 * t))
+         + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    y[: n // 3] *= 0.001  # a near-silent stretch exercises the log(x + 1e-6) floor
+    ref = logmel.log_mel(y)
+    got = log_mel(y).cpu().numpy()
+    assert got.shape == ref.shape == (1 + n // 160, 80)
+    # fp32 DFT (exact-fp32 MFMA) vs numpy's float64 rFFT: ~1e-6 typically; up to a few 1e-4 only where the
+    # power sits at the 1e-6 log floor (near-silent frames: d log(x + 1e-6) = dx / 1e-6)
+    assert np.abs(got - ref).max() < 5e-4, np.abs(got - ref).max()
+    assert np.median(np.abs(got - ref)) < 2e-6
+
+
+def test_wav_to_probabilities_plumbing(torch_cuda, model, state1234, tmp_path):
+    """configs[0]-style plumbing on the GPU: WAV -> log-mel -> windows -> model -> boosted probabilities."""
+    import wave
+
+    from oracle import logmel, oracle
+    from voice_activity_detection_amd import VADFromScratchPredictor
+    from voice_activity_detection_amd.features import load_wav_mono16k, log_mel
+
+    rng = np.random.default_rng(5)
+    pcm = (rng.standard_normal(16000 * 3) * 3000).astype(np.int16)
+    with wave.open(str(tmp_path / "a.wav"), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+    y = load_wav_mono16k(tmp_path / "a.wav")
+    feat = log_mel(y)
+    assert feat.shape == (301, 80)
+    probs = VADFromScratchPredictor(model, "cuda").predict_probabilities(feat)
+    ref_probs, _ = oracle.predict_probabilities(state1234, logmel.log_mel(y))
+    assert probs.shape == (301, 7) and np.abs(probs - ref_probs).max() < 1e-4

@@ -117,3 +117,26 @@ def test_streaming_mode_definition(state1234):
     # interior frames: mean of the two covering windows
     p01 = 0.5 * (np.exp(logp[0, 400:800, 1]) + np.exp(logp[1, 0:400, 1]))
     assert np.abs(probs[400:800] - p01).max() < 1e-6
+
+
+def test_logmel_oracle_properties():
+    """oracle/logmel.py restates librosa 0.8.0 defaults (parity UNPINNED: librosa is absent).  What CAN be
+    checked without it: frame count, filterbank shape / Slaney normalisation, a pure tone lands in the
+    right mel band, the silence floor is log(1e-6)."""
+    from oracle import logmel
+
+    M = logmel.mel_filterbank()
+    assert M.shape == (80, 257) and M.dtype == np.float32 and (M >= 0).all()
+    assert M[:, 0].max() == 0 and M[:, 256].max() == 0           # fmin = 0, fmax = sr/2: edge bins carry no weight
+    centres = logmel.mel_to_hz(np.linspace(logmel.hz_to_mel(0.0), logmel.hz_to_mel(8000.0), 82))[1:-1]
+    assert abs(centres[0] - 200.0 / 3 * (logmel.hz_to_mel(8000.0) / 81)) < 1e-6  # linear region below 1 kHz
+    peak_bins = M.argmax(axis=1)
+    assert (np.diff(peak_bins) >= 0).all()
+    y = np.zeros(16000, np.float32)
+    f0 = logmel.log_mel(y)
+    assert f0.shape == (101, 80) and np.allclose(f0, np.log(1e-6), atol=1e-6)
+    t = np.arange(16000) / 16000.0
+    tone = logmel.log_mel(np.sin(2 * np.pi * 1000.0 * t).astype(np.float32))
+    band = int(np.argmin(np.abs(centres - 1000.0)))
+    assert abs(int(tone[50].argmax()) - band) <= 1
+    assert logmel.frame_count(163414) == 1022  # the reference's test clip (SURVEY.md section 8d)

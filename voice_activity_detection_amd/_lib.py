@@ -42,6 +42,9 @@ SYMBOLS = {
     "savad_stream_window_count": (c_int, [c_int, c_int, c_int]),
     "savad_gather_strided": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "savad_overlap_merge": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "savad_logmel_frames": (c_int, [c_int]),
+    "savad_logmel_workspace_bytes": (c_size_t, [c_int]),
+    "savad_logmel": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "savad_last_error": (c_char_p, []),
     "savad_version": (c_char_p, []),
 }

@@ -3,6 +3,7 @@
 //   input_qkv -> [attention(l) -> row(l)] x L      (row(L-1) ends in classifier + log-softmax)
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
+#include "savad_logmel.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -718,6 +719,115 @@ SAVAD_EXPORT int savad_overlap_merge(const float* logp, int W, int N, int T, int
     if (!logp || !probs || W <= 0 || T <= 0 || hop <= 0) return fail(SAVAD_E_INVALID, "bad argument");
     const int grid = (N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048;
     hipLaunchKernelGGL(overlap_merge_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logp, W, N, T, hop, probs);
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
+// ---- log-mel front-end (savad_logmel.h) ---------------------------------------------------------
+namespace {
+
+struct MelTables {
+    int device = -1;
+    float* d_dft = nullptr;
+    float* d_mel = nullptr;
+};
+MelTables g_mel;
+
+double hz_to_mel(double f) {  // Slaney scale (librosa htk=False)
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double mm) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    return mm >= min_log_mel ? min_log_hz * exp(logstep * (mm - min_log_mel)) : f_sp * mm;
+}
+
+int ensure_mel_tables(hipStream_t st) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (g_mel.device == dev) return SAVAD_OK;
+    using namespace mel;
+    const double PI = 3.14159265358979323846;
+    // window-folded DFT rows in fragment order [row block 16][G 50][lane 64][4]:
+    // row 0 = re(bin 0), row 1 = re(bin 256) (both imaginary parts are identically 0), row 2b / 2b+1 = re / im of bin b
+    std::vector<float> dft((size_t)DFT_FRAG_FLOATS);
+    for (int rb = 0; rb < 16; ++rb)
+        for (int G = 0; G < KG; ++G)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int n = lane & 31, hh = lane >> 5, row = 32 * rb + n, kk = 8 * G + 4 * hh + e;
+                    const double win = 0.5 - 0.5 * cos(2.0 * PI * kk / WIN);  // periodic Hann(400)
+                    const int kp = kk + LPAD;                                  // position inside the 512-sample frame
+                    int bin = row >> 1;
+                    bool im = row & 1;
+                    if (row == 1) {
+                        bin = 256;
+                        im = false;
+                    }
+                    const double ph = 2.0 * PI * (double)((long)bin * kp % N_FFT) / N_FFT;
+                    dft[(((size_t)rb * KG + G) * 64 + lane) * 4 + e] = (float)((float)win * (im ? -sin(ph) : cos(ph)));
+                }
+    // Slaney mel filterbank (librosa.filters.mel, norm="slaney", float32)
+    const int NB = N_FFT / 2 + 1;
+    std::vector<double> mel_f(N_MELS + 2);
+    const double m_lo = hz_to_mel(0.0), m_hi = hz_to_mel(8000.0);
+    for (int i = 0; i < N_MELS + 2; ++i) mel_f[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (N_MELS + 1));
+    std::vector<float> M((size_t)N_MELS * NB, 0.0f);
+    for (int i = 0; i < N_MELS; ++i) {
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int b = 0; b < NB; ++b) {
+            const double fr = 8000.0 * b / (NB - 1);
+            const double lower = (fr - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+            const double upper = (mel_f[i + 2] - fr) / (mel_f[i + 2] - mel_f[i + 1]);
+            const double wgt = fmax(0.0, fmin(lower, upper));
+            M[(size_t)i * NB + b] = (float)wgt * (float)enorm;
+        }
+    }
+    // mel fragments [pass 4][mel block 3][row block 4][g pair 2][lane 64][4]; element e -> g = 2gp + (e>>1), bin
+    // 64 pass + 16 rbl + 4 g + 2 h + (e&1).  Bins 0 and 256 have zero weight in every filter (fmin 0, fmax 8 kHz).
+    std::vector<float> melf((size_t)MEL_FRAG_FLOATS, 0.0f);
+    for (int pass = 0; pass < 4; ++pass)
+        for (int mb = 0; mb < 3; ++mb)
+            for (int rbl = 0; rbl < 4; ++rbl)
+                for (int gp = 0; gp < 2; ++gp)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int n = lane & 31, hh = lane >> 5, g = 2 * gp + (e >> 1);
+                            const int bin = 64 * pass + 16 * rbl + 4 * g + 2 * hh + (e & 1);
+                            const int ml_ = 32 * mb + n;
+                            float v = 0.0f;
+                            if (ml_ < N_MELS && bin >= 1 && bin < 256) v = M[(size_t)ml_ * NB + bin];
+                            melf[(((((size_t)pass * 3 + mb) * 4 + rbl) * 2 + gp) * 64 + lane) * 4 + e] = v;
+                        }
+    if (g_mel.d_dft) hipFree(g_mel.d_dft);
+    if (g_mel.d_mel) hipFree(g_mel.d_mel);
+    HIP_TRY(hipMalloc(&g_mel.d_dft, dft.size() * sizeof(float)));
+    HIP_TRY(hipMalloc(&g_mel.d_mel, melf.size() * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(g_mel.d_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(g_mel.d_mel, melf.data(), melf.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    g_mel.device = dev;
+    return SAVAD_OK;
+}
+
+}  // namespace
+
+SAVAD_EXPORT int savad_logmel_frames(int n_samples) { return n_samples < 0 ? fail(SAVAD_E_INVALID, "n_samples") : 1 + n_samples / mel::HOP; }
+SAVAD_EXPORT size_t savad_logmel_workspace_bytes(int n_samples) { return ((size_t)n_samples + mel::N_FFT + 64) * sizeof(float); }
+
+SAVAD_EXPORT int savad_logmel(const float* audio, int n_samples, float* workspace, float* features, void* stream) {
+    if (!audio || !workspace || !features || n_samples < 1) return fail(SAVAD_E_INVALID, "bad argument");
+    if (((uintptr_t)workspace | (uintptr_t)features) & 15) return fail(SAVAD_E_INVALID, "workspace and features must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure_mel_tables(st))) return rc;
+    const int n_frames = 1 + n_samples / mel::HOP;
+    const long total = (long)n_samples + mel::N_FFT;
+    const int g1 = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(mel::reflect_pad_kernel, dim3(g1), dim3(256), 0, st, audio, n_samples, workspace);
+    const int tiles = (n_frames + 31) / 32;
+    hipLaunchKernelGGL(mel::logmel_kernel, dim3((tiles + 3) / 4), dim3(256), 0, st, workspace, n_frames, g_mel.d_dft, g_mel.d_mel,
+                       features);
     HIP_TRY(hipGetLastError());
     return SAVAD_OK;
 }

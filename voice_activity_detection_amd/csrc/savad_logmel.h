@@ -1,0 +1,102 @@
+// savad_logmel.h -- log-mel front-end on the GPU ("next" row 1).
+// Restates, for the reference's only transform configuration (tests/configs/vad/train_config.yaml:
+// 18-26: n_fft 512, hop 10 ms, window 25 ms, 80 mels @16 kHz), what
+// vad/acoustics/transforms/log_mel_spectrogram.py:19-32 obtains from librosa 0.8.0:
+//   frames (center=True, reflect padding, periodic Hann(400) zero-padded to 512) -> |rFFT|^2 ->
+//   Slaney mel filterbank (norm="slaney", fmin 0, fmax 8 kHz) -> log(x + 1e-6) -> [N, 80], N = 1 + len/160.
+//
+// The STFT is a DFT-as-GEMM on the exact-fp32 MFMA, in the same transposed / row-layout form as the
+// model kernels: Out^T[dft row][frame] = sum_k Wdft[row][k] * y[160*frame + 56 + k], k = 0..399 (only
+// the 400 samples under the window), A operand = window-folded DFT rows (re/im of a bin interleaved
+// in adjacent rows, so that |X|^2 is lane-local), B operand = the frame's samples straight from the
+// reflect-padded signal (16-byte aligned because 160, 56 and 8G+4h are multiples of 4).  The power
+// values feed the mel GEMM from the accumulator registers; log and the [N,80] store finish the
+// wave.  One wave = 32 frames, 4 passes of 4 DFT row blocks (64 bins) each.
+#pragma once
+#include "savad_kernels.h"
+
+namespace savad {
+namespace mel {
+
+constexpr int N_FFT = 512, HOP = 160, WIN = 400, N_MELS = 80, LPAD = (N_FFT - WIN) / 2;  // LPAD = 56
+constexpr int KG = WIN / 8;                    // 50 k-groups of 8 samples
+constexpr int DFT_FRAG_FLOATS = 16 * KG * 256;  // [row block 16][G 50][lane 64][4]
+constexpr int MEL_FRAG_FLOATS = 4 * 3 * 4 * 2 * 256;  // [pass 4][mel block 3][row block 4][g pair 2][lane 64][4]
+
+// y_pad[j] = y[reflect(j - 256)], j in [0, n + 512)   (numpy.pad(mode="reflect"))
+__global__ void reflect_pad_kernel(const float* __restrict__ y, int n, float* __restrict__ ypad) {
+    const long total = (long)n + N_FFT;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (long)gridDim.x * blockDim.x) {
+        long i = j - N_FFT / 2;
+        if (i < 0) i = -i;
+        if (i >= n) i = 2L * (n - 1) - i;
+        if (i < 0) i = 0;  // signals shorter than the padding
+        ypad[j] = y[i];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict__ ypad, int n_frames,
+                                                        const float* __restrict__ dft_frag,
+                                                        const float* __restrict__ mel_frag, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + w;
+    if (tile * 32 >= n_frames) return;
+    int f = tile * 32 + m;
+    const bool valid = f < n_frames;
+    if (!valid) f = n_frames - 1;
+    const float* xp = ypad + (size_t)HOP * f + LPAD + 4 * h;
+    f32x16 macc[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) macc[mb] = zero16();
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int rbl = 0; rbl < 4; ++rbl) acc[rbl] = zero16();
+        const float* ap = dft_frag + (size_t)(pass * 4) * KG * 256 + lane * 4;
+#pragma unroll 2
+        for (int G = 0; G < KG; ++G) {
+            const f32x4 x4 = ld4(xp + 8 * G);
+#pragma unroll
+            for (int rbl = 0; rbl < 4; ++rbl) {
+                const f32x4 a4 = ld4(ap + (size_t)(rbl * KG + G) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[rbl] = SAVAD_MFMA(a4[e], x4[e], acc[rbl]);
+            }
+        }
+        // power spectrum, lane-local: rows 2b (re) and 2b+1 (im) are registers 2i and 2i+1
+        const float* mp = mel_frag + (size_t)(pass * 3) * 4 * 2 * 256 + lane * 4;
+#pragma unroll
+        for (int rbl = 0; rbl < 4; ++rbl) {
+            float pw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pw[i] = acc[rbl][2 * i] * acc[rbl][2 * i] + acc[rbl][2 * i + 1] * acc[rbl][2 * i + 1];
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const f32x4 m4 = ld4(mp + (size_t)((mb * 4 + rbl) * 2 + gp) * 256);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) macc[mb] = SAVAD_MFMA(m4[e], pw[4 * gp + e], macc[mb]);
+                }
+        }
+    }
+    if (!valid) return;
+    float* op = out + (size_t)f * N_MELS;
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int mel0 = 32 * mb + 8 * g + 4 * h;
+            if (mel0 < N_MELS) {
+                f32x4 t;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) t[s] = logf(macc[mb][4 * g + s] + 1e-6f);
+                st4(op + mel0, t);
+            }
+        }
+}
+
+}  // namespace mel
+}  // namespace savad
