@@ -140,6 +140,20 @@ int savad_logmel_frames(int n_samples);
 size_t savad_logmel_workspace_bytes(int n_samples);
 int savad_logmel(const float* audio, int n_samples, float* workspace, float* features, void* stream);
 
+/* Post-processing of the predict path (next-row 3 of the scope table); HOST pointers.
+ * savad_trim_voice_activity  : vad/postprocessing/trim.py:4-66 (valley fill, hill flatten, hang before/over; the
+ *                              hang pass only runs when hang_before > 0, as in the reference)
+ * savad_frames_to_samples    : vad/postprocessing/convert.py:6-24; returns int((n-1)*hop + window) samples
+ *                              (out == NULL: size query)
+ * savad_samples_to_segments  : vad/postprocessing/convert.py:27-61; returns the segment count, writes up to `cap`
+ *                              (start, end) SAMPLE indices (the reference's times are index / sample_rate)
+ * savad_optimal_split        : vad/postprocessing/split.py:26-109 */
+int savad_trim_voice_activity(const uint8_t* pred, int n, int min_vally, int min_hill, int hang_before, int hang_over,
+                              uint8_t* out);
+long savad_frames_to_samples(const double* frames, int n, int sample_rate, double hop_ms, double window_ms, double* out);
+int savad_samples_to_segments(const double* samples, long n, long* starts, long* ends, int cap);
+int savad_optimal_split(const double* pred, const double* probs, long n, long max_samples, double* out);
+
 const char* savad_last_error(void);
 const char* savad_version(void);
 

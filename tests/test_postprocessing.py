@@ -1,0 +1,100 @@
+"""Post-processing row: the native host functions in libsavad.so against goldens produced
+by the reference's own vad/postprocessing/*.py, vad/util/time_utils.py and VADFromScratchPredictor.predict
+(tests/golden/make_golden_post.py).  Integer / index work: bit-exact."""
+import json
+from datetime import timedelta
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+G = json.loads((Path(__file__).resolve().parent / "golden" / "golden_post.json").read_text())
+
+
+def test_trim_voice_activity_bit_exact():
+    from voice_activity_detection_amd.postprocessing import trim_voice_activity
+
+    for c in G["trim"]:
+        out = trim_voice_activity(np.array(c["pred"], dtype=bool), c["min_vally"], c["min_hill"], c["hang_before"], c["hang_over"])
+        assert out.dtype == bool and out.astype(int).tolist() == c["out"], c
+    # the reference's hang pass only runs when hang_before > 0 (it tests hang_before twice, trim.py:51)
+    p = np.array([0, 0, 1, 1, 0, 0, 0], dtype=bool)
+    assert trim_voice_activity(p, 0, 0, 0, 2).tolist() == p.tolist()
+
+
+def test_frames_to_samples_and_segments():
+    from voice_activity_detection_amd.postprocessing import convert_frames_to_samples, convert_samples_to_segments
+
+    for c in G["frames_to_samples"]:
+        out = convert_frames_to_samples(np.array(c["frames"]), c["sr"], c["hop"], c["win"])
+        assert len(out) == c["n_out"] and out.dtype == np.float64
+        assert out[:50].tolist() == c["head"] and out[-50:].tolist() == c["tail"] and out[::97].tolist() == c["every97"]
+        assert out.sum() == c["sum"]
+    for c in G["segments"]:
+        s = convert_frames_to_samples(np.array(c["frames"]), c["sr"], c["hop"], c["win"])
+        segs = convert_samples_to_segments(s, c["sr"])
+        got = [[int(a / timedelta(microseconds=1)), int(b / timedelta(microseconds=1))] for a, b in segs]
+        assert got == c["segments_us"]
+    assert convert_samples_to_segments(np.zeros(0)) == []
+
+
+def test_optimal_split_bit_exact():
+    from voice_activity_detection_amd.postprocessing import optimal_split_voice_activity
+
+    for c in G["split"]:
+        out = optimal_split_voice_activity(np.array(c["pred"], dtype=float), np.array(c["probs"]), c["max_s"], c["sr"])
+        assert out.astype(int).tolist() == c["out"]
+
+
+def test_timecode_format_and_json_roundtrip(tmp_path):
+    from voice_activity_detection_amd.data_models import Activity, VoiceActivity, format_timedelta_to_timecode
+
+    for us, text in G["timecode"]:
+        assert format_timedelta_to_timecode(timedelta(microseconds=us)) == text
+    va = VoiceActivity(timedelta(seconds=10.213), [Activity(timedelta(seconds=0.525), timedelta(seconds=1.225))], 100, [0.16, 0.5])
+    va.save(tmp_path / "va.json")
+    data = json.loads((tmp_path / "va.json").read_text())
+    assert list(data) == ["version", "duration", "activities", "probs_sample_rate", "probs"] and data["version"] == "v0.3"
+    assert data["duration"] == "00:00:10.213" and data["activities"] == [{"start": "00:00:00.525", "end": "00:00:01.225"}]
+    assert VoiceActivity.load(tmp_path / "va.json") == va
+    # the reference's own sample file parses (format example of JSON v0.3: tests/data/WhenTheWeatherIsFine/voice_activity.json)
+    ref_file = Path("/root/reference/tests/data/WhenTheWeatherIsFine/voice_activity.json")
+    if ref_file.exists():
+        assert len(VoiceActivity.load(ref_file).activities) == 5
+
+
+def _audio(case, seconds):
+    n = int(seconds * 16000)
+    arng = np.random.default_rng(700 + case)
+    t = np.arange(n) / 16000.0
+    env = (np.sin(2 * np.pi * 0.7 * t + case) > 0).astype(np.float32)
+    return (env * 0.3 * np.sin(2 * np.pi * (200 + 50 * case) * t) + 0.02 * arng.standard_normal(n)).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_predict_matches_reference_predict(case, state1234):
+    """VADFromScratchPredictor.predict (vad/predictor.py:77-157): chunking, threshold, trim, frame->sample,
+    optimal split, segments, merge, JSON v0.3 -- against the reference's own predict() on the same weights.
+    Features are fed from the CPU log-mel oracle (as the golden run did) so that everything AFTER the
+    feature matrix is pinned; a second run uses the GPU log-mel front-end end to end."""
+    import torch
+
+    from oracle import logmel
+    from voice_activity_detection_amd import SelfAttentiveVAD, VADFromScratchPredictor, VADPredictParameters
+
+    c = G["predict"][case]
+    m = SelfAttentiveVAD(80, 3, 128, 0.5)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state1234.items()})
+    pred = VADFromScratchPredictor(m.cuda().eval(), "cuda")
+    audio = _audio(case, c["seconds"])
+    params = VADPredictParameters(**c["params"])
+    va = pred.predict(audio, params, features_fn=logmel.log_mel)
+    got, ref = va.to_json(), c["json"]
+    assert got["duration"] == ref["duration"] and got["probs_sample_rate"] == ref["probs_sample_rate"]
+    assert got["activities"] == ref["activities"]
+    if ref["probs"] is not None:
+        assert len(got["probs"]) == len(ref["probs"]) and np.abs(np.array(got["probs"]) - np.array(ref["probs"])).max() < 1e-5
+    # end to end on the GPU front-end: same segmentation up to frames whose probability sits on the threshold
+    va2 = pred.predict(audio, params).to_json()
+    assert va2["duration"] == ref["duration"] and abs(len(va2["activities"]) - len(ref["activities"])) <= 1

@@ -11,7 +11,10 @@ def __getattr__(name):  # torch / libsavad are imported lazily (seeded.py is num
     if name == "SelfAttentiveVAD":
         from .model import SelfAttentiveVAD
         return SelfAttentiveVAD
-    if name in ("VADFromScratchPredictor", "ContextResolution", "window_offsets", "StreamingPredictor"):
+    if name in ("VADFromScratchPredictor", "ContextResolution", "window_offsets", "StreamingPredictor", "VADPredictParameters"):
         from . import predictor
         return getattr(predictor, name)
+    if name in ("VoiceActivity", "Activity"):
+        from . import data_models
+        return getattr(data_models, name)
     raise AttributeError(name)

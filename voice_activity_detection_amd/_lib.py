@@ -3,7 +3,7 @@ fallback in the product path -- if the HIP library is missing or stale, importin
 from __future__ import annotations
 
 import ctypes
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_long, c_size_t, c_void_p
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
@@ -45,6 +45,10 @@ SYMBOLS = {
     "savad_logmel_frames": (c_int, [c_int]),
     "savad_logmel_workspace_bytes": (c_size_t, [c_int]),
     "savad_logmel": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "savad_trim_voice_activity": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "savad_frames_to_samples": (c_long, [c_void_p, c_int, c_int, c_double, c_double, c_void_p]),
+    "savad_samples_to_segments": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int]),
+    "savad_optimal_split": (c_int, [c_void_p, c_void_p, c_long, c_long, c_void_p]),
     "savad_last_error": (c_char_p, []),
     "savad_version": (c_char_p, []),
 }

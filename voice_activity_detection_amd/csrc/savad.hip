@@ -4,6 +4,7 @@
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
 #include "savad_logmel.h"
+#include "savad_post.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -829,6 +830,28 @@ SAVAD_EXPORT int savad_logmel(const float* audio, int n_samples, float* workspac
     hipLaunchKernelGGL(mel::logmel_kernel, dim3((tiles + 3) / 4), dim3(256), 0, st, workspace, n_frames, g_mel.d_dft, g_mel.d_mel,
                        features);
     HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
+// ---- post-processing (host arrays; savad_post.h) ------------------------------------------------
+SAVAD_EXPORT int savad_trim_voice_activity(const uint8_t* pred, int n, int min_vally, int min_hill, int hang_before,
+                                           int hang_over, uint8_t* out) {
+    if (n < 0 || (n > 0 && (!pred || !out))) return fail(SAVAD_E_INVALID, "bad argument");
+    savad::post::trim_voice_activity(pred, n, min_vally, min_hill, hang_before, hang_over, out);
+    return SAVAD_OK;
+}
+SAVAD_EXPORT long savad_frames_to_samples(const double* frames, int n, int sample_rate, double hop_ms, double window_ms,
+                                          double* out) {
+    if (n < 0 || (n > 0 && !frames)) return fail(SAVAD_E_INVALID, "bad argument");
+    return savad::post::frames_to_samples(frames, n, sample_rate, hop_ms, window_ms, out);
+}
+SAVAD_EXPORT int savad_samples_to_segments(const double* samples, long n, long* starts, long* ends, int cap) {
+    if (n < 0 || (n > 0 && !samples) || cap < 0) return fail(SAVAD_E_INVALID, "bad argument");
+    return savad::post::samples_to_segments(samples, n, starts, ends, cap);
+}
+SAVAD_EXPORT int savad_optimal_split(const double* pred, const double* probs, long n, long max_samples, double* out) {
+    if (n < 0 || (n > 0 && (!pred || !probs || !out)) || max_samples <= 1) return fail(SAVAD_E_INVALID, "bad argument");
+    savad::post::optimal_split(pred, probs, n, max_samples, out);
     return SAVAD_OK;
 }
 

@@ -11,13 +11,19 @@ with numpy on the host.
 from __future__ import annotations
 
 import ctypes
+import math
 from dataclasses import dataclass
+from datetime import timedelta
+from typing import Optional
 
 import numpy as np
 import torch
 
 from . import _lib
+from .data_models import Activity, VoiceActivity, merge_voice_activities
 from .model import SelfAttentiveVAD
+from .postprocessing import (convert_frames_to_samples, convert_samples_to_segments, optimal_split_voice_activity,
+                             trim_voice_activity)
 
 
 def window_offsets(half: int, jump: int) -> np.ndarray:
@@ -36,8 +42,27 @@ class ContextResolution:
     context_window_jump_frames: int = 9
 
 
+@dataclass
+class VADPredictParameters:
+    """vad/predictor.py:27-38 (same field order as the reference's positional construction in vad/predict.py:32-43)."""
+    split_max_seconds: Optional[float] = None
+    threshold: float = 0.5
+    min_vally_ms: int = 0
+    min_hill_ms: int = 0
+    hang_before_ms: int = 0
+    hang_over_ms: int = 0
+    activity_max_seconds: Optional[int] = None
+    return_probs: bool = False
+    probs_sample_rate: Optional[int] = None
+    show_progress_bar: bool = False
+
+
 class VADFromScratchPredictor:
-    """Hot-path subset of the reference class of the same name (vad/predictor.py:41-75,159-262)."""
+    """The reference class of the same name (vad/predictor.py:41-262) for the self-attention model:
+    predict_probabilities on the GPU (log-mel, window gather, forward, boost), predict() with the
+    reference's chunking and post-processing (native host code)."""
+
+    hop_ms, window_ms = 10, 25  # the reference's only transform config (tests/configs/vad/train_config.yaml:21-22)
 
     def __init__(self, model: SelfAttentiveVAD, device: torch.device, context: ContextResolution = ContextResolution(),
                  chunk_size: int = 1000):
@@ -48,6 +73,74 @@ class VADFromScratchPredictor:
         # vad/predictor.py:57-59
         self.context_window_frames = 2 * (self.context_window_half_frames - 1) // self.context_window_jump_frames + 3
         self.chunk_size = int(chunk_size)  # reference: 1000 (vad/predictor.py:180); any value gives the same result
+
+    @classmethod
+    def from_checkpoint(cls, checkpoint_path, device):
+        """vad/predictor.py:264-280: a training checkpoint holds {"config": ..., "state_dict": ...}; the model size
+        and the window geometry come from the config, the weights load strictly."""
+        ckpt = torch.load(checkpoint_path, map_location="cpu")
+        cfg = ckpt["config"]
+
+        def get(c, *names):
+            for n in names:
+                c = c[n] if isinstance(c, dict) else getattr(c, n)
+            return c
+
+        if get(cfg, "model", "name") != "self-attention":
+            raise NotImplementedError("only the self-attention model is built for MI355X")
+        sa = get(cfg, "model", "self_attention")
+        n_mels = get(cfg, "feature_extractor", "transform", "n_mels")
+        model = SelfAttentiveVAD(n_mels, get(sa, "num_layers"), get(sa, "d_model"), get(sa, "dropout"))
+        model.load_state_dict(ckpt["state_dict"])
+        ctx = ContextResolution(get(cfg, "context_resolution", "context_window_half_frames"),
+                                get(cfg, "context_resolution", "context_window_jump_frames"))
+        return cls(model.to(device).eval(), device, ctx)
+
+    def predict_from_path(self, audio_path, parameters: VADPredictParameters) -> VoiceActivity:
+        """vad/predictor.py:71-75 (16 kHz PCM WAV only; the reference also resamples via librosa)."""
+        from .features import load_wav_mono16k
+
+        return self.predict(load_wav_mono16k(audio_path), parameters)
+
+    def predict(self, audio: np.ndarray, parameters: VADPredictParameters, features_fn=None) -> VoiceActivity:
+        """vad/predictor.py:77-157.  audio: float32 mono @16 kHz.  features_fn(chunk_audio) -> [N, F] overrides
+        the GPU log-mel front-end (used by the parity tests to feed the reference's feature matrix)."""
+        from .features import SAMPLE_RATE, log_mel
+
+        audio = np.asarray(audio, dtype=np.float32)
+        duration_s = len(audio) / SAMPLE_RATE
+        num_chunks = math.ceil(duration_s / parameters.split_max_seconds) if parameters.split_max_seconds is not None else 1
+        adjusted = duration_s / num_chunks
+        chunks = []
+        for ci in range(num_chunks):
+            start_sample = int(ci * adjusted * SAMPLE_RATE)
+            end_sample = int((ci + 1) * adjusted * SAMPLE_RATE)
+            chunk = audio[start_sample:end_sample]
+            feature = features_fn(chunk) if features_fn is not None else log_mel(chunk, self.device)
+            probs_dev, mean_dev = self.predict_probabilities_device(feature)
+            # float64 mean of the float32 [N, 7] matrix, like numpy's probs.mean(axis=1) on the host (:95)
+            boosted = probs_dev.cpu().numpy().mean(axis=1)
+            predictions = boosted > parameters.threshold
+            hop_ms, window_ms = self.hop_ms, self.window_ms
+            trimmed = trim_voice_activity(predictions, min_vally=round(parameters.min_vally_ms / hop_ms),
+                                          min_hill=round(parameters.min_hill_ms / hop_ms),
+                                          hang_before=round(parameters.hang_before_ms / hop_ms),
+                                          hang_over=round(parameters.hang_over_ms / hop_ms))
+            sample_predictions = convert_frames_to_samples(trimmed, sample_rate=16000, hop_ms=hop_ms, window_ms=window_ms)
+            if parameters.activity_max_seconds is not None and parameters.activity_max_seconds > 0:
+                sample_full_probs = convert_frames_to_samples(boosted, sample_rate=16000, hop_ms=hop_ms, window_ms=window_ms)
+                sample_predictions = optimal_split_voice_activity(sample_predictions, sample_full_probs,
+                                                                  max_length_seconds=parameters.activity_max_seconds,
+                                                                  sample_rate=16000)
+            activities = [Activity(start=a, end=b) for a, b in convert_samples_to_segments(sample_predictions, 16000)]
+            probs = None
+            if parameters.return_probs:
+                probs = convert_frames_to_samples(boosted, sample_rate=parameters.probs_sample_rate, hop_ms=hop_ms,
+                                                  window_ms=window_ms).tolist()
+            chunks.append(VoiceActivity(duration=timedelta(seconds=adjusted), activities=activities,
+                                        probs_sample_rate=parameters.probs_sample_rate if parameters.return_probs else None,
+                                        probs=probs))
+        return merge_voice_activities(chunks)
 
     def predict_probabilities(self, feature) -> np.ndarray:
         """feature [N, F] (numpy or tensor) -> positive-class probabilities [N, W] (float32 numpy),
