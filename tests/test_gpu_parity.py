@@ -418,3 +418,22 @@ def test_wav_to_probabilities_plumbing(torch_cuda, model, state1234, tmp_path):
     probs = VADFromScratchPredictor(model, "cuda").predict_probabilities(feat)
     ref_probs, _ = oracle.predict_probabilities(state1234, logmel.log_mel(y))
     assert probs.shape == (301, 7) and np.abs(probs - ref_probs).max() < 1e-4
+
+
+def test_config3_size_batch(torch_cuda, model, state1234):
+    """BASELINE configs[2]/[3] per-GPU size [256,800,80]: sampled sequences against the oracle (fp32 path and
+    bf16 path), plus the size-independent properties on the whole batch."""
+    from oracle import oracle
+
+    x = feats(2048, (256, 800, 80))
+    pick = [0, 37, 128, 255]
+    ref = oracle.forward(state1234, x[pick])
+    y = run(torch_cuda, model, x)
+    assert np.isfinite(y).all() and np.abs(np.logaddexp(y[..., 0], y[..., 1])).max() < 2e-6
+    assert np.abs(y[pick] - ref).max() < TIGHT
+    yb = run_bf16(torch_cuda, model, x)
+    assert np.isfinite(yb).all() and np.abs(yb[pick] - ref).max() < BF16_TOL
+    # the same sequence anywhere in the batch gives the same bits
+    x2 = x.copy()
+    x2[200] = x[3]
+    assert np.array_equal(run(torch_cuda, model, x2)[200], y[3])
