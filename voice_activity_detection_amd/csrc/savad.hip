@@ -11,6 +11,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -66,6 +68,7 @@ struct savad_model {
     char* d_frag = nullptr;  // bf16 weight fragments (savad_kernels_bf16.h), filled when precision == 1
     size_t frag_bytes = 0;
     bool frag_dirty = true;
+    bool lds_attrs_set = false;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the bf16 kernels
     size_t f_win = 0;
     struct LayerFrag {
         size_t wqkv, wo, w1, w2;
@@ -470,14 +473,13 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     const char* Fr = m->d_frag;
     const int grid_rows = bp.nblk_pad / 4;
     const int lds_in = 2 * bf::RING_BYTES + 3 * D * 4, lds_att = 8 * bf::BLK_BYTES, lds_row = 2 * bf::RING_BYTES + 9 * D * 4;
-    static bool attrs_done = false;
-    if (!attrs_done) {
+    if (!m->lds_attrs_set) {
         if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float>, lds_in))) return rc;
         if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16>, lds_in))) return rc;
         if ((rc = allow_lds(bf::attention_kernel_bf16, lds_att))) return rc;
         if ((rc = allow_lds(bf::row_kernel_bf16<false>, lds_row))) return rc;
         if ((rc = allow_lds(bf::row_kernel_bf16<true>, lds_row))) return rc;
-        attrs_done = true;
+        m->lds_attrs_set = true;
     }
     Prof prof(m, st);
     if (x_is_bf16)
@@ -728,11 +730,11 @@ SAVAD_EXPORT int savad_overlap_merge(const float* logp, int W, int N, int T, int
 namespace {
 
 struct MelTables {
-    int device = -1;
     float* d_dft = nullptr;
     float* d_mel = nullptr;
 };
-MelTables g_mel;
+std::mutex g_mel_mutex;
+std::map<int, MelTables> g_mel_by_device;  // built once per device, never freed (process lifetime, 0.9 MB)
 
 double hz_to_mel(double f) {  // Slaney scale (librosa htk=False)
     const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
@@ -743,10 +745,16 @@ double mel_to_hz(double mm) {
     return mm >= min_log_mel ? min_log_hz * exp(logstep * (mm - min_log_mel)) : f_sp * mm;
 }
 
-int ensure_mel_tables(hipStream_t st) {
+int ensure_mel_tables(hipStream_t st, MelTables* out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (g_mel.device == dev) return SAVAD_OK;
+    std::lock_guard<std::mutex> lock(g_mel_mutex);
+    auto it = g_mel_by_device.find(dev);
+    if (it != g_mel_by_device.end()) {
+        *out = it->second;
+        return SAVAD_OK;
+    }
+    MelTables g_mel;
     using namespace mel;
     const double PI = 3.14159265358979323846;
     // window-folded DFT rows in fragment order [row block 16][G 50][lane 64][4]:
@@ -800,14 +808,13 @@ int ensure_mel_tables(hipStream_t st) {
                             if (ml_ < N_MELS && bin >= 1 && bin < 256) v = M[(size_t)ml_ * NB + bin];
                             melf[(((((size_t)pass * 3 + mb) * 4 + rbl) * 2 + gp) * 64 + lane) * 4 + e] = v;
                         }
-    if (g_mel.d_dft) hipFree(g_mel.d_dft);
-    if (g_mel.d_mel) hipFree(g_mel.d_mel);
     HIP_TRY(hipMalloc(&g_mel.d_dft, dft.size() * sizeof(float)));
     HIP_TRY(hipMalloc(&g_mel.d_mel, melf.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(g_mel.d_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(g_mel.d_mel, melf.data(), melf.size() * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    g_mel.device = dev;
+    g_mel_by_device[dev] = g_mel;
+    *out = g_mel;
     return SAVAD_OK;
 }
 
@@ -821,7 +828,8 @@ SAVAD_EXPORT int savad_logmel(const float* audio, int n_samples, float* workspac
     if (((uintptr_t)workspace | (uintptr_t)features) & 15) return fail(SAVAD_E_INVALID, "workspace and features must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = ensure_mel_tables(st))) return rc;
+    MelTables g_mel;
+    if ((rc = ensure_mel_tables(st, &g_mel))) return rc;
     const int n_frames = 1 + n_samples / mel::HOP;
     const long total = (long)n_samples + mel::N_FFT;
     const int g1 = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

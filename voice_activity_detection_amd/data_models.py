@@ -53,6 +53,15 @@ class VoiceActivity:
         with Path(path).open("w") as file:  # same dump settings as voice_activity.py:111-114
             json.dump(self.to_json(), file, ensure_ascii=False, indent=4)
 
+    def to_labels(self, sample_rate: int):
+        """vad/data_models/voice_activity.py:239-246: 0/1 label per 1/sample_rate second."""
+        import numpy as np
+
+        labels = np.zeros(int(self.duration.total_seconds() * sample_rate), dtype=np.int64)
+        for a in self.activities:
+            labels[int(a.start.total_seconds() * sample_rate):int(a.end.total_seconds() * sample_rate)] = 1
+        return labels
+
     @classmethod
     def from_json(cls, data: dict) -> "VoiceActivity":
         if data.get("version") != "v0.3":
