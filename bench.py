@@ -105,8 +105,8 @@ def cpu_baseline(state, T: int, seconds: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
     ap.add_argument("--frames", type=int, default=800, help="T")
     ap.add_argument("--splits", type=int, default=0, help="attention key splits (0 = auto)")
