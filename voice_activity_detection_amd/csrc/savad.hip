@@ -581,8 +581,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     for (int l = 0; l < L; ++l) {
         if (T <= 32) {
             const int G = 32 / T, nblk = (B + G - 1) / G;
-            hipLaunchKernelGGL(attention_packed_kernel, dim3((nblk + 3) / 4), dim3(256), 0, st, q, k, v, op, ml, B, T,
-                               (int)ws.rows, c);
+            hipLaunchKernelGGL(attention_packed_kernel, dim3(nblk), dim3(64), 0, st, q, k, v, op, ml, B, T, (int)ws.rows, c);
         } else {
             const int QB = (T + 31) / 32, NG = (QB + 3) / 4;
             const int grid = 8 * ((B + 7) / 8) * NG * ws.S;

@@ -238,32 +238,45 @@ __device__ __forceinline__ void store_attention_partial(float* __restrict__ Opar
     if (h == 0) *reinterpret_cast<f32x2*>(ml + prow * 2) = f32x2{m_run, l_run};
 }
 
-// ---- T <= 32: one item = floor(32/T) whole sequences (block-diagonal mask), one key tile, K and V
-// straight from global memory (nothing to share or pipeline).
-__global__ __launch_bounds__(256, 2) void attention_packed_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                  const float* __restrict__ v, float* __restrict__ Opart,
-                                                                  float* __restrict__ ml, int B, int T, int rows, float c) {
+// ---- T <= 32: one item = floor(32/T) whole sequences (block-diagonal mask), one key tile.  ONE WAVE PER
+// WORKGROUP (the 7-frame windows of the reference pipeline give only B/4 blocks: 250 for a 10 s clip, so
+// the blocks are spread over as many CUs as possible) and every operand of the tile is requested up front
+// (Q, K: 16 x 16-byte loads each, V: 64 dword loads) so that the wave pays the L2 latency once, not per MFMA
+// group; with one wave per SIMD the 256-VGPR budget of the multi-wave kernels does not apply.
+__global__ __launch_bounds__(64) void attention_packed_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, float* __restrict__ Opart,
+                                                              float* __restrict__ ml, int B, int T, int rows, float c) {
     const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = 32 / T, rowsPB = G * T;
-    const int nblk = (B + G - 1) / G;
-    const int blk = blockIdx.x * 4 + w;
-    if (blk >= nblk) return;
+    const int blk = blockIdx.x;
     const size_t k0 = (size_t)blk * rowsPB;
     const size_t qrow = k0 + m;
     const bool qvalid = (m < rowsPB) && (qrow < (size_t)rows);
     const int tq = m / T;
     // q/k/v carry 32 rows of slack behind rows_pad, so the tile may over-read without clamping:
     // over-read K rows only produce masked scores, over-read V rows are zero (input_qkv_kernel).
-    f32x4 qg[16];
+    f32x4 qg[16], kg[16];
+    float vv[4][16];
+    const float* kp = k + (k0 + n) * D + 4 * h;
+    const float* vp = v + (k0 + 4 * h) * D + n;
 #pragma unroll
-    for (int G8 = 0; G8 < 16; ++G8) qg[G8] = ld4(q + qrow * D + 8 * G8 + 4 * h);
+    for (int G8 = 0; G8 < 16; ++G8) {
+        qg[G8] = ld4(q + qrow * D + 8 * G8 + 4 * h);
+        kg[G8] = ld4(kp + 8 * G8);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[nb][r] = vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb];
     f32x16 O[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
     float m_run = NEG_BIG, l_run = 0.0f;
     f32x16 sc = zero16();
-    gemm_k128(sc, k + (k0 + n) * D + 4 * h, qg);
+#pragma unroll
+    for (int G8 = 0; G8 < 16; ++G8)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc = SAVAD_MFMA(kg[G8][e], qg[G8][e], sc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
@@ -271,11 +284,10 @@ __global__ __launch_bounds__(256, 2) void attention_packed_kernel(const float* _
         sc[r] = ok ? sc[r] : NEG_BIG;
     }
     online_softmax(sc, m_run, l_run, O, c);
-    const float* vp = v + (k0 + 4 * h) * D + n;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
+        for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vv[nb][r], sc[r], O[nb]);
     }
     if (qvalid) store_attention_partial(Opart, ml, qrow, O, m_run, l_run, h);
 }
@@ -472,21 +484,82 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 // 4 waves; wave w owns output features [32w,32w+32) of out-proj / QKV (N split) and hidden units
 // [128w,128w+128) of the FFN (K split, partial sums reduce-scattered through LDS once).
 // ---------------------------------------------------------------------------------------------
+// Biases live in LDS for the whole kernel (loaded once, published by the first ring barrier): a
+// global load inside the block loop would be drained by the ring's vmcnt(0) at full L2 latency,
+// once per block.  For the same reason results are stored one block LATE (after the next block's
+// barrier), so that a store's write-ack is never waited for.
+__device__ __forceinline__ void stage_bias(float* dst, const float* __restrict__ src, int count) {
+    for (int i = threadIdx.x * 4; i < count; i += 256 * 4) st4(dst + i, ld4(src + i));
+}
+__device__ __forceinline__ f32x16 bias_block(const float* lds_bias /* &bias[n0] */, int h) {
+    f32x16 r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = ld4(lds_bias + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[4 * g + e] = b4[e];
+    }
+    return r;
+}
+
+// ---- N-split weight streaming: every wave owns its slices of the weight matrices (nothing to share), so
+// they go straight from L2 into the A operand -- but as whole 16-KB BLOCKS (16 x 16-byte loads = 64 VGPRs =
+// 64 MFMAs of work), double-buffered in registers: the next block is requested before the current block's
+// MFMAs start, so the L2 latency hides under 4096 MFMA cycles instead of being paid per group of 4.
+// The N-split kernels run at one workgroup per CU (small batches), hence the 512-VGPR budget.
+struct WBlock {
+    f32x4 v[16];
+};
+// 32 rows (lane & 31) x 128 k: chunk G at wp + 8G   (wp = W + (n0 + n) * ld + 4h)
+__device__ __forceinline__ void wload_k128(WBlock& wb, const float* __restrict__ wp) {
+#pragma unroll
+    for (int G = 0; G < 16; ++G) wb.v[G] = ld4(wp + 8 * G);
+}
+// 4 output blocks x 32 k (a column slice of W2 [128][512]): chunk (nb, g) at wp + 32*nb*ld + 8g
+__device__ __forceinline__ void wload_w2(WBlock& wb, const float* __restrict__ wp, int ld) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wb.v[4 * nb + g] = ld4(wp + (size_t)(32 * nb) * ld + 8 * g);
+}
+__device__ __forceinline__ void wmma_k128(f32x16& acc, const WBlock& wb, const f32x4 (&xg)[16]) {
+#pragma unroll
+    for (int G = 0; G < 16; ++G)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = SAVAD_MFMA(wb.v[G][e], xg[G][e], acc);
+}
+__device__ __forceinline__ void wmma_w2(f32x16 (&o)[4], const WBlock& wb, const f32x16& a) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[nb] = SAVAD_MFMA(wb.v[4 * nb + g][e], a[4 * g + e], o[nb]);
+}
+
 template <bool LAST>
-__global__ __launch_bounds__(256, 2) void row_kernel(
+__global__ __launch_bounds__(256, 1) void row_kernel(
     const float* __restrict__ Opart, const float* __restrict__ ml, int S, int rows, int rows_pad, float c,
     float* __restrict__ hbuf, const float* __restrict__ Wo, const float* __restrict__ bo,
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
     const float* __restrict__ b2, const float* __restrict__ Wn /* LAST ? Wc'[2][D] : Wqkv'[3D][D] */,
     const float* __restrict__ bn, float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
     float* __restrict__ out /* [rows][2] */) {
-    __shared__ __attribute__((aligned(16))) float lds[TILE * XLD + 12 * TILE * PLD];
+    __shared__ __attribute__((aligned(16))) float lds[TILE * XLD + 12 * TILE * PLD + 8 * D];
     float* xbuf = lds;
     float* pbuf = lds + TILE * XLD;  // [dest block 4][src slot 3][32 rows][PLD]
+    float* lb1 = pbuf + 12 * TILE * PLD;  // biases b1[512] b2[128] bqkv[384] in LDS (published by the first barrier):
+    float* lb2 = lb1 + DFF;                // a global load per use would cost an exposed L2 round trip each
+    float* lbn = lb2 + D;
     const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t row = (size_t)blockIdx.x * TILE + m;
 
+    WBlock wa, wb;
+    stage_bias(lb1, b1, DFF);
+    stage_bias(lb2, b2, D);
+    if (!LAST) stage_bias(lbn, bn, 3 * D);
+    wload_k128(wa, Wo + (size_t)(32 * w + n) * D + 4 * h);  // requested before the partials: consumed after phase 0
     // ---- phase 0: ctx = sum_s w_s O_s / sum_s w_s l_s   (rows are lane-local: all scalars per lane)
     // Pad rows (row >= rows) were never written by the attention stage: give them ctx = 0 so the
     // whole pipeline stays finite (their V rows are multiplied by probability 0 downstream).
@@ -520,7 +593,8 @@ __global__ __launch_bounds__(256, 2) void row_kernel(
     }
     // ---- phase 1: h1 = ctx Wo^T + bo + h   (wave's 32 features)
     f32x16 h1 = zero16();
-    gemm_k128(h1, Wo + (size_t)(32 * w + n) * D + 4 * h, xg);
+    wload_k128(wb, W1 + (size_t)(128 * w + n) * D + 4 * h);  // first FFN block
+    wmma_k128(h1, wa, xg);
     add_bias(h1, bo + 32 * w, h);
     add_block(h1, hbuf + row * D + 32 * w, h);
     store_block(xbuf + m * XLD + 32 * w, h1, h);
@@ -534,21 +608,16 @@ __global__ __launch_bounds__(256, 2) void row_kernel(
 #pragma unroll 1
     for (int ch = 0; ch < 4; ++ch) {
         const int hid0 = 128 * w + 32 * ch;
-        f32x16 a = zero16();
-        gemm_k128(a, W1 + (size_t)(hid0 + n) * D + 4 * h, xg);
-        add_bias(a, b1 + hid0, h);
+        wload_w2(wa, W2 + (size_t)n * DFF + hid0 + 4 * h, DFF);
+        f32x16 a = bias_block(lb1 + hid0, h);
+        wmma_k128(a, wb, xg);
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const float* wp = W2 + (size_t)(32 * nb + n) * DFF + hid0 + 4 * h;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 w4 = ld4(wp + 8 * g);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) o[nb] = SAVAD_MFMA(w4[s], a[4 * g + s], o[nb]);
-            }
-        }
+        if (ch + 1 < 4)
+            wload_k128(wb, W1 + (size_t)(hid0 + 32 + n) * D + 4 * h);
+        else if (!LAST)
+            wload_k128(wb, Wn + (size_t)(32 * w + n) * D + 4 * h);  // query block of the next layer
+        wmma_w2(o, wa, a);
     }
     // reduce-scatter the 4 K-split partials: wave w ends up with feature block w
     f32x16 own = o[0];
@@ -564,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void row_kernel(
     __syncthreads();
 #pragma unroll
     for (int slot = 0; slot < 3; ++slot) add_block(own, pbuf + ((w * 3 + slot) * TILE + m) * PLD, h);
-    add_bias(own, b2 + 32 * w, h);
+    own += bias_block(lb2 + 32 * w, h);
     own += h1;  // residual onto the un-normalised stream (transformer.py:235-237)
     if (!LAST) store_block(hbuf + row * D + 32 * w, own, h);
     // ---- phase 3
@@ -572,7 +641,17 @@ __global__ __launch_bounds__(256, 2) void row_kernel(
     __syncthreads();
     read_rows_layernorm(xbuf, m, h, xg);
     if (!LAST) {
-        qkv_block(xg, Wn, bn, q, k, v, row, w, n, h);
+        // Q (already in wb), K, V blocks of this wave's 32 features, each prefetched one block ahead
+        float* dst[3] = {q, k, v};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            WBlock& cur = (j & 1) ? wa : wb;
+            WBlock& nxt = (j & 1) ? wb : wa;
+            if (j + 1 < 3) wload_k128(nxt, Wn + (size_t)(D * (j + 1) + 32 * w + n) * D + 4 * h);
+            f32x16 acc = bias_block(lbn + D * j + 32 * w, h);
+            wmma_k128(acc, cur, xg);
+            store_block(dst[j] + row * D + 32 * w, acc, h);
+        }
     } else if (w == 0) {
         float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
@@ -659,24 +738,6 @@ __device__ __forceinline__ void layernorm_regs(const f32x16 (&x)[4], f32x4 (&xg)
     const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + LN_EPS);
 #pragma unroll
     for (int G = 0; G < 16; ++G) xg[G] *= rstd;
-}
-
-// Biases live in LDS for the whole kernel (loaded once, published by the first ring barrier): a
-// global load inside the block loop would be drained by the ring's vmcnt(0) at full L2 latency,
-// once per block.  For the same reason results are stored one block LATE (after the next block's
-// barrier), so that a store's write-ack is never waited for.
-__device__ __forceinline__ void stage_bias(float* dst, const float* __restrict__ src, int count) {
-    for (int i = threadIdx.x * 4; i < count; i += 256 * 4) st4(dst + i, ld4(src + i));
-}
-__device__ __forceinline__ f32x16 bias_block(const float* lds_bias /* &bias[n0] */, int h) {
-    f32x16 r;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 b4 = ld4(lds_bias + 8 * g + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[4 * g + e] = b4[e];
-    }
-    return r;
 }
 
 // QKV tail shared by both M-split kernels: 12 ring blocks (Wqkv rows 32j .. 32j+31); block 0 must
