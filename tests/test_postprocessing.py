@@ -98,3 +98,33 @@ def test_predict_matches_reference_predict(case, state1234):
     # end to end on the GPU front-end: same segmentation up to frames whose probability sits on the threshold
     va2 = pred.predict(audio, params).to_json()
     assert va2["duration"] == ref["duration"] and abs(len(va2["activities"]) - len(ref["activities"])) <= 1
+
+
+@pytest.mark.gpu
+def test_predict_cli_writes_json_v03(tmp_path, state1234):
+    """`python -m voice_activity_detection_amd predict AUDIO CKPT --output-path ...` (the reference's main.py predict):
+    a checkpoint in the reference's format ({"config", "state_dict"}: vad/training/model_checkpointer.py:97-110,
+    vad/predictor.py:266-278) and a 16 kHz WAV in, JSON v0.3 out; mirrors tests/test_predict.py:12-30 of the reference."""
+    import wave
+
+    import torch
+
+    from voice_activity_detection_amd.__main__ import main
+    from voice_activity_detection_amd.data_models import VoiceActivity
+
+    cfg = {"model": {"name": "self-attention", "self_attention": {"num_layers": 3, "d_model": 128, "dropout": 0.5}},
+           "context_resolution": {"context_window_half_frames": 19, "context_window_jump_frames": 9},
+           "feature_extractor": {"transform": {"name": "log-mel", "n_fft": 512, "hop_ms": 10, "window_ms": 25, "n_mels": 80}}}
+    torch.save({"config": cfg, "state_dict": {k: torch.from_numpy(v) for k, v in state1234.items()}}, tmp_path / "m.checkpoint")
+    pcm = (_audio(0, 6.0) * 20000).astype(np.int16)
+    with wave.open(str(tmp_path / "a.wav"), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+    out = tmp_path / "out" / "va.json"
+    assert main(["predict", str(tmp_path / "a.wav"), str(tmp_path / "m.checkpoint"), "--output-path", str(out),
+                 "--return-probs", "--probs-sample-rate", "100"]) == 0
+    data = json.loads(out.read_text())
+    assert data["version"] == "v0.3" and data["duration"] == "00:00:06.000" and data["probs_sample_rate"] == 100
+    assert len(data["probs"]) == 602 and len(VoiceActivity.load(out).activities) == len(data["activities"])
