@@ -311,10 +311,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_bf16(const char* __re
         dma_seg8(vtf + kb0 * BLK_BYTES, dst + 2 * BLK_BYTES, w, lane);
         dma_seg8(vtf + (kb0 + 1) * BLK_BYTES, dst + 3 * BLK_BYTES, w, lane);
     };
+#ifdef SAVAD_TIMING
+    long long tacc[4] = {0, 0, 0, 0}, tp = __builtin_readcyclecounter(), tn;
+#define SAVAD_TB(i) do { tn = __builtin_readcyclecounter(); tacc[i] += tn - tp; tp = tn; } while (0)
+#else
+#define SAVAD_TB(i) do {} while (0)
+#endif
     issue(0, 0);
     for (int stg = 0; stg < NST; ++stg) {
+        SAVAD_TB(3);
         ring_wait();
+        SAVAD_TB(0);
         if (stg + 1 < NST) issue(stg + 1, (stg + 1) & 1);
+        SAVAD_TB(1);
         if (!active) continue;
         const char* buf = smem + (stg & 1) * 4 * BLK_BYTES;
 #pragma unroll
@@ -327,7 +336,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_bf16(const char* __re
             for (int r = 0; r < 16; ++r) keyok[r] = (32 * jt + 8 * (r >> 2) + 4 * h + (r & 3)) < T;
             attn_tile(st, qp, buf + tt * BLK_BYTES, buf + (2 + tt) * BLK_BYTES, true, keyok, need_mask, c, lane);
         }
+        SAVAD_TB(2);
     }
+#ifdef SAVAD_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i2 = 0; i2 < 4; ++i2) g_savad_dbg[24 + i2] = tacc[i2];
+#endif
     if (active) store_ctx(ctxf, blk_q, st, 32 * qb + (lane & 31) < T, lane);
 }
 
