@@ -42,7 +42,8 @@ typedef struct savad_model* savad_handle;
 /* Mirrors SelfAttentiveVAD.__init__(feature_size, num_layers, d_model, dropout)
  * (vad/models/self_attention.py:7-21; d_ff = 4*d_model :10, n_heads = 1 :18).  dropout is an
  * inference no-op and is not part of the ABI.  Kernels implement d_model = 128 (the only value
- * the reference ships: tests/configs/vad/train_config.yaml:7-10), feature_size % 8 == 0. */
+ * the reference ships: tests/configs/vad/train_config.yaml:7-10) and any feature_size (rows are zero-padded to a
+ * multiple of 16 internally when needed). */
 typedef struct savad_config {
     int32_t feature_size;
     int32_t num_layers;
@@ -78,7 +79,7 @@ int savad_forward(savad_handle h, const float* x, int B, int T, float* out, void
 /* Arithmetic of the forward pass: 0 = fp32 operands on the exact-fp32 MFMA (default; log-probs within
  * 1e-4 of the reference), 1 = bf16 operands (weights, Q/K/V, probabilities, FFN activations) with fp32
  * accumulation, fp32 softmax / LayerNorm statistics and an fp32 residual stream (BASELINE.json
- * configs[2..3]; judged on AUC, not on 1e-4).  Needs feature_size % 16 == 0. */
+ * configs[2..3]; judged on AUC, not on 1e-4). */
 int savad_set_precision(savad_handle h, int precision);
 /* savad_forward with an explicit feature dtype: x_dtype 0 = fp32 [B,T,F], 1 = bf16 [B,T,F] (bf16
  * precision only).  Output is always fp32 log-probabilities. */

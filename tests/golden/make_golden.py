@@ -16,6 +16,7 @@ What is pinned:
       (vad/predictor.py:159-262 run unmodified behind 5 in-memory import shims)
   g6  intermediate taps on [2,40,80] (input layer, layer-0 attention context, encoder LN)
   g7  peaked-softmax weights (gain 4) on [2,96,80]
+  g8/g9 other model sizes: F=40 L=2; F=257 and F=13 (not multiples of 8) L=1
   pe  rows of the reference's sinusoidal table built for T=801 (vad/modeling/transformer.py:403-414)
 """
 from __future__ import annotations
@@ -116,6 +117,12 @@ def main():
     state8 = seeded_state_dict(88, feature_size=40, num_layers=2, d_model=128)
     m8 = ref_model(state8, 40, 2, 128)
     g["g8_F40L2"] = run(m8, seeded_features(800, (3, 50, 40)))
+
+    # feature sizes that are not a multiple of 8/16 (spectrogram: n_fft/2+1 = 257 bins; 13 MFCCs):
+    # vad/acoustics/transforms/transform_factory.py:30-59
+    for F in (257, 13):
+        st9 = seeded_state_dict(90 + F, feature_size=F, num_layers=1, d_model=128)
+        g[f"g9_F{F}"] = run(ref_model(st9, F, 1, 128), seeded_features(900 + F, (3, 37, F)))
 
     # positional-encoding table of the reference
     pe = m.input_layer[1].build_positional_encoding(801).numpy()[0]

@@ -118,6 +118,21 @@ def test_golden_other_model_size(torch_cuda, golden):
     assert np.abs(run(torch_cuda, m, feats(800, (3, 50, 40))) - golden["g8_F40L2"]).max() < TIGHT
 
 
+@pytest.mark.parametrize("F", [257, 13])
+def test_golden_odd_feature_sizes(torch_cuda, golden, F):
+    """Feature sizes that are not a multiple of the kernels' K granularity (257 spectrogram bins, 13 MFCCs) are
+    zero-padded inside the library; fp32 and bf16 paths."""
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    m = make_model(torch_cuda, seeded_state_dict(90 + F, feature_size=F, num_layers=1), F=F, L=1)
+    x = feats(900 + F, (3, 37, F))
+    assert np.abs(run(torch_cuda, m, x) - golden[f"g9_F{F}"]).max() < TIGHT
+    for row_mode in (1, 2):
+        assert np.abs(run(torch_cuda, m, x, row_mode=row_mode) - golden[f"g9_F{F}"]).max() < TIGHT
+    assert np.abs(run_bf16(torch_cuda, m, x) - golden[f"g9_F{F}"]).max() < BF16_TOL
+    assert np.abs(run_bf16(torch_cuda, m, x, bf16_input=True) - golden[f"g9_F{F}"]).max() < 3 * BF16_TOL
+
+
 @pytest.mark.parametrize("shape", [(5, 7, 80), (3, 45, 80), (2, 257, 80), (9, 33, 80), (37, 3, 80)])
 def test_against_oracle(torch_cuda, model, state1234, shape):
     from oracle import oracle
@@ -271,7 +286,7 @@ def test_c_abi_error_behaviour(torch_cuda):
     lib = _lib.load()
     h = ctypes.c_void_p()
     assert lib.savad_create(ctypes.byref(_lib.savad_config(80, 3, 64)), ctypes.byref(h)) == -2  # unsupported d_model
-    assert lib.savad_create(ctypes.byref(_lib.savad_config(81, 3, 128)), ctypes.byref(h)) == -2
+    assert lib.savad_create(ctypes.byref(_lib.savad_config(0, 3, 128)), ctypes.byref(h)) == -1
     _lib.check(lib.savad_create(ctypes.byref(_lib.savad_config(80, 3, 128)), ctypes.byref(h)))
     assert lib.savad_num_params(h) == 54
     w = torch.zeros(128 * 80, device="cuda")

@@ -69,6 +69,12 @@ def test_other_model_size(golden):
     assert np.abs(oracle.forward(st, seeded_features(800, (3, 50, 40))) - golden["g8_F40L2"]).max() < TOL
 
 
+@pytest.mark.parametrize("F", [257, 13])
+def test_odd_feature_sizes(golden, F):
+    st = seeded_state_dict(90 + F, feature_size=F, num_layers=1, d_model=128)
+    assert np.abs(oracle.forward(st, seeded_features(900 + F, (3, 37, F))) - golden[f"g9_F{F}"]).max() < TOL
+
+
 def test_window_offsets():
     # vad/predictor.py:57-59,186-212 with the only shipped config (half 19, jump 9)
     assert oracle.window_offsets(19, 9).tolist() == [-19, -10, -1, 0, 1, 10, 19]

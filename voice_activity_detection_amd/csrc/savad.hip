@@ -91,6 +91,8 @@ struct savad_model {
     };
     std::vector<LayerPacked> lp;
     size_t p_wc, p_bc;
+    int FP = 0;           // feature size rounded up to a multiple of 16 (kernels' K granularity)
+    size_t p_win_pad = 0;  // [D][FP] zero-padded copy of input_layer.0.weight (only when FP != feature_size)
 };
 
 namespace {
@@ -133,7 +135,7 @@ int choose_splits(const savad_model* m, int B, int T) {
 struct Workspace {
     size_t rows, rows_pad;
     int S;
-    size_t h, q, k, v, opart, ml, total;  // float offsets
+    size_t h, q, k, v, opart, ml, xpad, total;  // float offsets
 };
 
 Workspace plan(const savad_model* m, int B, int T) {
@@ -154,6 +156,8 @@ Workspace plan(const savad_model* m, int B, int T) {
     off += (size_t)w.S * w.rows_pad * D;
     w.ml = off;
     off += (size_t)w.S * w.rows_pad * 2;
+    w.xpad = off;
+    if (m->FP != m->cfg.feature_size) off += w.rows * (size_t)m->FP;  // zero-padded features
     w.total = off;
     return w;
 }
@@ -216,8 +220,18 @@ int prepare_weights(savad_model* m, hipStream_t st) {
     }
     int rc = fold(m, st, m->r_wc, m->r_bc, m->r_lnf_w, m->r_lnf_b, m->p_wc, m->p_bc, 2, D);
     if (rc) return rc;
+    if (m->FP != m->cfg.feature_size) {
+        hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(64), dim3(256), 0, st, m->d_raw + m->r_win, (size_t)D,
+                           m->cfg.feature_size, m->FP, m->d_packed + m->p_win_pad);
+        HIP_TRY(hipGetLastError());
+    }
     m->dirty = false;
     return SAVAD_OK;
+}
+
+// input weight as the kernels read it: [D][FP], the raw tensor itself when no padding is needed
+const float* win_fp32(const savad_model* m) {
+    return m->FP == m->cfg.feature_size ? m->d_raw + m->r_win : m->d_packed + m->p_win_pad;
 }
 
 int pack_frags(savad_model* m, hipStream_t st, const float* W, int N, int K, size_t off) {
@@ -233,7 +247,8 @@ int prepare_frags(savad_model* m, hipStream_t st) {
     if (!m->frag_dirty) return SAVAD_OK;
     const int F = m->cfg.feature_size, L = m->cfg.num_layers;
     int rc;
-    if ((rc = pack_frags(m, st, m->d_raw + m->r_win, D, F, m->f_win))) return rc;
+    (void)F;
+    if ((rc = pack_frags(m, st, win_fp32(m), D, m->FP, m->f_win))) return rc;
     for (int l = 0; l < L; ++l) {
         if ((rc = pack_frags(m, st, m->d_packed + m->lp[l].wqkv, 3 * D, D, m->lf[l].wqkv))) return rc;
         if ((rc = pack_frags(m, st, m->d_raw + m->lr[l].wo, D, D, m->lf[l].wo))) return rc;
@@ -247,9 +262,9 @@ int prepare_frags(savad_model* m, hipStream_t st) {
 // block space of the bf16 path (savad_kernels_bf16.h)
 struct BlockPlan {
     int nblk, nblk_pad;
-    size_t h, q, k, vt, ctx, total;  // byte offsets
+    size_t h, q, k, vt, ctx, xpad, total;  // byte offsets
 };
-BlockPlan plan_blocks(int B, int T) {
+BlockPlan plan_blocks(const savad_model* m, int B, int T) {
     BlockPlan p;
     if (T > 32)
         p.nblk = B * ((T + 31) / 32);
@@ -268,6 +283,8 @@ BlockPlan plan_blocks(int B, int T) {
     off += fb;
     p.ctx = off;
     off += fb;
+    p.xpad = off;
+    if (m->FP != m->cfg.feature_size) off += (size_t)B * T * m->FP * sizeof(float);
     p.total = off;
     return p;
 }
@@ -313,8 +330,8 @@ SAVAD_EXPORT int savad_create(const savad_config* cfg, savad_handle* out) {
     if (cfg->d_model != D)
         return fail(SAVAD_E_UNSUPPORTED, "d_model=%d: the gfx950 kernels implement d_model=128 (the reference's only config)",
                     cfg->d_model);
-    if (cfg->feature_size <= 0 || cfg->feature_size % 8)
-        return fail(SAVAD_E_UNSUPPORTED, "feature_size=%d must be a positive multiple of 8", cfg->feature_size);
+    if (cfg->feature_size <= 0 || cfg->feature_size > 4096)
+        return fail(SAVAD_E_INVALID, "feature_size=%d", cfg->feature_size);
     if (cfg->num_layers < 1 || cfg->num_layers > 64) return fail(SAVAD_E_INVALID, "num_layers=%d", cfg->num_layers);
     savad_model* m = new savad_model();
     m->cfg = *cfg;
@@ -361,9 +378,12 @@ SAVAD_EXPORT int savad_create(const savad_config* cfg, savad_handle* out) {
     m->packed_floats += 2 * D;
     m->p_bc = m->packed_floats;
     m->packed_floats += 4;
+    m->FP = (F + 15) / 16 * 16;
+    m->p_win_pad = m->packed_floats;
+    m->packed_floats += (size_t)D * m->FP;
     m->lf.resize(L);
     m->f_win = 0;
-    m->frag_bytes = (size_t)D * F * 2;
+    m->frag_bytes = (size_t)D * ((F + 15) / 16 * 16) * 2;
     for (int l = 0; l < L; ++l) {
         auto& fl = m->lf[l];
         fl.wqkv = m->frag_bytes;
@@ -438,7 +458,7 @@ SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* byt
     if (B == 0 || T == 0)
         *bytes = 0;
     else if (m->precision == 1)
-        *bytes = plan_blocks(B, T).total;
+        *bytes = plan_blocks(m, B, T).total;
     else
         *bytes = plan(m, B, T).total * sizeof(float);
     return SAVAD_OK;
@@ -446,8 +466,6 @@ SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* byt
 
 SAVAD_EXPORT int savad_set_precision(savad_handle m, int precision) {
     if (!m || precision < 0 || precision > 1) return fail(SAVAD_E_INVALID, "precision %d (0 = fp32, 1 = bf16)", precision);
-    if (precision == 1 && m->cfg.feature_size % 16)
-        return fail(SAVAD_E_UNSUPPORTED, "bf16 path needs feature_size %% 16 == 0 (got %d)", m->cfg.feature_size);
     m->precision = precision;
     return SAVAD_OK;
 }
@@ -457,7 +475,7 @@ namespace {
 // bf16-operand forward: input_qkv -> [attention -> row] x L on fragment-major buffers
 int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, float* out, void* workspace,
                  size_t workspace_bytes, hipStream_t st) {
-    const BlockPlan bp = plan_blocks(B, T);
+    const BlockPlan bp = plan_blocks(m, B, T);
     if (workspace_bytes < bp.total) return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, bp.total);
     int rc;
     if ((rc = prepare_weights(m, st))) return rc;
@@ -466,7 +484,20 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     char* W = (char*)workspace;
     float* hb = (float*)(W + bp.h);
     char *qf = W + bp.q, *kf = W + bp.k, *vtf = W + bp.vt, *ctxf = W + bp.ctx;
-    const int F = m->cfg.feature_size, L = m->cfg.num_layers;
+    const int L = m->cfg.num_layers;
+    int F = m->cfg.feature_size;
+    if (m->FP != F) {  // zero-pad the features to the kernels' K granularity (fp32 copy)
+        float* xp = (float*)(W + bp.xpad);
+        const size_t rows = (size_t)B * T;
+        const int grid = (int)((rows * m->FP + 255) / 256 < 4096 ? (rows * m->FP + 255) / 256 : 4096);
+        if (x_is_bf16)
+            hipLaunchKernelGGL(pad_rows_kernel<__bf16>, dim3(grid), dim3(256), 0, st, (const __bf16*)x, rows, F, m->FP, xp);
+        else
+            hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, rows, F, m->FP, xp);
+        x = xp;
+        x_is_bf16 = 0;
+        F = m->FP;
+    }
     const float c = (float)(1.4426950408889634 / sqrt((double)D));
     const float* R = m->d_raw;
     const float* P = m->d_packed;
@@ -557,7 +588,15 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
 
     float* W = (float*)workspace;
     float *hb = W + ws.h, *q = W + ws.q, *k = W + ws.k, *v = W + ws.v, *op = W + ws.opart, *ml = W + ws.ml;
-    const int F = m->cfg.feature_size, L = m->cfg.num_layers;
+    const int L = m->cfg.num_layers;
+    int F = m->cfg.feature_size;
+    if (m->FP != F) {  // zero-pad the features to the kernels' K granularity
+        float* xp = W + ws.xpad;
+        const int grid = (int)((ws.rows * m->FP + 255) / 256 < 4096 ? (ws.rows * m->FP + 255) / 256 : 4096);
+        hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(grid), dim3(256), 0, st, x, ws.rows, F, m->FP, xp);
+        x = xp;
+        F = m->FP;
+    }
     const int tiles = (int)(ws.rows_pad / TILE);
     const float c = (float)(1.4426950408889634 / sqrt((double)D));  // log2(e) / sqrt(d_head)
     const float* R = m->d_raw;
@@ -572,10 +611,10 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     // layer; B=32 (200 tiles) 134 vs 120.
     const bool msplit = m->row_mode == 2 || (m->row_mode == 0 && tiles_m >= 192);
     if (msplit)
-        hipLaunchKernelGGL(input_qkv_kernel_m, dim3(tiles_m), dim3(256), 0, st, x, (int)ws.rows, T, F, R + m->r_win,
+        hipLaunchKernelGGL(input_qkv_kernel_m, dim3(tiles_m), dim3(256), 0, st, x, (int)ws.rows, T, F, win_fp32(m),
                            R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
     else
-        hipLaunchKernelGGL(input_qkv_kernel, dim3(tiles), dim3(256), 0, st, x, (int)ws.rows, T, F, R + m->r_win,
+        hipLaunchKernelGGL(input_qkv_kernel, dim3(tiles), dim3(256), 0, st, x, (int)ws.rows, T, F, win_fp32(m),
                            R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
     prof.mark("input_qkv");
     for (int l = 0; l < L; ++l) {

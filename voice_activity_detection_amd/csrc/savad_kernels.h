@@ -1049,4 +1049,20 @@ __global__ void overlap_merge_kernel(const float* __restrict__ logp, int W, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Arbitrary feature sizes (the reference's transforms give 80 mels, 257 spectrogram bins, n_mfcc ...):
+// the MFMA kernels read K in groups of 8 (fp32) / 16 (bf16) with 16-byte loads, so rows are zero-padded
+// to FP = round_up(F, 16) when F is not a multiple of 16: the input weight once (prepare_weights), the
+// features once per forward.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pad_rows_kernel(const T* __restrict__ src, size_t rows, int F, int FP, float* __restrict__ dst) {
+    const size_t total = rows * (size_t)FP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % FP);
+        const size_t r = i / FP;
+        dst[i] = c < F ? (float)src[r * F + c] : 0.0f;
+    }
+}
+
 }  // namespace savad
