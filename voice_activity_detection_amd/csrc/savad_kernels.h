@@ -207,27 +207,33 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel(
 
 // One 32-key tile of the flash loop, K and V tiles supplied by functors (LDS or global).
 // sc in/out: raw scores S^T (already masked) -> probabilities p.
+// Deferred rescale: the running reference point m_run only moves when some row's maximum has grown by
+// more than 2^RESCALE_LOG2 since it was set (wave-uniform decision); until then probabilities are taken
+// relative to the stale reference, p = 2^((s - m_run) c) <= 2^RESCALE_LOG2.  O, l and p stay mutually
+// consistent, so O / l is unchanged (fp32 accumulators: no precision cost), and the 64-register rescale of O
+// plus one exp -- needed on ~3/4 of the tiles with a per-tile reference on random data -- all but disappears.
+constexpr float RESCALE_LOG2 = 16.0f;
 __device__ __forceinline__ void online_softmax(f32x16& sc, float& m_run, float& l_run, f32x16 (&O)[4], float c) {
     float mx = sc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
     mx = half_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);  // base-2 domain: p = 2^((s - m) c)
-    const float mc = m_new * c;
+    if (__any((mx - m_run) * c > RESCALE_LOG2)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);  // base-2 domain: p = 2^((s - m) c)
+        l_run *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) O[nb] *= alpha;
+    }
+    const float mc = m_run * c;
     float rs = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         sc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -mc));
         rs += sc[r];
     }
-    rs = half_sum(rs);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-    if (__any(alpha != 1.0f)) {  // wave-uniform: skip the 64-register rescale when no row's maximum moved
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) O[nb] *= alpha;
-    }
+    l_run += half_sum(rs);
 }
 
 __device__ __forceinline__ void store_attention_partial(float* __restrict__ Opart, float* __restrict__ ml, size_t prow,
