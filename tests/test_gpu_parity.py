@@ -392,6 +392,20 @@ def test_bf16_permutation_and_determinism(torch_cuda, model):
     assert np.array_equal(run_bf16(torch_cuda, model, x), y)
 
 
+@pytest.mark.parametrize("shape", [(3, 800, 80), (2, 801, 80), (5, 16, 80), (9, 96, 80), (1, 1, 80)])
+def test_bf16_wide_workgroups_identical(torch_cuda, model, shape):
+    """row_mode 2 = the 8-wave / 4-deep-ring variant of the bf16 kernels: the same arithmetic per data row
+    in a different workgroup shape, so the log-probs must be bit-identical to the default 4-wave variant."""
+    x = feats(sum(shape) + 1, shape)
+    y4 = run_bf16(torch_cuda, model, x)
+    model.row_mode = 2
+    try:
+        y8 = run_bf16(torch_cuda, model, x)
+    finally:
+        model.row_mode = 0
+    assert np.isfinite(y8).all() and np.array_equal(y4, y8)
+
+
 # ---- log-mel front-end (next-row 1; parity UNPINNED: librosa is absent, the oracle restates its defaults) ----
 @pytest.mark.parametrize("n", [163414, 16000, 1600, 513, 160, 159, 1])
 def test_logmel_matches_oracle(torch_cuda, n):

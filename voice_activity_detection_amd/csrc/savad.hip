@@ -3,6 +3,7 @@
 //   input_qkv -> [attention(l) -> row(l)] x L      (row(L-1) ends in classifier + log-softmax)
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
+#include <type_traits>
 #include "savad_logmel.h"
 #include "savad_post.h"
 
@@ -270,7 +271,7 @@ BlockPlan plan_blocks(const savad_model* m, int B, int T) {
         p.nblk = B * ((T + 31) / 32);
     else
         p.nblk = (B + (32 / T) - 1) / (32 / T);
-    p.nblk_pad = (p.nblk + 3) / 4 * 4;
+    p.nblk_pad = (p.nblk + 7) / 8 * 8;  // whole workgroups for both the 4- and the 8-wave kernels
     size_t off = 0;
     p.h = off;
     off += (size_t)p.nblk_pad * bf::HBLK_FLOATS * sizeof(float);
@@ -502,49 +503,69 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     const float* R = m->d_raw;
     const float* P = m->d_packed;
     const char* Fr = m->d_frag;
-    const int grid_rows = bp.nblk_pad / 4;
-    const int lds_in = 2 * bf::RING_BYTES + 3 * D * 4, lds_att = 8 * bf::BLK_BYTES, lds_row = 2 * bf::RING_BYTES + 9 * D * 4;
+    // 4-wave workgroups (two per CU, 2-slot ring) by default.  row_mode 2 selects the 8-wave variant with a
+    // 4-deep ring (half the DMA stream per data row, one workgroup per CU): measured SLOWER on MI355X at
+    // every size tried (B=256, T=800: 0.86 vs 0.75 ms), kept as a tuning knob and covered by the tests.
+    const bool wide = m->row_mode == 2;
     if (!m->lds_attrs_set) {
-        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float>, lds_in))) return rc;
-        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16>, lds_in))) return rc;
-        if ((rc = allow_lds(bf::attention_kernel_bf16, lds_att))) return rc;
-        if ((rc = allow_lds(bf::row_kernel_bf16<false>, lds_row))) return rc;
-        if ((rc = allow_lds(bf::row_kernel_bf16<true>, lds_row))) return rc;
+        constexpr int r4 = bf::Ring<4>::NRING * bf::RING_BYTES, r8 = bf::Ring<8>::NRING * bf::RING_BYTES;
+        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float, 4>, r4 + 3 * D * 4))) return rc;
+        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16, 4>, r4 + 3 * D * 4))) return rc;
+        if ((rc = allow_lds(bf::attention_kernel_bf16<4>, r4))) return rc;
+        if ((rc = allow_lds(bf::row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
+        if ((rc = allow_lds(bf::row_kernel_bf16<true, 4>, r4 + 9 * D * 4))) return rc;
+        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float, 8>, r8 + 3 * D * 4))) return rc;
+        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16, 8>, r8 + 3 * D * 4))) return rc;
+        if ((rc = allow_lds(bf::attention_kernel_bf16<8>, r8))) return rc;
+        if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
+        if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
         m->lds_attrs_set = true;
     }
     Prof prof(m, st);
-    if (x_is_bf16)
-        hipLaunchKernelGGL(bf::input_qkv_kernel_bf16<__bf16>, dim3(grid_rows), dim3(256), lds_in, st, (const __bf16*)x, B, T, F,
-                           bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf, kf, vtf);
+    auto run = [&](auto nw_tag) {
+        constexpr int NW = decltype(nw_tag)::value;
+        constexpr int ring = bf::Ring<NW>::NRING * bf::RING_BYTES;
+        const int grid_rows = bp.nblk_pad / NW;
+        const dim3 wg(64 * NW);
+        if (x_is_bf16)
+            hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<__bf16, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const __bf16*)x,
+                               B, T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb,
+                               qf, kf, vtf);
+        else
+            hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<float, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const float*)x, B,
+                               T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf,
+                               kf, vtf);
+        prof.mark("input_qkv_bf16");
+        for (int l = 0; l < L; ++l) {
+            if (T <= 32) {
+                hipLaunchKernelGGL(bf::attention_packed_kernel_bf16, dim3((bp.nblk + 3) / 4), dim3(256), 0, st, qf, kf, vtf, ctxf,
+                                   B, T, bp.nblk, c);
+            } else {
+                const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
+                hipLaunchKernelGGL((bf::attention_kernel_bf16<NW>), dim3(8 * ((B + 7) / 8) * NG), wg, ring, st, qf, kf, vtf, ctxf, B,
+                                   T, NG, c);
+            }
+            prof.mark("attention_bf16");
+            const auto& r = m->lr[l];
+            const auto& p = m->lp[l];
+            const auto& f = m->lf[l];
+            if (l + 1 < L) {
+                hipLaunchKernelGGL((bf::row_kernel_bf16<false, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, B, T, bp.nblk,
+                                   hb, Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, Fr + m->lf[l + 1].wqkv,
+                                   (const float*)nullptr, P + m->lp[l + 1].bqkv, qf, kf, vtf, out);
+                prof.mark("row_bf16");
+            } else {
+                hipLaunchKernelGGL((bf::row_kernel_bf16<true, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, B, T, bp.nblk,
+                                   hb, Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, (const char*)nullptr,
+                                   P + m->p_wc, P + m->p_bc, qf, kf, vtf, out);
+                prof.mark("row_last_bf16");
+            }
+        }
+    };
+    if (wide)
+        run(std::integral_constant<int, 8>{});
     else
-        hipLaunchKernelGGL(bf::input_qkv_kernel_bf16<float>, dim3(grid_rows), dim3(256), lds_in, st, (const float*)x, B, T, F,
-                           bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf, kf, vtf);
-    prof.mark("input_qkv_bf16");
-    for (int l = 0; l < L; ++l) {
-        if (T <= 32) {
-            hipLaunchKernelGGL(bf::attention_packed_kernel_bf16, dim3((bp.nblk + 3) / 4), dim3(256), 0, st, qf, kf, vtf, ctxf, B,
-                               T, bp.nblk, c);
-        } else {
-            const int QB = (T + 31) / 32, NG = (QB + 3) / 4;
-            hipLaunchKernelGGL(bf::attention_kernel_bf16, dim3(8 * ((B + 7) / 8) * NG), dim3(256), lds_att, st, qf, kf, vtf, ctxf,
-                               B, T, NG, c);
-        }
-        prof.mark("attention_bf16");
-        const auto& r = m->lr[l];
-        const auto& p = m->lp[l];
-        const auto& f = m->lf[l];
-        if (l + 1 < L) {
-            hipLaunchKernelGGL(bf::row_kernel_bf16<false>, dim3(grid_rows), dim3(256), lds_row, st, ctxf, B, T, bp.nblk, hb,
-                               Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, Fr + m->lf[l + 1].wqkv,
-                               (const float*)nullptr, P + m->lp[l + 1].bqkv, qf, kf, vtf, out);
-            prof.mark("row_bf16");
-        } else {
-            hipLaunchKernelGGL(bf::row_kernel_bf16<true>, dim3(grid_rows), dim3(256), lds_row, st, ctxf, B, T, bp.nblk, hb,
-                               Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, (const char*)nullptr,
-                               P + m->p_wc, P + m->p_bc, qf, kf, vtf, out);
-            prof.mark("row_last_bf16");
-        }
-    }
+        run(std::integral_constant<int, 4>{});
     prof.done();
     HIP_TRY(hipGetLastError());
     return SAVAD_OK;

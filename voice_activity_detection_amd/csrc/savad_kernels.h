@@ -212,6 +212,15 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel(
 // relative to the stale reference, p = 2^((s - m_run) c) <= 2^RESCALE_LOG2.  O, l and p stay mutually
 // consistent, so O / l is unchanged (fp32 accumulators: no precision cost), and the 64-register rescale of O
 // plus one exp -- needed on ~3/4 of the tiles with a per-tile reference on random data -- all but disappears.
+// Drain this wave's vector-memory operations (global loads AND the LDS-DMA issued through inline asm).
+// It must be the BUILTIN, not an asm string: the compiler's wait-count pass cannot see into asm, would
+// still believe earlier global loads (e.g. the Q rows read before the key loop) to be pending, and
+// would then guard their first use INSIDE the loop with vmcnt(N) waits -- which the hardware counts
+// against the DMA just issued for the next tile, exposing its full latency on every iteration.
+__device__ __forceinline__ void wait_vmem_all() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+    asm volatile("" ::: "memory");
+}
 constexpr float RESCALE_LOG2 = 16.0f;
 __device__ __forceinline__ void online_softmax(f32x16& sc, float& m_run, float& l_run, f32x16 (&O)[4], float c) {
     float mx = sc[0];
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         // vmcnt(0) for LDS-DMA issued in the previous loop iteration (checked in the ISA), so the
         // publish "my part of tile jt is in LDS" must be stated by hand.  It is free: the DMA was
         // issued a whole tile (8192+ MFMA cycles) ago.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vmem_all();
         __syncthreads();  // tile jt has landed for every wave; everyone is done reading the other buffer
         SAVAD_TACC(0);
         if (jt + 1 < jt1) {
@@ -697,7 +706,7 @@ constexpr int WBLK = 4096;  // floats per ring buffer (16 KB)
 // the previous block (so its buffer may be refilled right after this returns)
 __device__ __forceinline__ void ring_acquire() {
     if (SAVAD_ABLATE & 2) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // hipcc does not count LDS-DMA across the loop back-edge
+    wait_vmem_all();  // hipcc does not count LDS-DMA across the loop back-edge
     __syncthreads();
 }
 __device__ __forceinline__ void gemm_lds_a(f32x16& acc, const float* buf, int n, int h, const f32x4 (&xg)[16]) {
@@ -884,14 +893,12 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
     SAVAD_STAMP(2);
     layernorm_regs(h1, xg);
     SAVAD_STAMP(3);
-    // park the residual stream in hbuf (this wave owns its rows; L2-resident) instead of holding 64
-    // more registers across the FFN: keeps the kernel spill-free at 2 waves per SIMD
+    // ---- FFN: 16 hidden chunks of 32; W1 chunk in ring buffer 0, W2 column slice in buffer 1.  The
+    // accumulators START from the residual stream (h1 + b2: transformer.py:235-237), so h1 needs no
+    // registers of its own across the FFN and the kernel stays spill-free at 2 waves per SIMD.
+    f32x16(&o)[4] = h1;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) store_block(hbuf + row * D + 32 * nb, h1[nb], h);
-    // ---- FFN: 16 hidden chunks of 32; W1 chunk in ring buffer 0, W2 column slice in buffer 1
-    f32x16 o[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) o[nb] = zero16();
+    for (int nb = 0; nb < 4; ++nb) o[nb] += bias_block(lb2 + 32 * nb, h);
     SAVAD_STAMP(4);
 #pragma unroll 1
     for (int ch = 0; ch < 16; ++ch) {
@@ -909,11 +916,9 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
         gemm_lds_b(o, ring + WBLK, n, h, a);
     }
     SAVAD_STAMP(5);
+    if (!LAST) {
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        o[nb] += bias_block(lb2 + 32 * nb, h);
-        add_block(o[nb], hbuf + row * D + 32 * nb, h);  // residual onto the un-normalised stream (transformer.py:235-237)
-        if (!LAST) store_block(hbuf + row * D + 32 * nb, o[nb], h);
+        for (int nb = 0; nb < 4; ++nb) store_block(hbuf + row * D + 32 * nb, o[nb], h);
     }
     SAVAD_STAMP(6);
     layernorm_regs(o, xg);

@@ -90,44 +90,62 @@ __device__ __forceinline__ void store_hblock(float* hb, const f32x16 (&x)[4], in
         }
 }
 
-// ---- DMA of one 8 KiB contiguous segment (8 fragments) into LDS; each wave issues 2 of the 8
-//      1-KiB instructions (i = 2w, 2w+1).  Source and LDS image are both lane-linear.
-__device__ __forceinline__ void dma_seg8(const void* __restrict__ src /* wave-uniform */, void* lds_dst, int w, int lane) {
-    if (SAVAD_ABLATE & 1) return;
-    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_dst;
-    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr) + 2048u * (unsigned)w;
-    const char* base = reinterpret_cast<const char*>(src) + 2048 * w;
-    const unsigned off0 = (unsigned)lane * 16u, off1 = off0 + 1024u;
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "s_add_u32 m0, m0, 1024\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %3\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(off0), "v"(off1), "s"(base), "s"(m0v)
-        : "memory");
-}
-// 32 KiB contiguous ring block
-__device__ __forceinline__ void dma_ring32(const void* __restrict__ src, char* lds_dst, int w, int lane) {
+// ---- LDS ring of 32 KiB blocks fed by asynchronous global->LDS DMA, shared by the NW waves of a
+// workgroup.  A block = 4 segments of 8 KiB (8 fragments each), every segment contiguous in global
+// memory; source and LDS image are both lane-linear, so one DMA instruction moves 1 KiB (64 lanes x
+// 16 B) and wave w issues instructions i = w, w+NW, ... of the block's 32.
+//   NW = 4: 2 slots, the DMA runs one block ahead (two workgroups per CU hide its latency);
+//   NW = 8: 4 slots, the DMA runs THREE blocks ahead -- a bf16 block is only ~2000 cycles of work,
+//           less than the DMA latency under load -- and the 8 waves halve the stream per data row.
+// Completion is tracked with a COUNTED s_waitcnt: loads return in order, so "at most PER * k
+// outstanding" (k = DMA blocks issued after block t) implies block t has landed, whatever other
+// vector-memory operations are in flight (they can only make the wait longer, never shorter).
+template <int NW>
+struct Ring {
+    static constexpr int NRING = NW == 8 ? 4 : 2;
+    static constexpr int DEPTH = NRING - 1;
+    static constexpr int PER = 32 / NW;
+    char* base;
+    int w, lane;
+
+    __device__ __forceinline__ char* slot(int t) const { return base + (t & (NRING - 1)) * RING_BYTES; }
+
+    template <class SegSrc>
+    __device__ __forceinline__ void issue(int t, SegSrc seg_src) const {
+        if (SAVAD_ABLATE & 1) return;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)slot(t));
+        const unsigned off = (unsigned)lane * 16u;
 #pragma unroll
-    for (int sgm = 0; sgm < 4; ++sgm) dma_seg8(reinterpret_cast<const char*>(src) + sgm * BLK_BYTES, lds_dst + sgm * BLK_BYTES, w, lane);
-}
-// W2 chunk c: for every output block nb the 8 K-steps 8c..8c+7 (K = 512 -> 32 K-steps per n-block)
-__device__ __forceinline__ void dma_ring_w2(const void* __restrict__ w2frag, int c, char* lds_dst, int w, int lane) {
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-        dma_seg8(reinterpret_cast<const char*>(w2frag) + (size_t)(nb * 32 + 8 * c) * FRAG_BYTES, lds_dst + nb * BLK_BYTES, w, lane);
-}
-__device__ __forceinline__ void ring_wait() {
-    if (SAVAD_ABLATE & 2) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
+        for (int k = 0; k < PER; ++k) {
+            const int i = w + NW * k;  // instruction 0..31 of the block
+            const char* src = seg_src(i >> 3) + (i & 7) * FRAG_BYTES;
+            const unsigned m0v = lds0 + (unsigned)i * FRAG_BYTES;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %2\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(off), "s"(src), "s"(m0v)
+                : "memory");
+        }
+    }
+    // wait until block t has landed for every wave; `newer` = DMA blocks issued after block t (wave-uniform)
+    __device__ __forceinline__ void acquire(int newer) const {
+        if (SAVAD_ABLATE & 2) return;
+        // builtin, not asm: see wait_vmem_all().  gfx9 encoding: vmcnt in bits 3:0 (PER <= 8), others "no wait"
+        if (DEPTH >= 3 && newer >= 2)
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * PER));
+        else if (DEPTH >= 2 && newer == 1)
+            __builtin_amdgcn_s_waitcnt(0x0F70 | PER);
+        else
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        __syncthreads();
+    }
+};
 
 // acc[nbl] += W[ring n-block nbl] . x   (transposed form: lane = data row, registers = output features)
 __device__ __forceinline__ void gemm_ring(f32x16 (&acc)[4], const char* ringblk, const bf16x8 (&xp)[8], int lane) {
@@ -146,86 +164,92 @@ __device__ __forceinline__ void gemm_ring_swapped(f32x16 (&acc)[4], const char* 
             acc[nbl] = SAVAD_MFMA_BF16(xp[ks], ldfrag(ringblk + ((nbl * 8 + ks) * 64 + lane) * 16), acc[nbl]);
 }
 
-// LN -> fragments -> Q, K (transposed form) and V^T (swapped form); ring block 0 (Wq) must be in
-// flight into ring buffer `first_buf`.
-__device__ __forceinline__ void qkv_tail(const f32x4 (&xg)[16], const char* __restrict__ wqkv_frag, const float* lbq,
-                                         char* __restrict__ qf, char* __restrict__ kf, char* __restrict__ vtf, int blk,
-                                         char* ring, int first_buf, int w, int lane) {
+// One of the three QKV ring blocks (rb = 0 query, 1 key: transposed form; 2 value: swapped form -> V^T)
+__device__ __forceinline__ void qkv_block_bf16(int rb, const char* ringblk, const bf16x8 (&xp)[8], const float* lbq,
+                                               char* __restrict__ qf, char* __restrict__ kf, char* __restrict__ vtf,
+                                               int blk, int lane) {
     const int n = lane & 31, h = lane >> 5;
-    bf16x8 xp[8];
-    pack_row(xg, xp);
-    char* dst[2] = {qf, kf};
+    f32x16 acc[4];
+    if (rb < 2) {
 #pragma unroll
-    for (int rb = 0; rb < 3; ++rb) {
-        const int buf = (first_buf + rb) & 1;
-        ring_wait();
-        if (rb + 1 < 3) dma_ring32(wqkv_frag + (size_t)(rb + 1) * RING_BYTES, ring + (buf ^ 1) * RING_BYTES, w, lane);
-        f32x16 acc[4];
-        if (rb < 2) {
+        for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] = bias_block(lbq + D * rb + 32 * nbl, h);
+        gemm_ring(acc, ringblk, xp, lane);
+    } else {
 #pragma unroll
-            for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] = bias_block(lbq + D * rb + 32 * nbl, h);
-            gemm_ring(acc, ring + buf * RING_BYTES, xp, lane);
+        for (int nbl = 0; nbl < 4; ++nbl) {
+            const float bv = lbq[2 * D + 32 * nbl + n];  // lane = output feature
 #pragma unroll
-            for (int nbl = 0; nbl < 4; ++nbl)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    stfrag(dst[rb] + ((size_t)blk * 8 + 2 * nbl + j) * FRAG_BYTES + lane * 16, pack_half(acc[nbl], j));
-        } else {
-#pragma unroll
-            for (int nbl = 0; nbl < 4; ++nbl) {
-                const float bv = lbq[2 * D + 32 * nbl + n];  // lane = output feature
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nbl][r] = bv;
-            }
-            gemm_ring_swapped(acc, ring + buf * RING_BYTES, xp, lane);
-#pragma unroll
-            for (int nbl = 0; nbl < 4; ++nbl)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    stfrag(vtf + ((size_t)blk * 8 + 2 * nbl + j) * FRAG_BYTES + lane * 16, pack_half(acc[nbl], j));
+            for (int r = 0; r < 16; ++r) acc[nbl][r] = bv;
         }
+        gemm_ring_swapped(acc, ringblk, xp, lane);
     }
+    char* dst = rb == 0 ? qf : (rb == 1 ? kf : vtf);
+#pragma unroll
+    for (int nbl = 0; nbl < 4; ++nbl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) stfrag(dst + ((size_t)blk * 8 + 2 * nbl + j) * FRAG_BYTES + lane * 16, pack_half(acc[nbl], j));
+}
+
+// features f0..f0+3 and f0+8..f0+11 of one input row -> the 8 bf16 of an input K-step fragment
+__device__ __forceinline__ bf16x8 load_x_frag(const float* p, bool valid) {
+    f32x4 a = ld4(p), b = ld4(p + 8);
+    if (!valid) a = b = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = (__bf16)a[e];
+        r[4 + e] = (__bf16)b[e];
+    }
+    return r;
+}
+__device__ __forceinline__ bf16x8 load_x_frag(const __bf16* p, bool valid) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 a = *reinterpret_cast<const u32x2*>(p), b = *reinterpret_cast<const u32x2*>(p + 8);
+    if (!valid) a = b = u32x2{0u, 0u};
+    return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel 1 (bf16): input Linear + PE -> h (fp32) -> LN -> Q, K, V^T fragments.  4 waves = 4 blocks.
+// Kernel 1 (bf16): input Linear + PE -> h (fp32) -> LN -> Q, K, V^T fragments.  NW waves = NW blocks.
 // XT = float or __bf16 input features.
 // ---------------------------------------------------------------------------------------------
-template <typename XT>
-__global__ __launch_bounds__(256, 2) void input_qkv_kernel_bf16(
+template <typename XT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf16(
     const XT* __restrict__ x, int B, int T, int F, int nblk, const char* __restrict__ win_frag,
     const float* __restrict__ bin, const float* __restrict__ pe, const char* __restrict__ wqkv_frag,
     const float* __restrict__ bqkv, float* __restrict__ hbuf, char* __restrict__ qf, char* __restrict__ kf,
     char* __restrict__ vtf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ring = smem;
-    float* lbq = reinterpret_cast<float*>(smem + 2 * RING_BYTES);
+    using R = Ring<NW>;
+    float* lbq = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = blockIdx.x * 4 + w;
-    dma_ring32(wqkv_frag, ring, w, lane);
+    const int blk = blockIdx.x * NW + w;
+    const R ring{smem, w, lane};
+    constexpr int NBLK = 3;
+    auto issue = [&](int t) { ring.issue(t, [&](int sgm) { return wqkv_frag + (size_t)t * RING_BYTES + sgm * BLK_BYTES; }); };
+#pragma unroll
+    for (int t = 0; t < R::DEPTH && t < NBLK; ++t) issue(t);
     stage_bias(lbq, bqkv, 3 * D);
     size_t row;
-    int t;
-    const bool valid = (blk < nblk) && slot_row(B, T, blk, m, row, t);
+    int t_frame;
+    const bool valid = (blk < nblk) && slot_row(B, T, blk, m, row, t_frame);
     if (!valid) {
         row = 0;
-        t = 0;
+        t_frame = 0;
     }
     f32x16 h0[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         h0[nb] = zero16();
         add_bias(h0[nb], bin + 32 * nb, h);
-        add_block(h0[nb], pe + (size_t)t * D + 32 * nb, h);
+        add_block(h0[nb], pe + (size_t)t_frame * D + 32 * nb, h);
     }
     const int KS = F / 16;
     const XT* xr = x + row * (size_t)F;
     for (int ks = 0; ks < KS; ++ks) {
         const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
-        bf16x8 xf;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xf[e] = valid ? (__bf16)(float)xr[f0 + 8 * (e >> 2) + (e & 3)] : (__bf16)0.0f;
+        const bf16x8 xf = load_x_frag(xr + f0, valid);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
             h0[nb] = SAVAD_MFMA_BF16(ldfrag(win_frag + ((size_t)(nb * KS + ks) * 64 + lane) * 16), xf, h0[nb]);
@@ -233,21 +257,27 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel_bf16(
     store_hblock(hbuf + (size_t)blk * HBLK_FLOATS, h0, lane);
     f32x4 xg[16];
     layernorm_regs(h0, xg);
-    qkv_tail(xg, wqkv_frag, lbq, qf, kf, vtf, blk, ring, 0, w, lane);
+    bf16x8 xp[8];
+    pack_row(xg, xp);
+#pragma unroll
+    for (int t = 0; t < NBLK; ++t) {
+        ring.acquire(NBLK - 1 - t < R::DEPTH - 1 ? NBLK - 1 - t : R::DEPTH - 1);
+        if (t + R::DEPTH < NBLK) issue(t + R::DEPTH);
+        qkv_block_bf16(t, ring.slot(t), xp, lbq, qf, kf, vtf, blk, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel 2 (bf16): flash attention on fragments.  T > 32: workgroup = (sequence, group of <= 4
-// query blocks); K and V^T fragments of 2 key blocks (64 keys) per stage are DMA'd into LDS,
-// double-buffered.  Output: NORMALISED context as B-operand fragments.
+// Kernel 2 (bf16): flash attention on fragments.  T > 32: workgroup = (sequence, group of <= NW
+// query blocks); K and V^T fragments of 2 key blocks (64 keys, 32 KiB) per ring block.
+// Output: NORMALISED context as B-operand fragments.
 // ---------------------------------------------------------------------------------------------
 struct AttnState {
     f32x16 O[4];
     float m_run, l_run;
 };
 __device__ __forceinline__ void attn_tile(AttnState& st, const bf16x8 (&qp)[8], const char* kblk, const char* vtblk,
-                                          bool lds, const bool (&keyok)[16], bool need_mask, float c, int lane) {
-    (void)lds;
+                                          const bool (&keyok)[16], bool need_mask, float c, int lane) {
     f32x16 sc = zero16();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) sc = SAVAD_MFMA_BF16(ldfrag(kblk + (ks * 64 + lane) * 16), qp[ks], sc);
@@ -277,10 +307,12 @@ __device__ __forceinline__ void store_ctx(char* ctxf, int blk, AttnState& st, bo
     }
 }
 
-__global__ __launch_bounds__(256, 2) void attention_kernel_bf16(const char* __restrict__ qf, const char* __restrict__ kf,
-                                                                const char* __restrict__ vtf, char* __restrict__ ctxf,
-                                                                int B, int T, int NG, float c) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K 2 blocks | VT 2 blocks] = 64 KiB
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_kernel_bf16(const char* __restrict__ qf, const char* __restrict__ kf,
+                                                                    const char* __restrict__ vtf, char* __restrict__ ctxf,
+                                                                    int B, int T, int NG, float c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // ring of [K 2 blocks | V^T 2 blocks] stages
+    using R = Ring<NW>;
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int QB = (T + 31) / 32;
@@ -293,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_bf16(const char* __re
     const bool active = qb < qb1;
     const int blk_q = b * QB + (active ? qb : qb0);
     const int NST = (QB + 1) / 2;
+    const R ring{smem, w, lane};
 
     bf16x8 qp[8];
 #pragma unroll
@@ -303,29 +336,26 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_bf16(const char* __re
     st.m_run = NEG_BIG;
     st.l_run = 0.0f;
 
-    auto issue = [&](int stage, int buf) {
+    auto issue = [&](int stage) {
         const size_t kb0 = (size_t)b * QB + 2 * stage;
-        char* dst = smem + buf * 4 * BLK_BYTES;
-        dma_seg8(kf + kb0 * BLK_BYTES, dst, w, lane);
-        dma_seg8(kf + (kb0 + 1) * BLK_BYTES, dst + BLK_BYTES, w, lane);
-        dma_seg8(vtf + kb0 * BLK_BYTES, dst + 2 * BLK_BYTES, w, lane);
-        dma_seg8(vtf + (kb0 + 1) * BLK_BYTES, dst + 3 * BLK_BYTES, w, lane);
+        ring.issue(stage, [&](int sgm) { return (sgm < 2 ? kf : vtf) + (kb0 + (sgm & 1)) * BLK_BYTES; });
     };
+    for (int s0 = 0; s0 < R::DEPTH && s0 < NST; ++s0) issue(s0);
 #ifdef SAVAD_TIMING
     long long tacc[4] = {0, 0, 0, 0}, tp = __builtin_readcyclecounter(), tn;
 #define SAVAD_TB(i) do { tn = __builtin_readcyclecounter(); tacc[i] += tn - tp; tp = tn; } while (0)
 #else
 #define SAVAD_TB(i) do {} while (0)
 #endif
-    issue(0, 0);
     for (int stg = 0; stg < NST; ++stg) {
         SAVAD_TB(3);
-        ring_wait();
+        const int newer = NST - 1 - stg < R::DEPTH - 1 ? NST - 1 - stg : R::DEPTH - 1;
+        ring.acquire(newer);
         SAVAD_TB(0);
-        if (stg + 1 < NST) issue(stg + 1, (stg + 1) & 1);
+        if (stg + R::DEPTH < NST) issue(stg + R::DEPTH);
         SAVAD_TB(1);
         if (!active) continue;
-        const char* buf = smem + (stg & 1) * 4 * BLK_BYTES;
+        const char* buf = ring.slot(stg);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int jt = 2 * stg + tt;
@@ -334,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel_bf16(const char* __re
             const bool need_mask = 32 * jt + 32 > T;
 #pragma unroll
             for (int r = 0; r < 16; ++r) keyok[r] = (32 * jt + 8 * (r >> 2) + 4 * h + (r & 3)) < T;
-            attn_tile(st, qp, buf + tt * BLK_BYTES, buf + (2 + tt) * BLK_BYTES, true, keyok, need_mask, c, lane);
+            attn_tile(st, qp, buf + tt * BLK_BYTES, buf + (2 + tt) * BLK_BYTES, keyok, need_mask, c, lane);
         }
         SAVAD_TB(2);
     }
@@ -370,32 +400,51 @@ __global__ __launch_bounds__(256, 2) void attention_packed_kernel_bf16(const cha
         const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
         keyok[r] = (jk < G * T) && (jk / T == m / T) && (blk * G + jk / T < B);
     }
-    attn_tile(st, qp, kf + (size_t)blk * BLK_BYTES, vtf + (size_t)blk * BLK_BYTES, false, keyok, true, c, lane);
+    attn_tile(st, qp, kf + (size_t)blk * BLK_BYTES, vtf + (size_t)blk * BLK_BYTES, keyok, true, c, lane);
     store_ctx(ctxf, blk, st, (m < G * T) && (blk * G + m / T < B), lane);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Kernel 3 (bf16, per layer): out-projection + residual -> LN -> FFN (4 chunks of 128 hidden units,
 // ReLU output repacked in registers) + residual -> next layer's LN + Q/K/V^T, or the classifier.
-// Weight stream: 12 ring blocks of 32 KiB through a 2 x 32 KiB LDS ring, one block ahead.
+// Weight stream = ring blocks  0: Wo | 1+2c: W1 chunk c | 2+2c: W2 chunk c (c = 0..3) | 9,10,11: Wq, Wk, Wv.
 // ---------------------------------------------------------------------------------------------
-template <bool LAST>
-__global__ __launch_bounds__(256, 2) void row_kernel_bf16(
+template <bool LAST, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(
     const char* __restrict__ ctxf, int B, int T, int nblk, float* __restrict__ hbuf, const char* __restrict__ wo_frag,
     const float* __restrict__ bo, const char* __restrict__ w1_frag, const float* __restrict__ b1,
     const char* __restrict__ w2_frag, const float* __restrict__ b2, const char* __restrict__ wn_frag /* !LAST: Wqkv' */,
     const float* __restrict__ wc /* LAST: Wc' fp32 [2][D] */, const float* __restrict__ bn, char* __restrict__ qf,
     char* __restrict__ kf, char* __restrict__ vtf, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ring = smem;
-    float* lbo = reinterpret_cast<float*>(smem + 2 * RING_BYTES);
+    using R = Ring<NW>;
+    float* lbo = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
     float* lb1 = lbo + D;
     float* lb2 = lb1 + DFF;
     float* lbn = lb2 + D;
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = blockIdx.x * 4 + w;
-    dma_ring32(wo_frag, ring, w, lane);
+    const int blk = blockIdx.x * NW + w;
+    const R ring{smem, w, lane};
+    constexpr int NBLK = LAST ? 9 : 12;
+    auto issue = [&](int t) {
+        ring.issue(t, [&](int sgm) -> const char* {
+            if (t == 0) return wo_frag + sgm * BLK_BYTES;
+            if (t < 9) {
+                const int c = (t - 1) >> 1;
+                return ((t - 1) & 1) ? w2_frag + (size_t)(sgm * 32 + 8 * c) * FRAG_BYTES  // output block sgm, K-steps 8c..8c+7
+                                     : w1_frag + (size_t)c * RING_BYTES + sgm * BLK_BYTES;
+            }
+            return wn_frag + (size_t)(t - 9) * RING_BYTES + sgm * BLK_BYTES;
+        });
+    };
+    // acquire block t (wave-uniform t), then keep the DMA DEPTH blocks ahead
+    auto advance = [&](int t) {
+        ring.acquire(NBLK - 1 - t < R::DEPTH - 1 ? NBLK - 1 - t : R::DEPTH - 1);
+        if (t + R::DEPTH < NBLK) issue(t + R::DEPTH);
+    };
+#pragma unroll
+    for (int t = 0; t < R::DEPTH; ++t) issue(t);
     stage_bias(lbo, bo, D);
     stage_bias(lb1, b1, DFF);
     stage_bias(lb2, b2, D);
@@ -412,27 +461,24 @@ __global__ __launch_bounds__(256, 2) void row_kernel_bf16(
         if (blk >= nblk) xp[ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});  // pad blocks: attention never wrote them
     }
     // ---- h1 = h + bo + ctx Wo^T
-    ring_wait();
-    dma_ring32(w1_frag, ring + RING_BYTES, w, lane);
+    advance(0);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) h1[nb] += bias_block(lbo + 32 * nb, h);
-    gemm_ring(h1, ring, xp, lane);
-    store_hblock(hb, h1, lane);  // park the residual stream (fp32) while the FFN runs
+    gemm_ring(h1, ring.slot(0), xp, lane);
     f32x4 xg[16];
     layernorm_regs(h1, xg);
     pack_row(xg, xp);
-    // ---- FFN
-    f32x16 o[4];
+    // ---- FFN; its accumulators START from the residual stream (h1 + b2), so nothing is parked in HBM
+    f32x16(&o)[4] = h1;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) o[nb] = zero16();
+    for (int nb = 0; nb < 4; ++nb) o[nb] += bias_block(lb2 + 32 * nb, h);
 #pragma unroll 1
     for (int ch = 0; ch < 4; ++ch) {
-        ring_wait();  // W1 chunk in ring buffer 1
-        dma_ring_w2(w2_frag, ch, ring, w, lane);
+        advance(1 + 2 * ch);  // W1 chunk
         f32x16 a[4];
 #pragma unroll
         for (int nbl = 0; nbl < 4; ++nbl) a[nbl] = bias_block(lb1 + 128 * ch + 32 * nbl, h);
-        gemm_ring(a, ring + RING_BYTES, xp, lane);
+        gemm_ring(a, ring.slot(1 + 2 * ch), xp, lane);
         bf16x8 ap[8];
 #pragma unroll
         for (int nbl = 0; nbl < 4; ++nbl) {
@@ -441,20 +487,18 @@ __global__ __launch_bounds__(256, 2) void row_kernel_bf16(
             ap[2 * nbl] = pack_half(a[nbl], 0);
             ap[2 * nbl + 1] = pack_half(a[nbl], 1);
         }
-        ring_wait();  // W2 chunk in ring buffer 0
-        if (ch + 1 < 4)
-            dma_ring32(w1_frag + (size_t)(ch + 1) * RING_BYTES, ring + RING_BYTES, w, lane);
-        else if (!LAST)
-            dma_ring32(wn_frag, ring + RING_BYTES, w, lane);
-        gemm_ring(o, ring, ap, lane);
+        advance(2 + 2 * ch);  // W2 chunk
+        gemm_ring(o, ring.slot(2 + 2 * ch), ap, lane);
     }
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) o[nb] += bias_block(lb2 + 32 * nb, h);
-    load_hblock(o, hb, lane);  // residual onto the un-normalised stream
     if (!LAST) store_hblock(hb, o, lane);
     layernorm_regs(o, xg);
     if (!LAST) {
-        qkv_tail(xg, wn_frag, lbn, qf, kf, vtf, blk, ring, 1, w, lane);
+        pack_row(xg, xp);
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            advance(9 + rb);
+            qkv_block_bf16(rb, ring.slot(9 + rb), xp, lbn, qf, kf, vtf, blk, lane);
+        }
     } else {
         float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
@@ -471,8 +515,8 @@ __global__ __launch_bounds__(256, 2) void row_kernel_bf16(
         const float mx = fmaxf(z0, z1);
         const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
         size_t row;
-        int t;
-        const bool valid = (blk < nblk) && slot_row(B, T, blk, m, row, t);
+        int t_frame;
+        const bool valid = (blk < nblk) && slot_row(B, T, blk, m, row, t_frame);
         if (h == 0 && valid) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
     }
 }
