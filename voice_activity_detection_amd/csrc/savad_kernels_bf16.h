@@ -276,15 +276,14 @@ struct AttnState {
     f32x16 O[4];
     float m_run, l_run;
 };
+// `mask(sc)` sets the scores of keys that do not exist to NEG_BIG (lane (m,h), register r <-> key 8(r>>2)+4h+(r&3)).
+template <class Mask>
 __device__ __forceinline__ void attn_tile(AttnState& st, const bf16x8 (&qp)[8], const char* kblk, const char* vtblk,
-                                          const bool (&keyok)[16], bool need_mask, float c, int lane) {
+                                          Mask mask, float c, int lane) {
     f32x16 sc = zero16();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) sc = SAVAD_MFMA_BF16(ldfrag(kblk + (ks * 64 + lane) * 16), qp[ks], sc);
-    if (need_mask) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = keyok[r] ? sc[r] : NEG_BIG;
-    }
+    mask(sc);
     online_softmax(sc, st.m_run, st.l_run, st.O, c);
     const bf16x8 p0 = pack_half(sc, 0), p1 = pack_half(sc, 1);
 #pragma unroll
@@ -360,11 +359,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_kernel_bf1
         for (int tt = 0; tt < 2; ++tt) {
             const int jt = 2 * stg + tt;
             if (jt >= QB) break;
-            bool keyok[16];
-            const bool need_mask = 32 * jt + 32 > T;
+            // Only the last tile of a ragged sequence has missing keys.  The empty asm keeps this a REAL
+            // (wave-uniform) branch: if-converted, its 16 compares + selects + index arithmetic would run on
+            // every tile, and VALU instructions do not hide behind this wave's MFMAs (~1 ns each, measured).
+            auto mask = [&](f32x16& sc) {
+                if (32 * jt + 32 > T) {
+                    asm volatile("" ::: "memory");
+                    const int lim = T - 32 * jt - 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) keyok[r] = (32 * jt + 8 * (r >> 2) + 4 * h + (r & 3)) < T;
-            attn_tile(st, qp, buf + tt * BLK_BYTES, buf + (2 + tt) * BLK_BYTES, keyok, need_mask, c, lane);
+                    for (int r = 0; r < 16; ++r) sc[r] = (8 * (r >> 2) + (r & 3) < lim) ? sc[r] : NEG_BIG;
+                }
+            };
+            attn_tile(st, qp, buf + tt * BLK_BYTES, buf + (2 + tt) * BLK_BYTES, mask, c, lane);
         }
         SAVAD_TB(2);
     }
@@ -400,7 +406,11 @@ __global__ __launch_bounds__(256, 2) void attention_packed_kernel_bf16(const cha
         const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
         keyok[r] = (jk < G * T) && (jk / T == m / T) && (blk * G + jk / T < B);
     }
-    attn_tile(st, qp, kf + (size_t)blk * BLK_BYTES, vtf + (size_t)blk * BLK_BYTES, keyok, true, c, lane);
+    auto mask = [&](f32x16& sc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = keyok[r] ? sc[r] : NEG_BIG;
+    };
+    attn_tile(st, qp, kf + (size_t)blk * BLK_BYTES, vtf + (size_t)blk * BLK_BYTES, mask, c, lane);
     store_ctx(ctxf, blk, st, (m < G * T) && (blk * G + m / T < B), lane);
 }
 
