@@ -530,20 +530,20 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
         if (x_is_bf16)
             hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<__bf16, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const __bf16*)x,
                                B, T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb,
-                               qf, kf, vtf);
+                               qf, kf, vtf, c);
         else
             hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<float, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const float*)x, B,
                                T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf,
-                               kf, vtf);
+                               kf, vtf, c);
         prof.mark("input_qkv_bf16");
         for (int l = 0; l < L; ++l) {
             if (T <= 32) {
                 hipLaunchKernelGGL(bf::attention_packed_kernel_bf16, dim3((bp.nblk + 3) / 4), dim3(256), 0, st, qf, kf, vtf, ctxf,
-                                   B, T, bp.nblk, c);
+                                   B, T, bp.nblk);
             } else {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
                 hipLaunchKernelGGL((bf::attention_kernel_bf16<NW>), dim3(8 * ((B + 7) / 8) * NG), wg, ring, st, qf, kf, vtf, ctxf, B,
-                                   T, NG, c);
+                                   T, NG);
             }
             prof.mark("attention_bf16");
             const auto& r = m->lr[l];
@@ -552,12 +552,12 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
             if (l + 1 < L) {
                 hipLaunchKernelGGL((bf::row_kernel_bf16<false, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, B, T, bp.nblk,
                                    hb, Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, Fr + m->lf[l + 1].wqkv,
-                                   (const float*)nullptr, P + m->lp[l + 1].bqkv, qf, kf, vtf, out);
+                                   (const float*)nullptr, P + m->lp[l + 1].bqkv, qf, kf, vtf, out, c);
                 prof.mark("row_bf16");
             } else {
                 hipLaunchKernelGGL((bf::row_kernel_bf16<true, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, B, T, bp.nblk,
                                    hb, Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, (const char*)nullptr,
-                                   P + m->p_wc, P + m->p_bc, qf, kf, vtf, out);
+                                   P + m->p_wc, P + m->p_bc, qf, kf, vtf, out, c);
                 prof.mark("row_last_bf16");
             }
         }

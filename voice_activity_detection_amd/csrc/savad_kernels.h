@@ -335,7 +335,7 @@ __device__ long long g_savad_dbg[64];
     } while (0)
 #endif
 #ifndef SAVAD_ABLATE
-#define SAVAD_ABLATE 0  // experiment switch (scripts/ablate.sh): 1 = no DMA, 2 = no ring barrier, 4 = no softmax
+#define SAVAD_ABLATE 0  // experiment switch (scripts/ablate.sh): 1 = no DMA, 2 = no ring barrier, 4 = no softmax, 8 = no LDS operand reads (bf16 attention)
 #endif
 // ---- asynchronous global -> LDS DMA (global_load_lds_dwordx4): 64 lanes x 16 B from
 // base (SGPR pair, wave-uniform) + per-lane byte offset (VGPR) to LDS at M0 + lane*16.

@@ -165,9 +165,11 @@ __device__ __forceinline__ void gemm_ring_swapped(f32x16 (&acc)[4], const char* 
 }
 
 // One of the three QKV ring blocks (rb = 0 query, 1 key: transposed form; 2 value: swapped form -> V^T)
+// Q is stored PRE-SCALED by qscale = log2(e)/sqrt(D): the attention stage then gets its scores directly in
+// the base-2 exponent domain and spends no VALU instruction on scaling them.
 __device__ __forceinline__ void qkv_block_bf16(int rb, const char* ringblk, const bf16x8 (&xp)[8], const float* lbq,
                                                char* __restrict__ qf, char* __restrict__ kf, char* __restrict__ vtf,
-                                               int blk, int lane) {
+                                               int blk, int lane, float qscale) {
     const int n = lane & 31, h = lane >> 5;
     f32x16 acc[4];
     if (rb < 2) {
@@ -184,6 +186,10 @@ __device__ __forceinline__ void qkv_block_bf16(int rb, const char* ringblk, cons
         gemm_ring_swapped(acc, ringblk, xp, lane);
     }
     char* dst = rb == 0 ? qf : (rb == 1 ? kf : vtf);
+    if (rb == 0) {
+#pragma unroll
+        for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] *= qscale;
+    }
 #pragma unroll
     for (int nbl = 0; nbl < 4; ++nbl)
 #pragma unroll
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf1
     const XT* __restrict__ x, int B, int T, int F, int nblk, const char* __restrict__ win_frag,
     const float* __restrict__ bin, const float* __restrict__ pe, const char* __restrict__ wqkv_frag,
     const float* __restrict__ bqkv, float* __restrict__ hbuf, char* __restrict__ qf, char* __restrict__ kf,
-    char* __restrict__ vtf) {
+    char* __restrict__ vtf, float qscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using R = Ring<NW>;
     float* lbq = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf1
     for (int t = 0; t < NBLK; ++t) {
         ring.acquire(NBLK - 1 - t < R::DEPTH - 1 ? NBLK - 1 - t : R::DEPTH - 1);
         if (t + R::DEPTH < NBLK) issue(t + R::DEPTH);
-        qkv_block_bf16(t, ring.slot(t), xp, lbq, qf, kf, vtf, blk, lane);
+        qkv_block_bf16(t, ring.slot(t), xp, lbq, qf, kf, vtf, blk, lane, qscale);
     }
 }
 
@@ -272,24 +278,65 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf1
 // query blocks); K and V^T fragments of 2 key blocks (64 keys, 32 KiB) per ring block.
 // Output: NORMALISED context as B-operand fragments.
 // ---------------------------------------------------------------------------------------------
+// Online softmax state of one query block.  Scores arrive in the base-2 exponent domain (Q is pre-scaled)
+// and RELATIVE to a per-row reference: negm = -reference rides in as the C operand of the first S^T MFMA,
+// so the common tile spends no instruction on "s*c - m*c".  The reference only moves when a row maximum
+// drifts more than 2^RESCALE_LOG2 above it (or, on the first tile, away from the initial reference 0 in
+// either direction): p = 2^(s - ref) <= 2^16 and sums of 800+ of them are far inside fp32 range.
 struct AttnState {
     f32x16 O[4];
-    float m_run, l_run;
+    f32x16 negm;  // all 16 registers of a lane hold -reference of the lane's query row
+    float l_run;
 };
+__device__ __forceinline__ void attn_state_init(AttnState& st) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) st.O[nb] = zero16();
+    st.negm = zero16();
+    st.l_run = 0.0f;
+}
+__device__ __forceinline__ void online_softmax_shifted(f32x16& sc, AttnState& st, bool first /* wave-uniform */) {
+    float mx = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+    mx = half_max(mx);
+    const bool move = (mx > RESCALE_LOG2) || (first && mx < -RESCALE_LOG2);
+    if (__any(move)) {
+        const float d = move ? mx : 0.0f;  // new reference = old + d: the row maximum becomes 0
+        if (!first) {                      // on the first tile O and l are still zero (and 2^-d may overflow)
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            st.l_run *= alpha;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) st.O[nb] *= alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] -= d;
+            st.negm[r] -= d;
+        }
+    }
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+        rs += sc[r];
+    }
+    st.l_run += half_sum(rs);
+}
 // `mask(sc)` sets the scores of keys that do not exist to NEG_BIG (lane (m,h), register r <-> key 8(r>>2)+4h+(r&3)).
 template <class Mask>
 __device__ __forceinline__ void attn_tile(AttnState& st, const bf16x8 (&qp)[8], const char* kblk, const char* vtblk,
-                                          Mask mask, float c, int lane) {
-    f32x16 sc = zero16();
+                                          Mask mask, bool first, int lane) {
+    f32x16 sc = st.negm;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) sc = SAVAD_MFMA_BF16(ldfrag(kblk + (ks * 64 + lane) * 16), qp[ks], sc);
+    for (int ks = 0; ks < 8; ++ks)
+        sc = SAVAD_MFMA_BF16((SAVAD_ABLATE & 8) ? qp[7 - ks] : ldfrag(kblk + (ks * 64 + lane) * 16), qp[ks], sc);
     mask(sc);
-    online_softmax(sc, st.m_run, st.l_run, st.O, c);
+    if (!(SAVAD_ABLATE & 4)) online_softmax_shifted(sc, st, first);
     const bf16x8 p0 = pack_half(sc, 0), p1 = pack_half(sc, 1);
 #pragma unroll
     for (int nbd = 0; nbd < 4; ++nbd) {
-        st.O[nbd] = SAVAD_MFMA_BF16(ldfrag(vtblk + ((nbd * 2 + 0) * 64 + lane) * 16), p0, st.O[nbd]);
-        st.O[nbd] = SAVAD_MFMA_BF16(ldfrag(vtblk + ((nbd * 2 + 1) * 64 + lane) * 16), p1, st.O[nbd]);
+        st.O[nbd] = SAVAD_MFMA_BF16((SAVAD_ABLATE & 8) ? qp[nbd] : ldfrag(vtblk + ((nbd * 2 + 0) * 64 + lane) * 16), p0, st.O[nbd]);
+        st.O[nbd] = SAVAD_MFMA_BF16((SAVAD_ABLATE & 8) ? qp[4 + nbd] : ldfrag(vtblk + ((nbd * 2 + 1) * 64 + lane) * 16), p1, st.O[nbd]);
     }
 }
 // Invalid query slots (padding of the block space) get an exactly-zero context: a fully masked row
@@ -309,7 +356,7 @@ __device__ __forceinline__ void store_ctx(char* ctxf, int blk, AttnState& st, bo
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_kernel_bf16(const char* __restrict__ qf, const char* __restrict__ kf,
                                                                     const char* __restrict__ vtf, char* __restrict__ ctxf,
-                                                                    int B, int T, int NG, float c) {
+                                                                    int B, int T, int NG) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // ring of [K 2 blocks | V^T 2 blocks] stages
     using R = Ring<NW>;
     const int lane = threadIdx.x & 63, h = lane >> 5;
@@ -330,10 +377,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_kernel_bf1
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qp[ks] = ldfrag(qf + ((size_t)blk_q * 8 + ks) * FRAG_BYTES + lane * 16);
     AttnState st;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) st.O[nb] = zero16();
-    st.m_run = NEG_BIG;
-    st.l_run = 0.0f;
+    attn_state_init(st);
 
     auto issue = [&](int stage) {
         const size_t kb0 = (size_t)b * QB + 2 * stage;
@@ -370,7 +414,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_kernel_bf1
                     for (int r = 0; r < 16; ++r) sc[r] = (8 * (r >> 2) + (r & 3) < lim) ? sc[r] : NEG_BIG;
                 }
             };
-            attn_tile(st, qp, buf + tt * BLK_BYTES, buf + (2 + tt) * BLK_BYTES, mask, c, lane);
+            attn_tile(st, qp, buf + tt * BLK_BYTES, buf + (2 + tt) * BLK_BYTES, mask, jt == 0, lane);
         }
         SAVAD_TB(2);
     }
@@ -385,8 +429,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_kernel_bf1
 __global__ __launch_bounds__(256, 2) void attention_packed_kernel_bf16(const char* __restrict__ qf,
                                                                        const char* __restrict__ kf,
                                                                        const char* __restrict__ vtf,
-                                                                       char* __restrict__ ctxf, int B, int T, int nblk,
-                                                                       float c) {
+                                                                       char* __restrict__ ctxf, int B, int T, int nblk) {
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = blockIdx.x * 4 + w;
@@ -396,10 +439,7 @@ __global__ __launch_bounds__(256, 2) void attention_packed_kernel_bf16(const cha
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qp[ks] = ldfrag(qf + ((size_t)blk * 8 + ks) * FRAG_BYTES + lane * 16);
     AttnState st;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) st.O[nb] = zero16();
-    st.m_run = NEG_BIG;
-    st.l_run = 0.0f;
+    attn_state_init(st);
     bool keyok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -410,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void attention_packed_kernel_bf16(const cha
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = keyok[r] ? sc[r] : NEG_BIG;
     };
-    attn_tile(st, qp, kf + (size_t)blk * BLK_BYTES, vtf + (size_t)blk * BLK_BYTES, mask, c, lane);
+    attn_tile(st, qp, kf + (size_t)blk * BLK_BYTES, vtf + (size_t)blk * BLK_BYTES, mask, true, lane);
     store_ctx(ctxf, blk, st, (m < G * T) && (blk * G + m / T < B), lane);
 }
 
@@ -425,7 +465,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(
     const float* __restrict__ bo, const char* __restrict__ w1_frag, const float* __restrict__ b1,
     const char* __restrict__ w2_frag, const float* __restrict__ b2, const char* __restrict__ wn_frag /* !LAST: Wqkv' */,
     const float* __restrict__ wc /* LAST: Wc' fp32 [2][D] */, const float* __restrict__ bn, char* __restrict__ qf,
-    char* __restrict__ kf, char* __restrict__ vtf, float* __restrict__ out) {
+    char* __restrict__ kf, char* __restrict__ vtf, float* __restrict__ out, float qscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using R = Ring<NW>;
     float* lbo = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
@@ -507,7 +547,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             advance(9 + rb);
-            qkv_block_bf16(rb, ring.slot(9 + rb), xp, lbn, qf, kf, vtf, blk, lane);
+            qkv_block_bf16(rb, ring.slot(9 + rb), xp, lbn, qf, kf, vtf, blk, lane, qscale);
         }
     } else {
         float z0 = 0.0f, z1 = 0.0f;
