@@ -10,7 +10,9 @@ def mk():
     m.load_state_dict(sd)
     return m.cuda().eval()
 m0, m1, m2 = mk(), mk(), mk()
-B = 32
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+PREC = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+for mm in (m0, m1, m2): mm.precision = PREC
 x = torch.randn(B, 800, 80, device="cuda")
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def run_single():
@@ -30,5 +32,5 @@ def bench(f, n=50):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 print("single", round(bench(run_single), 4))
-for k in (16, 20, 22, 24, 26, 28, 30):
+for k in [B // 2, B // 2 + B // 8, B // 4]:
     print("split", k, B - k, round(bench(lambda: run_split(k)), 4))

@@ -274,7 +274,7 @@ BlockPlan plan_blocks(const savad_model* m, int B, int T) {
     p.nblk_pad = (p.nblk + 7) / 8 * 8;  // whole workgroups for both the 4- and the 8-wave kernels
     size_t off = 0;
     p.h = off;
-    off += (size_t)p.nblk_pad * bf::HBLK_FLOATS * sizeof(float);
+    off += (size_t)p.nblk_pad * bf::HBLK_FLOATS * sizeof(bf::hres_t);
     const size_t fb = (size_t)(p.nblk_pad + 1) * bf::BLK_BYTES;  // +1 block: a 2-block key stage may over-read
     p.q = off;
     off += fb;
@@ -483,7 +483,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     if ((rc = prepare_frags(m, st))) return rc;
     if ((rc = ensure_pe(m, T, st))) return rc;
     char* W = (char*)workspace;
-    float* hb = (float*)(W + bp.h);
+    bf::hres_t* hb = (bf::hres_t*)(W + bp.h);
     char *qf = W + bp.q, *kf = W + bp.k, *vtf = W + bp.vt, *ctxf = W + bp.ctx;
     const int L = m->cfg.num_layers;
     int F = m->cfg.feature_size;

@@ -68,25 +68,34 @@ __device__ __forceinline__ bool slot_row(int B, int T, int blk, int m, size_t& r
     return m < G * T && seq < B;
 }
 
-__device__ __forceinline__ void load_hblock(f32x16 (&x)[4], const float* hb, int lane) {
+// The residual stream h lives in HBM between kernels as FP16 (all arithmetic on it is fp32 in registers):
+// at B=256, T=800 the fp32 image was a third of the row stage's 430 MB of HBM traffic per launch, and that
+// stage runs at the HBM limit.  fp16 keeps 11 significant bits -- 8x finer than the bf16 rounding every
+// consumer of h applies right after its LayerNorm -- and saturates at +-65504 instead of overflowing.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hres_t;
+__device__ __forceinline__ void load_hblock(f32x16 (&x)[4], const hres_t* hb, int lane) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 t = ld4(hb + ((nb * 4 + g) * 64 + lane) * 4);
+        for (int gp = 0; gp < 2; ++gp) {
+            const f16x8 t = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(hb + ((nb * 2 + gp) * 64 + lane) * 8));
+            const f32x8 f = __builtin_convertvector(t, f32x8);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) x[nb][4 * g + s] += t[s];
+            for (int s = 0; s < 8; ++s) x[nb][8 * gp + s] += f[s];
         }
 }
-__device__ __forceinline__ void store_hblock(float* hb, const f32x16 (&x)[4], int lane) {
+__device__ __forceinline__ void store_hblock(hres_t* hb, const f32x16 (&x)[4], int lane) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 t;
+        for (int gp = 0; gp < 2; ++gp) {
+            f32x8 f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) t[s] = x[nb][4 * g + s];
-            st4(hb + ((nb * 4 + g) * 64 + lane) * 4, t);
+            for (int s = 0; s < 8; ++s) f[s] = fminf(fmaxf(x[nb][8 * gp + s], -65504.0f), 65504.0f);
+            const f16x8 t = __builtin_convertvector(f, f16x8);
+            *reinterpret_cast<u32x4*>(hb + ((nb * 2 + gp) * 64 + lane) * 8) = __builtin_bit_cast(u32x4, t);
         }
 }
 
@@ -223,7 +232,7 @@ template <typename XT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf16(
     const XT* __restrict__ x, int B, int T, int F, int nblk, const char* __restrict__ win_frag,
     const float* __restrict__ bin, const float* __restrict__ pe, const char* __restrict__ wqkv_frag,
-    const float* __restrict__ bqkv, float* __restrict__ hbuf, char* __restrict__ qf, char* __restrict__ kf,
+    const float* __restrict__ bqkv, hres_t* __restrict__ hbuf, char* __restrict__ qf, char* __restrict__ kf,
     char* __restrict__ vtf, float qscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using R = Ring<NW>;
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void attention_packed_kernel_bf16(const cha
 // ---------------------------------------------------------------------------------------------
 template <bool LAST, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(
-    const char* __restrict__ ctxf, int B, int T, int nblk, float* __restrict__ hbuf, const char* __restrict__ wo_frag,
+    const char* __restrict__ ctxf, int B, int T, int nblk, hres_t* __restrict__ hbuf, const char* __restrict__ wo_frag,
     const float* __restrict__ bo, const char* __restrict__ w1_frag, const float* __restrict__ b1,
     const char* __restrict__ w2_frag, const float* __restrict__ b2, const char* __restrict__ wn_frag /* !LAST: Wqkv' */,
     const float* __restrict__ wc /* LAST: Wc' fp32 [2][D] */, const float* __restrict__ bn, char* __restrict__ qf,
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(
     stage_bias(lb1, b1, DFF);
     stage_bias(lb2, b2, D);
     if (!LAST) stage_bias(lbn, bn, 3 * D);
-    float* hb = hbuf + (size_t)blk * HBLK_FLOATS;
+    hres_t* hb = hbuf + (size_t)blk * HBLK_FLOATS;
     f32x16 h1[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) h1[nb] = zero16();
