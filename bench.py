@@ -92,13 +92,13 @@ def cpu_baseline(state, T: int, seconds: float):
     oracle.forward(state, xn, threads=cores)
     c_fps = Bc * T / (time.perf_counter() - t0)
     best = max(torch_fps, c_fps)
+    used = torch_threads if torch_fps >= c_fps else cores  # threads of the run that produced `value`
     return {
-        "value": round(best, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+        "value": round(best, 1), "unit": "frames/s", "cores": used, "host_cores": cores, "kind": "port",
         "sample": f"stock-PyTorch CPU port (the reference's ATen ops) on [{Bt},{T},{F_MEL}] fp32, {it_total} forwards, "
                   f"best of thread counts {cands}: {torch_fps:.0f} frames/s at {torch_threads} threads (torch "
                   f"{torch.__version__}); C oracle on [{Bc},{T},{F_MEL}], 1 pass, OpenMP {cores} threads: "
                   f"{c_fps:.0f} frames/s; faster one reported",
-        "threads_used": torch_threads if torch_fps >= c_fps else cores,
     }
 
 
