@@ -29,6 +29,7 @@ sys.path.insert(0, str(REPO))
 F_MEL, D_MODEL, N_LAYERS = 80, 128, 3
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: bf16 MFMA, dense (AMD's 5 PF figure includes 2:1 sparsity)
+PEAK_HBM_TBPS = 8.0  # same guide: HBM3E
 
 
 def flops_per_frame(T: int) -> float:
@@ -37,19 +38,27 @@ def flops_per_frame(T: int) -> float:
     return 2 * F * D + L * (8 * D * D + 4 * T * D + 4 * D * 4 * D) + 4 * D
 
 
-def measured_traffic(kernel: str, B: int, T: int):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json, produced by scripts/profile_gpu.sh on the default workload; FETCH_SIZE
-    doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be collected from
-    inside this process, so the number is only reported when the workload matches the profiled one."""
-    if (B, T) != (32, 800):
+def measured_traffic(precision: str, B: int, T: int):
+    """HBM-side bytes per launch of the attention kernel from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, produced by scripts/profile_gpu.sh; FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md).  PMC counters cannot be collected from inside this process, so
+    the number is only reported when the workload matches a profiled one: fp32 [32,800] (the default
+    bench line) or bf16 [256,800]."""
+    if (precision, B, T) == ("fp32", 32, 800):
+        files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if "bf16" not in f.name]
+        prefix = "attention_kernel"
+    elif (precision, B, T) == ("bf16", 256, 800):
+        files = sorted((REPO / "profiles").glob("*bf16_b256_traffic.json"))
+        prefix = "attention_kernel_bf16"
+    else:
         return None
-    files = sorted((REPO / "profiles").glob("*_traffic.json"))
     if not files:
         return None
     data = json.loads(files[-1].read_text())
-    entry = data.get(kernel)
-    return round(entry["hbm_bytes_per_launch"]) if entry else None
+    for key, entry in data.items():
+        if key == prefix or key.startswith(prefix + "<"):
+            return round(entry["hbm_bytes_per_launch"])
+    return None
 
 
 def cpu_baseline(state, T: int, seconds: float):
@@ -209,12 +218,17 @@ def main():
             att_ms = sum(att) / len(att)
             att_flops = 4.0 * T * T * D_MODEL * B  # QK^T + PV of one layer's launch
             ach = att_flops / (att_ms * 1e-3) / 1e12
+            att_bytes = 4 * T * D_MODEL * (2 if args.precision == "bf16" else 4) * B  # Q, K, V read + context written
             roof = {
                 "bound": "mfma", "kernel": "attention_kernel (1 launch per layer)",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4),
-                "traffic": measured_traffic("attention_kernel", B, T) if args.precision == "fp32" else None, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
-                "algorithmic_bytes": 4 * T * D_MODEL * 4 * B,
+                "traffic": measured_traffic(args.precision, B, T), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                "algorithmic_bytes": att_bytes,
+                # the same launch against the HBM roofline (SURVEY section 8d "attention HBM roofline"): it is the
+                # non-binding one -- the fp32 MFMA rate caps it at 9.8 % of 8 TB/s, bf16 at ~100 %
+                "hbm_achieved_TBps": round(att_bytes / (att_ms * 1e-3) / 1e12, 3), "hbm_peak_TBps": PEAK_HBM_TBPS,
+                "hbm_frac": round(att_bytes / (att_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
                 "ms_per_launch": round(att_ms, 4),
                 "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / peak, 4),
                 "kernels_ms": {f"{i}:{n}": round(t, 4) for i, (n, t) in enumerate(ktimes)},

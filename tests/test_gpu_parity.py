@@ -199,6 +199,36 @@ def test_empty_and_call_forms(torch_cuda, model):
         model(features=torch.zeros(2, 9, 81, device="cuda"))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_forward_is_graph_capturable(torch_cuda, model, precision):
+    """savad_forward neither allocates nor synchronises (include/savad.h), so after one warm-up call (weights
+    packed, PE table grown) the 7 launches can be captured in a hipGraph and replayed on new data."""
+    torch = torch_cuda
+    model.precision = precision
+    try:
+        x0, x1 = (torch.from_numpy(feats(s, (6, 96, 80))).cuda() for s in (41, 42))
+        static_x = x0.clone()
+        with torch.no_grad():
+            eager0, eager1 = model(features=x0).clone(), model(features=x1).clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(features=static_x)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_y = model(features=static_x)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(static_y, eager0)
+            static_x.copy_(x1)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(static_y, eager1)
+    finally:
+        model.precision = "fp32"
+
+
 def test_pe_cache_growth(torch_cuda, state1234):
     # PE cache starts at 10 frames and regrows on demand (vad/modeling/transformer.py:392-397)
     from oracle import oracle
