@@ -160,13 +160,17 @@ def main():
     x = torch.from_numpy(np.random.default_rng(rank).uniform(-13.8, 4.2, (B, T, F_MEL)).astype(np.float32)).to(dev)
     if args.precision == "bf16":
         x = x.to(torch.bfloat16)
+    # The single collective of the path: one RCCL all_gather of this step's log-probs [B,T,2] per rank, ordered
+    # after the step's kernels.  Measured on 1 GPU through RCCL (SAVAD_BENCH_FORCE_DIST=1): +2 us per step; an
+    # async, double-buffered variant that lets the gather overlap the next step's kernels measured +45 us per step
+    # (the extra stream's barrier packets cost more than the 205 KB transfer), so the plain form stays.
     gathered = torch.empty((world, B, T, 2), dtype=torch.float32, device=dev) if use_dist else None
 
     def step():
         with torch.no_grad():
             y = model(features=x)
         if use_dist:
-            dist.all_gather_into_tensor(gathered, y)  # the single collective of the path (measured: +2 us per step at N=1)
+            dist.all_gather_into_tensor(gathered, y)
         return y
 
     def drain():
@@ -205,6 +209,8 @@ def main():
         elapsed_ev, y = timed_region()
     ktimes = [] if args.no_events else model.kernel_times()
     ok = bool(torch.isfinite(y).all().item())
+    if use_dist:  # the last gather really delivered this rank's shard
+        ok = ok and bool(torch.equal(gathered[rank], y))
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
