@@ -143,6 +143,16 @@ def test_against_oracle(torch_cuda, model, state1234, shape):
     assert err < TIGHT, err
 
 
+def test_long_sequence(torch_cuda, model, state1234):
+    """One 20 s sequence (T = 2049: 65 key tiles, ragged tail, PE table grown twice, automatic key splits)."""
+    from oracle import oracle
+
+    x = feats(2049, (1, 2049, 80))
+    ref = oracle.forward(state1234, x)
+    assert np.abs(run(torch_cuda, model, x) - ref).max() < TIGHT
+    assert np.abs(run_bf16(torch_cuda, model, x) - ref).max() < BF16_TOL
+
+
 @pytest.mark.parametrize("splits", [1, 2, 5, 8])
 def test_attention_split_invariance(torch_cuda, model, golden, splits):
     y = run(torch_cuda, model, feats(102, (2, 800, 80)), splits)
