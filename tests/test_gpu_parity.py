@@ -489,6 +489,43 @@ def test_wav_to_probabilities_plumbing(torch_cuda, model, state1234, tmp_path):
     assert probs.shape == (301, 7) and np.abs(probs - ref_probs).max() < 1e-4
 
 
+def test_evaluate_command_end_to_end(torch_cuda, state1234, tmp_path):
+    """`evaluate` (vad/evaluate.py:20-190) from files: checkpoint + data list + WAV + v0.3 labels -> metric lines.
+    The boosted AUC must equal the one computed from the oracle's probabilities on the oracle's log-mel."""
+    import json
+    import wave
+    from datetime import timedelta
+
+    from oracle import logmel, oracle
+    from voice_activity_detection_amd.data_models import Activity, VoiceActivity
+    from voice_activity_detection_amd.evaluate import evaluate_vad_from_scratch
+    from voice_activity_detection_amd.features import load_wav_mono16k
+    from voice_activity_detection_amd.metrics import roc_auc
+
+    torch = torch_cuda
+    cfg = {"model": {"name": "self-attention", "self_attention": {"num_layers": 3, "d_model": 128, "dropout": 0.5}},
+           "feature_extractor": {"transform": {"n_mels": 80}},
+           "context_resolution": {"context_window_half_frames": 19, "context_window_jump_frames": 9}}
+    torch.save({"config": cfg, "state_dict": {k: torch.from_numpy(v) for k, v in state1234.items()}}, tmp_path / "model.checkpoint")
+    rng = np.random.default_rng(9)
+    pcm = (rng.standard_normal(16000 * 4) * 2500 * (1 + np.sin(np.arange(64000) / 4000.0))).astype(np.int16)
+    with wave.open(str(tmp_path / "clip.wav"), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+    VoiceActivity(timedelta(seconds=4), [Activity(timedelta(seconds=0.5), timedelta(seconds=1.7)),
+                                         Activity(timedelta(seconds=2.2), timedelta(seconds=3.4))], None, None).save(tmp_path / "va.json")
+    (tmp_path / "list.jsonl").write_text(json.dumps({"audio_path": "clip.wav", "voice_activity_path": "va.json"}) + "\n")
+    out = evaluate_vad_from_scratch(tmp_path / "list.jsonl", tmp_path / "model.checkpoint", tmp_path / "eval.jsonl", echo=lambda s: None)
+    r = out["files"][0]
+    assert all(np.isfinite(v) for k, v in r.items() if not k.endswith("_path"))
+    labels = VoiceActivity.load(tmp_path / "va.json").to_labels(100)
+    ref_probs, ref_mean = oracle.predict_probabilities(state1234, logmel.log_mel(load_wav_mono16k(tmp_path / "clip.wav")))
+    assert abs(r["auc"] - roc_auc(labels, ref_probs.mean(axis=1)[: len(labels)])) < 1e-3
+    assert len((tmp_path / "eval.jsonl").read_text().splitlines()) == 2
+
+
 def test_config3_size_batch(torch_cuda, model, state1234):
     """BASELINE configs[2]/[3] per-GPU size [256,800,80]: sampled sequences against the oracle (fp32 path and
     bf16 path), plus the size-independent properties on the whole batch."""

@@ -1,6 +1,8 @@
-"""``python -m voice_activity_detection_amd predict AUDIO CHECKPOINT [options]`` -- the reference's
-``python main.py predict`` (``main.py:9``, ``vad/predict.py:10-50``) on the MI355X path: same positional
-arguments, same options, JSON v0.3 to ``--output-path`` or a printed summary."""
+"""``python -m voice_activity_detection_amd predict AUDIO CHECKPOINT [options]`` and
+``... evaluate EVAL_LIST CHECKPOINT [options]`` -- the reference's ``python main.py predict`` / ``evaluate``
+(``main.py:8-10``, ``vad/predict.py:10-50``, ``vad/evaluate.py:20-29``) on the MI355X path: same positional
+arguments, same options, JSON v0.3 (predict) / metric lines (evaluate) to ``--output-path`` or stdout.
+``train`` is out of scope."""
 from __future__ import annotations
 
 import argparse
@@ -26,7 +28,24 @@ def main(argv=None) -> int:
     p.add_argument("--return-probs", action="store_true")
     p.add_argument("--probs-sample-rate", type=int, default=None)
     p.add_argument("--device", default="cuda")
+    e = sub.add_parser("evaluate", help="frame metrics over a labelled data list (vad/evaluate.py:20-29)")
+    e.add_argument("eval_path", type=Path)
+    e.add_argument("checkpoint_path", type=Path)
+    e.add_argument("--output-path", type=Path, default=None, help="Path to store output. Default to stdout.")
+    e.add_argument("--data-dir", type=Path, default=None)
+    e.add_argument("--threshold", type=float, default=0.5)
+    e.add_argument("--shuffle", action="store_true")
+    e.add_argument("--limit", type=int, default=None)
+    e.add_argument("--random-seed", type=int, default=0)
+    e.add_argument("--device", default="cuda")
     args = ap.parse_args(argv)
+
+    if args.command == "evaluate":
+        from .evaluate import evaluate_vad_from_scratch
+
+        evaluate_vad_from_scratch(args.eval_path, args.checkpoint_path, args.output_path, args.data_dir, args.threshold,
+                                  args.shuffle, args.limit, args.random_seed, args.device)
+        return 0
 
     from .predictor import VADFromScratchPredictor, VADPredictParameters
 
