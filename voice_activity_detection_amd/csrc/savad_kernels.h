@@ -205,13 +205,6 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel(
 // kernel combines the splits and divides.
 // ---------------------------------------------------------------------------------------------
 
-// One 32-key tile of the flash loop, K and V tiles supplied by functors (LDS or global).
-// sc in/out: raw scores S^T (already masked) -> probabilities p.
-// Deferred rescale: the running reference point m_run only moves when some row's maximum has grown by
-// more than 2^RESCALE_LOG2 since it was set (wave-uniform decision); until then probabilities are taken
-// relative to the stale reference, p = 2^((s - m_run) c) <= 2^RESCALE_LOG2.  O, l and p stay mutually
-// consistent, so O / l is unchanged (fp32 accumulators: no precision cost), and the 64-register rescale of O
-// plus one exp -- needed on ~3/4 of the tiles with a per-tile reference on random data -- all but disappears.
 // Drain this wave's vector-memory operations (global loads AND the LDS-DMA issued through inline asm).
 // It must be the BUILTIN, not an asm string: the compiler's wait-count pass cannot see into asm, would
 // still believe earlier global loads (e.g. the Q rows read before the key loop) to be pending, and
@@ -221,6 +214,14 @@ __device__ __forceinline__ void wait_vmem_all() {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
     asm volatile("" ::: "memory");
 }
+
+// One 32-key tile of the flash loop, K and V tiles supplied by functors (LDS or global).
+// sc in/out: raw scores S^T (already masked) -> probabilities p.
+// Deferred rescale: the running reference point m_run only moves when some row's maximum has grown by
+// more than 2^RESCALE_LOG2 since it was set (wave-uniform decision); until then probabilities are taken
+// relative to the stale reference, p = 2^((s - m_run) c) <= 2^RESCALE_LOG2.  O, l and p stay mutually
+// consistent, so O / l is unchanged (fp32 accumulators: no precision cost), and the 64-register rescale of O
+// plus one exp -- needed on ~3/4 of the tiles with a per-tile reference on random data -- all but disappears.
 constexpr float RESCALE_LOG2 = 16.0f;
 __device__ __forceinline__ void online_softmax(f32x16& sc, float& m_run, float& l_run, f32x16 (&O)[4], float c) {
     float mx = sc[0];
