@@ -38,25 +38,58 @@ def flops_per_frame(T: int) -> float:
     return 2 * F * D + L * (8 * D * D + 4 * T * D + 4 * D * 4 * D) + 4 * D
 
 
-def measured_traffic(precision: str, B: int, T: int):
-    """HBM-side bytes per launch of the attention kernel from the committed rocprofv3 PMC passes
+# Algorithmic work of one launch of each kernel of the forward (per frame unless noted):
+# attention 4*T*D FLOP (QK^T + PV), row chain 393 216 FLOP (out-proj 32 768 + FFN 262 144 + next QKV 98 304), last row
+# chain 295 424 (classifier instead of QKV), input stage 118 784.  Bytes: what the launch must read + write in HBM.
+def launch_work(name: str, B: int, T: int, e: int):
+    """name = launch label reported by the library -> (FLOP, algorithmic HBM bytes) of one launch; e = bytes per
+    element of q/k/v/context (4 fp32, 2 bf16).  The residual stream is fp32 in the fp32 path, fp16 in the bf16 path."""
+    D, F = D_MODEL, F_MEL
+    frames = B * T
+    att = 4.0 * T * T * D * B
+    hres = 4 if e == 4 else 2
+    base = name.replace("_bf16", "")
+    if base == "attention":
+        return att, frames * 4 * D * e                                   # Q, K, V read + context written
+    if base == "attention_row":
+        return att + 393216.0 * frames, frames * (3 * D * e + D * hres) * 2   # q, k, v, h read; h, q', k', v' written
+    if base == "attention_row_last":
+        return att + 295424.0 * frames, frames * (3 * D * e + D * hres + 8)
+    if base == "row":
+        return 393216.0 * frames, frames * (D * e + 8 + D * hres + D * hres + 3 * D * e)
+    if base == "row_last":
+        return 295424.0 * frames, frames * (D * e + 8 + D * hres + 8)
+    if base == "input_qkv":
+        return 118784.0 * frames, frames * (F * e + D * hres + 3 * D * e)
+    return 0.0, 0
+
+
+def measured_traffic(name: str, precision: str, B: int, T: int):
+    """HBM-side bytes per launch of kernel `name` from the committed rocprofv3 PMC passes
     (profiles/*_traffic.json, produced by scripts/profile_gpu.sh; FETCH_SIZE doubled per the gfx950
     correction of MI355X_MICROARCH.md).  PMC counters cannot be collected from inside this process, so
     the number is only reported when the workload matches a profiled one: fp32 [32,800] (the default
     bench line) or bf16 [256,800]."""
     if (precision, B, T) == ("fp32", 32, 800):
         files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if "bf16" not in f.name]
-        prefix = "attention_kernel"
     elif (precision, B, T) == ("bf16", 256, 800):
         files = sorted((REPO / "profiles").glob("*bf16_b256_traffic.json"))
-        prefix = "attention_kernel_bf16"
     else:
         return None
     if not files:
         return None
     data = json.loads(files[-1].read_text())
+    last = name.endswith("_last") or name.endswith("_last_bf16")
+    stem = name.replace("_last", "")
+    prefix = {"attention": "attention_kernel", "attention_row": "attention_row_kernel", "row": "row_kernel", "input_qkv": "input_qkv_kernel",
+              "attention_bf16": "attention_kernel_bf16", "row_bf16": "row_kernel_bf16", "input_qkv_bf16": "input_qkv_kernel_bf16"}.get(stem)
+    if prefix is None:
+        return None
     for key, entry in data.items():
-        if key == prefix or key.startswith(prefix + "<"):
+        if key == prefix or key.startswith(prefix + "<") or key.startswith(prefix + "_m"):
+            if "<" in key and prefix.startswith(("attention_row", "row")):
+                if ("<true" in key) != last:
+                    continue
             return round(entry["hbm_bytes_per_launch"])
     return None
 
@@ -119,7 +152,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
     ap.add_argument("--frames", type=int, default=800, help="T")
     ap.add_argument("--splits", type=int, default=0, help="attention key splits (0 = auto)")
-    ap.add_argument("--row-mode", type=int, default=0, help="0 auto, 1 N-split 32-row tiles, 2 M-split 128-row tiles")
+    ap.add_argument("--row-mode", type=int, default=0, help="0 auto, 1 N-split 32-row tiles, 2 M-split 128-row tiles (separate attention / row launches), 3 M-split fused with attention")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = BASELINE configs[1] (default); bf16 = configs[2]: bf16 MFMA operands, bf16 features")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -220,23 +253,35 @@ def main():
         roof = None
         if ktimes:
             peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
-            att = [t for n, t in ktimes if n.startswith("attention")]
-            att_ms = sum(att) / len(att)
-            att_flops = 4.0 * T * T * D_MODEL * B  # QK^T + PV of one layer's launch
-            ach = att_flops / (att_ms * 1e-3) / 1e12
-            att_bytes = 4 * T * D_MODEL * (2 if args.precision == "bf16" else 4) * B  # Q, K, V read + context written
+            e = 2 if args.precision == "bf16" else 4
+            # the dominant kernel = the launch label with the largest total time (the fused attention + row chain
+            # when the library fuses them, otherwise the attention stage)
+            by_name = {}
+            for n, t in ktimes:
+                by_name.setdefault(n, []).append(t)
+            dom = max(by_name, key=lambda n: sum(by_name[n]))
+            dom_ms = sum(by_name[dom]) / len(by_name[dom])
+            dom_flops, dom_bytes = launch_work(dom, B, T, e)
+            ach = dom_flops / (dom_ms * 1e-3) / 1e12
+            per_kernel = {}
+            for n, ts in by_name.items():
+                fl, by = launch_work(n, B, T, e)
+                ms_k = sum(ts) / len(ts)
+                per_kernel[n] = {"launches": len(ts), "ms": round(ms_k, 4), "tflops": round(fl / (ms_k * 1e-3) / 1e12, 2),
+                                 "frac": round(fl / (ms_k * 1e-3) / 1e12 / peak, 4)}
             roof = {
-                "bound": "mfma", "kernel": "attention_kernel (1 launch per layer)",
+                "bound": "mfma", "kernel": f"{dom} ({len(by_name[dom])} launches per forward)",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4),
-                "traffic": measured_traffic(args.precision, B, T), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
-                "algorithmic_bytes": att_bytes,
-                # the same launch against the HBM roofline (SURVEY section 8d "attention HBM roofline"): it is the
-                # non-binding one -- the fp32 MFMA rate caps it at 9.8 % of 8 TB/s, bf16 at ~100 %
-                "hbm_achieved_TBps": round(att_bytes / (att_ms * 1e-3) / 1e12, 3), "hbm_peak_TBps": PEAK_HBM_TBPS,
-                "hbm_frac": round(att_bytes / (att_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
-                "ms_per_launch": round(att_ms, 4),
+                "traffic": measured_traffic(dom, args.precision, B, T), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                "algorithmic_bytes": dom_bytes, "algorithmic_flops": dom_flops,
+                # the same launch against the HBM roofline: the non-binding one -- the fp32 MFMA
+                # rate caps the attention stage at 9.8 % of 8 TB/s
+                "hbm_achieved_TBps": round(dom_bytes / (dom_ms * 1e-3) / 1e12, 3), "hbm_peak_TBps": PEAK_HBM_TBPS,
+                "hbm_frac": round(dom_bytes / (dom_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
+                "ms_per_launch": round(dom_ms, 4),
                 "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / peak, 4),
+                "per_kernel": per_kernel,
                 "kernels_ms": {f"{i}:{n}": round(t, 4) for i, (n, t) in enumerate(ktimes)},
             }
         line = {

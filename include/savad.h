@@ -90,7 +90,10 @@ int savad_forward_ex(savad_handle h, const void* x, int x_dtype, int B, int T, f
 int savad_set_attention_splits(savad_handle h, int splits);
 /* Tuning knob: tiling of the row-wise stages: 0 = automatic, 1 = 32-row tiles with the output
  * features split over the workgroup's waves, 2 = 128-row tiles with the weight stream shared
- * through LDS. */
+ * through LDS, attention and row stages as separate launches, 3 = as 2 but with the attention stage
+ * and the row chain of a query-block group fused into one launch per layer whenever T > 32 and the
+ * key range is not split (what "automatic" picks for large batches).  With bf16 operands:
+ * 2 = 8-wave workgroups, anything else = 4-wave workgroups. */
 int savad_set_row_mode(savad_handle h, int mode);
 /* Fills the names/durations of the kernels of the most recent savad_forward when profiling is
  * enabled with savad_set_profiling(h, 1): the forward then brackets every launch with hipEvents on

@@ -18,6 +18,13 @@ def short(name):
     m = re.search(r"savad::(?:bf::)?(\w+)(<[^>]*>)?", name)
     if m:
         return m.group(1) + (m.group(2) or "")
+    # rocprofv3 leaves some template instantiations mangled: _ZN5savad2bf15row_kernel_bf16ILb0ELi4EEEv...
+    m = re.match(r"_ZN5savad(?:2bf)?\d+([A-Za-z_0-9]+?)I((?:Lb[01]E|Li\d+E|DF16b|f)+)E", name)
+    if m:
+        args = []
+        for a in re.findall(r"Lb[01]E|Li\d+E|DF16b|f", m.group(2)):
+            args.append({"Lb0E": "false", "Lb1E": "true", "DF16b": "__bf16", "f": "float"}.get(a, a[2:-1]))
+        return m.group(1) + "<" + ", ".join(args) + ">"
     return name[:60]
 
 
@@ -78,7 +85,7 @@ for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         acc, cnt = defaultdict(float), defaultdict(int)
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if row["Counter_Name"] == cname and "savad::" in row["Kernel_Name"]:
+                if row["Counter_Name"] == cname and "savad" in row["Kernel_Name"]:
                     acc[short(row["Kernel_Name"])] += float(row["Counter_Value"])
                     cnt[short(row["Kernel_Name"])] += 1
         for k in acc:

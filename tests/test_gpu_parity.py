@@ -175,6 +175,44 @@ def test_row_tilings_agree_with_golden(torch_cuda, model, golden, row_mode):
     assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g3_seqsum"]).max() < 1600 * TIGHT
 
 
+def test_fused_attention_row_launches(torch_cuda, model, golden, state1234):
+    """row_mode 3 with one key split: attention + row chain in ONE launch per layer (q/k/v double-buffered), the
+    path `automatic` takes for large batches.  Goldens incl. ragged lengths (lanes past T fill MFMA tiles but never
+    store), batches that do not fill the 8 XCDs, and bit-identity with the two-launch M-split path is NOT expected
+    (the context skips the fp32 partial-buffer round trip but the arithmetic is the same): compare to goldens."""
+    from oracle import oracle
+
+    for tag, seed, shape in (("g2_out", 102, (2, 800, 80)), ("g6_out", 600, (2, 40, 80))):
+        y = run(torch_cuda, model, feats(seed, shape), splits=1, row_mode=3)
+        assert np.abs(y - golden[tag]).max() < TIGHT
+    for T in (33, 65, 100, 801):
+        y = run(torch_cuda, model, feats(400 + T, (3, T, 80)), splits=1, row_mode=3)
+        assert np.abs(y - golden[f"g4_T{T}"]).max() < TIGHT
+    for shape in ((9, 97, 80), (1, 2049, 80), (17, 160, 80)):
+        x = feats(sum(shape), shape)
+        assert np.abs(run(torch_cuda, model, x, splits=1, row_mode=3) - oracle.forward(state1234, x)).max() < TIGHT
+    # T <= 32 has no fused form: row_mode 3 must fall back to the separate launches and still be right
+    y = run(torch_cuda, model, feats(101, (4, 7, 80)), splits=1, row_mode=3)
+    assert np.abs(y - golden["g1_out"]).max() < TIGHT
+    # the same sequence alone and inside a batch: bit-exact (sequences are independent)
+    x = feats(5, (12, 800, 80))
+    assert np.array_equal(run(torch_cuda, model, x[7:8], splits=1, row_mode=3), run(torch_cuda, model, x, splits=1, row_mode=3)[7:8])
+    # workspace poisoning: a second call on a recycled workspace full of NaNs must not leak them through the
+    # over-read V rows behind the batch
+    torch = torch_cuda
+    model.row_mode, model.attention_splits = 3, 1
+    try:
+        xt = torch.from_numpy(feats(77, (3, 801, 80))).cuda()
+        with torch.no_grad():
+            y0 = model(features=xt).clone()
+            if getattr(model, "_workspace", None) is not None:
+                model._workspace.view(torch.float32).fill_(float("nan"))
+            y1 = model(features=xt)
+        assert torch.isfinite(y1).all() and torch.equal(y0, y1)
+    finally:
+        model.row_mode, model.attention_splits = 0, 0
+
+
 def test_properties_full_size(torch_cuda, model):
     # size-independent properties at config-2 size: normalisation, batch-permutation equivariance
     # (sequences are independent: bit-exact), determinism

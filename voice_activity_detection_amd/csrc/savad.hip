@@ -136,7 +136,9 @@ int choose_splits(const savad_model* m, int B, int T) {
 struct Workspace {
     size_t rows, rows_pad;
     int S;
-    size_t h, q, k, v, opart, ml, xpad, total;  // float offsets
+    bool msplit;  // row-wise stages on 128-row tiles with the weight stream shared through LDS
+    bool fused;   // attention + row chain in one launch per layer (q/k/v double-buffered: q2, k2, v2)
+    size_t h, q, k, v, q2, k2, v2, opart, ml, xpad, total;  // float offsets
 };
 
 Workspace plan(const savad_model* m, int B, int T) {
@@ -144,6 +146,15 @@ Workspace plan(const savad_model* m, int B, int T) {
     w.rows = (size_t)B * T;
     w.rows_pad = (w.rows + 127) / 128 * 128;  // whole 128-row tiles (M-split kernels); also a multiple of TILE
     w.S = choose_splits(m, B, T);
+    // Row-wise stages: 128-row tiles with the weight stream shared through LDS (M split) when that
+    // fills the chip; 32-row tiles with the output features split over the 4 waves (N split) when
+    // the batch is small and the critical path per workgroup matters more than weight traffic.
+    // Measured crossover on MI355X at T=800: B=24 (150 tiles) N-split 105 us vs M-split 119 us per
+    // layer; B=32 (200 tiles) 134 vs 120.
+    w.msplit = m->row_mode >= 2 || (m->row_mode == 0 && w.rows_pad / 128 >= 192);
+    // In the M-split regime without key splits the attention stage and the row chain of a query-block group
+    // run back to back in one workgroup (attention_row_kernel).  row_mode 2 keeps them as separate launches.
+    w.fused = w.msplit && T > 32 && w.S == 1 && m->row_mode != 2;
     size_t off = 0;
     w.h = off;
     off += w.rows_pad * D;
@@ -153,6 +164,15 @@ Workspace plan(const savad_model* m, int B, int T) {
     off += (w.rows_pad + TILE) * D;
     w.v = off;
     off += (w.rows_pad + TILE) * D;
+    w.q2 = w.k2 = w.v2 = off;
+    if (w.fused) {
+        w.q2 = off;
+        off += (w.rows_pad + TILE) * D;
+        w.k2 = off;
+        off += (w.rows_pad + TILE) * D;
+        w.v2 = off;
+        off += (w.rows_pad + TILE) * D;
+    }
     w.opart = off;
     off += (size_t)w.S * w.rows_pad * D;
     w.ml = off;
@@ -448,7 +468,7 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
-    if (!m || mode < 0 || mode > 2) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 3) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -624,13 +644,8 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     const float* P = m->d_packed;
     Prof prof(m, st);
 
-    // Row-wise stages: 128-row tiles with the weight stream shared through LDS (M split) when that
-    // fills the chip; 32-row tiles with the output features split over the 4 waves (N split) when
-    // the batch is small and the critical path per workgroup matters more than weight traffic.
     const int tiles_m = (int)(ws.rows_pad / 128);
-    // Measured crossover on MI355X at T=800: B=24 (150 tiles) N-split 105 us vs M-split 119 us per
-    // layer; B=32 (200 tiles) 134 vs 120.
-    const bool msplit = m->row_mode == 2 || (m->row_mode == 0 && tiles_m >= 192);
+    const bool msplit = ws.msplit;
     if (msplit)
         hipLaunchKernelGGL(input_qkv_kernel_m, dim3(tiles_m), dim3(256), 0, st, x, (int)ws.rows, T, F, win_fp32(m),
                            R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
@@ -638,6 +653,31 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
         hipLaunchKernelGGL(input_qkv_kernel, dim3(tiles), dim3(256), 0, st, x, (int)ws.rows, T, F, win_fp32(m),
                            R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
     prof.mark("input_qkv");
+    if (ws.fused) {
+        float* qkv[2][3] = {{q, k, v}, {W + ws.q2, W + ws.k2, W + ws.v2}};
+        const int QB = (T + 31) / 32, NG = (QB + 3) / 4;
+        const int grid = 8 * ((B + 7) / 8) * NG;
+        for (int l = 0; l < L; ++l) {
+            const auto& r = m->lr[l];
+            const auto& p = m->lp[l];
+            float** cur = qkv[l & 1];
+            float** nxt = qkv[(l + 1) & 1];
+            if (l + 1 < L) {
+                hipLaunchKernelGGL(attention_row_kernel<false>, dim3(grid), dim3(256), 0, st, cur[0], cur[1], cur[2], B, T, NG, c, hb,
+                                   R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2, P + m->lp[l + 1].wqkv,
+                                   P + m->lp[l + 1].bqkv, nxt[0], nxt[1], nxt[2], out);
+                prof.mark("attention_row");
+            } else {
+                hipLaunchKernelGGL(attention_row_kernel<true>, dim3(grid), dim3(256), 0, st, cur[0], cur[1], cur[2], B, T, NG, c, hb,
+                                   R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2, P + m->p_wc, P + m->p_bc, nxt[0],
+                                   nxt[1], nxt[2], out);
+                prof.mark("attention_row_last");
+            }
+        }
+        prof.done();
+        HIP_TRY(hipGetLastError());
+        return SAVAD_OK;
+    }
     for (int l = 0; l < L; ++l) {
         if (T <= 32) {
             const int G = 32 / T, nblk = (B + G - 1) / G;

@@ -760,19 +760,20 @@ __device__ __forceinline__ void layernorm_regs(const f32x16 (&x)[4], f32x4 (&xg)
 // already be in flight into ring buffer 0; bq = LDS copy of the packed QKV bias [384].
 __device__ __forceinline__ void qkv_tail_m(const f32x4 (&xg)[16], const float* __restrict__ Wqkv, const float* bq,
                                            float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
-                                           size_t row, float* ring, const DmaLanes& LA, int w, int n, int h) {
+                                           size_t row, float* ring, const DmaLanes& LA, int w, int n, int h,
+                                           bool store_ok = true /* per lane: this lane's row exists */) {
     float* dst[3] = {q, k, v};
     f32x16 prev = zero16();
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
         ring_acquire();
         if (j + 1 < 12) dma_block(Wqkv + (size_t)(32 * (j + 1)) * D, LA, ring + ((j + 1) & 1) * WBLK, w);
-        if (j > 0) store_block(dst[(j - 1) >> 2] + row * D + 32 * ((j - 1) & 3), prev, h);
+        if (j > 0 && store_ok) store_block(dst[(j - 1) >> 2] + row * D + 32 * ((j - 1) & 3), prev, h);
         f32x16 acc = bias_block(bq + 32 * j, h);
         gemm_lds_a(acc, ring + (j & 1) * WBLK, n, h, xg);
         prev = acc;
     }
-    store_block(dst[2] + row * D + 96, prev, h);
+    if (store_ok) store_block(dst[2] + row * D + 96, prev, h);
 }
 
 __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
@@ -817,6 +818,88 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
     f32x4 xg[16];
     layernorm_regs(h0, xg);
     qkv_tail_m(xg, Wqkv, bq, q, k, v, row, ring, LA, w, n, h);
+}
+
+// The row-wise chain of one layer for the 32 rows of a wave, weights through the workgroup's LDS ring:
+//   h1 = h + bo + ctx Wo^T -> LN -> FFN (+ residual) -> next layer's LN + QKV, or final LN + classifier.
+// In : xg = attention context of the wave's rows (row layout), h1 = their residual-stream rows.
+// Pre: block 0 of Wo is in flight into ring buffer 0; lbo / lb1 / lb2 / lbn are being staged (the first ring
+//      barrier publishes both).  store_ok / out_ok (per lane): the lane's row exists and may be written.
+template <bool LAST>
+__device__ __forceinline__ void row_chain_m(f32x4 (&xg)[16], f32x16 (&h1)[4], size_t row, bool store_ok, bool out_ok,
+                                            float* ring, const float* lbo, const float* lb1, const float* lb2, const float* lbn,
+                                            const DmaLanes& LA, const DmaLanes& LB, const float* __restrict__ Wo,
+                                            const float* __restrict__ W1, const float* __restrict__ W2,
+                                            const float* __restrict__ Wn, const float* __restrict__ bn,
+                                            float* __restrict__ hbuf, float* __restrict__ q, float* __restrict__ k,
+                                            float* __restrict__ v, float* __restrict__ out, int w, int n, int h) {
+    SAVAD_STAMP(1);
+    // ---- h1 = h + bo + ctx Wo^T  (ring blocks 0..3)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        ring_acquire();
+        if (nb < 3)
+            dma_block(Wo + (size_t)(32 * (nb + 1)) * D, LA, ring + ((nb + 1) & 1) * WBLK, w);
+        else
+            dma_block(W1, LA, ring, w);
+        h1[nb] += bias_block(lbo + 32 * nb, h);
+        gemm_lds_a(h1[nb], ring + (nb & 1) * WBLK, n, h, xg);
+    }
+    SAVAD_STAMP(2);
+    layernorm_regs(h1, xg);
+    SAVAD_STAMP(3);
+    // ---- FFN: 16 hidden chunks of 32; W1 chunk in ring buffer 0, W2 column slice in buffer 1.  The
+    // accumulators START from the residual stream (h1 + b2: transformer.py:235-237), so h1 needs no
+    // registers of its own across the FFN and the kernel stays spill-free at 2 waves per SIMD.
+    f32x16(&o)[4] = h1;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) o[nb] += bias_block(lb2 + 32 * nb, h);
+    SAVAD_STAMP(4);
+#pragma unroll 1
+    for (int ch = 0; ch < 16; ++ch) {
+        ring_acquire();
+        dma_block(W2 + 32 * ch, LB, ring + WBLK, w);
+        f32x16 a = bias_block(lb1 + 32 * ch, h);
+        gemm_lds_a(a, ring, n, h, xg);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
+        ring_acquire();
+        if (ch + 1 < 16)
+            dma_block(W1 + (size_t)(32 * (ch + 1)) * D, LA, ring, w);
+        else if (!LAST)
+            dma_block(Wn, LA, ring, w);
+        gemm_lds_b(o, ring + WBLK, n, h, a);
+    }
+    SAVAD_STAMP(5);
+    if (!LAST) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) if (store_ok) store_block(hbuf + row * D + 32 * nb, o[nb], h);
+    }
+    SAVAD_STAMP(6);
+    layernorm_regs(o, xg);
+    SAVAD_STAMP(7);
+    if (!LAST) {
+        qkv_tail_m(xg, Wn, lbn, q, k, v, row, ring, LA, w, n, h, store_ok);
+        SAVAD_STAMP(8);
+    } else {
+        float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const f32x4 c0 = ld4(Wn + 8 * G + 4 * h), c1 = ld4(Wn + D + 8 * G + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z0 = __builtin_fmaf(xg[G][e], c0[e], z0);
+                z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
+            }
+        }
+        z0 = half_sum(z0);
+        z1 = half_sum(z1);
+        z0 += bn[0];
+        z1 += bn[1];
+        const float mx = fmaxf(z0, z1);
+        const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+        if (h == 0 && out_ok) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+    }
 }
 
 template <bool LAST>
@@ -879,73 +962,119 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
 #pragma unroll
         for (int G = 0; G < 16; ++G) xg[G] *= inv;
     }
-    SAVAD_STAMP(1);
-    // ---- h1 = h + bo + ctx Wo^T  (ring blocks 0..3)
+    row_chain_m<LAST>(xg, h1, row, true, row < (size_t)rows, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, q, k, v, out,
+                      w, n, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused stage (T > 32, no key split, M-split regime): attention of one (sequence, group of <= 4 query
+// blocks) IMMEDIATELY followed by the row chain of those same rows, in the same workgroup.  The
+// unnormalised context O^T a wave holds after its last key tile IS the row chain's B operand (row
+// layout), so the context never leaves registers: no partial buffer, one launch per layer instead of
+// two, and the chain's weight ring reuses the K/V staging LDS.  Because a workgroup now writes the NEXT
+// layer's K/V rows while other workgroups of the sequence may still be reading this layer's, q/k/v are
+// double-buffered between layers (read q,k,v -- write qn,kn,vn).
+// Rows are addressed per sequence (flat row b*T + 32*qb + m); lanes past T exist only to fill the MFMA
+// tile: they compute on zeros and never store.
+// ---------------------------------------------------------------------------------------------
+template <bool LAST>
+__global__ __launch_bounds__(256, 2) void attention_row_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int B, int T, int NG, float c,
+    float* __restrict__ hbuf, const float* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ Wn,
+    const float* __restrict__ bn, float* __restrict__ qn, float* __restrict__ kn, float* __restrict__ vn,
+    float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * KV_TILE_FLOATS];  // attention: [buffer 2][K, V]; then ring + biases
+    static_assert(4 * KV_TILE_FLOATS >= 2 * WBLK + 9 * D, "the row chain's ring and biases must fit the K/V staging area");
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int QB = (T + 31) / 32, NT = QB;
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;  // all workgroups of a sequence on one XCD (its K/V stay in that L2)
+    const int b = (i / NG) * 8 + xcd;
+    if (b >= B) return;
+    const int g = i % NG;
+    const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;
+    const int qb = qb0 + w;
+    const bool active = qb < qb1;  // wave-uniform
+    const size_t kbase = (size_t)b * T;
+    const size_t row = kbase + 32 * (size_t)(active ? qb : qb0) + m;
+    const bool qvalid = active && (32 * qb + m) < T;
+
+    f32x4 xg[16];  // Q rows first, the normalised context afterwards
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        ring_acquire();
-        if (nb < 3)
-            dma_block(Wo + (size_t)(32 * (nb + 1)) * D, LA, ring + ((nb + 1) & 1) * WBLK, w);
-        else
-            dma_block(W1, LA, ring, w);
-        h1[nb] += bias_block(lbo + 32 * nb, h);
-        gemm_lds_a(h1[nb], ring + (nb & 1) * WBLK, n, h, xg);
-    }
-    SAVAD_STAMP(2);
-    layernorm_regs(h1, xg);
-    SAVAD_STAMP(3);
-    // ---- FFN: 16 hidden chunks of 32; W1 chunk in ring buffer 0, W2 column slice in buffer 1.  The
-    // accumulators START from the residual stream (h1 + b2: transformer.py:235-237), so h1 needs no
-    // registers of its own across the FFN and the kernel stays spill-free at 2 waves per SIMD.
-    f32x16(&o)[4] = h1;
+    for (int G8 = 0; G8 < 16; ++G8) xg[G8] = ld4(q + row * D + 8 * G8 + 4 * h);
+    f32x16 O[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) o[nb] += bias_block(lb2 + 32 * nb, h);
-    SAVAD_STAMP(4);
-#pragma unroll 1
-    for (int ch = 0; ch < 16; ++ch) {
-        ring_acquire();
-        dma_block(W2 + 32 * ch, LB, ring + WBLK, w);
-        f32x16 a = bias_block(lb1 + 32 * ch, h);
-        gemm_lds_a(a, ring, n, h, xg);
+    for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
+    float m_run = NEG_BIG, l_run = 0.0f;
+
+    const DmaLanes LK = dma_lanes_rows32(D, true, w, lane), LV = dma_lanes_rows32(D, false, w, lane);
+    dma_block(k + kbase * D, LK, lds, w);
+    dma_block(v + kbase * D, LV, lds + KV_TILE_FLOATS, w);
+    for (int jt = 0; jt < NT; ++jt) {
+        float* kb = lds + (jt & 1) * 2 * KV_TILE_FLOATS;
+        float* vb = kb + KV_TILE_FLOATS;
+        wait_vmem_all();
+        __syncthreads();  // tile jt has landed for every wave; everyone is done reading the other buffer
+        if (jt + 1 < NT) {
+            float* kn2 = lds + ((jt + 1) & 1) * 2 * KV_TILE_FLOATS;
+            dma_block(k + (kbase + 32 * (size_t)(jt + 1)) * D, LK, kn2, w);
+            dma_block(v + (kbase + 32 * (size_t)(jt + 1)) * D, LV, kn2 + KV_TILE_FLOATS, w);
+        }
+        if (!active) continue;
+        f32x16 sc = zero16();
+        const float* krow = kb + n * D;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
-        ring_acquire();
-        if (ch + 1 < 16)
-            dma_block(W1 + (size_t)(32 * (ch + 1)) * D, LA, ring, w);
-        else if (!LAST)
-            dma_block(Wn, LA, ring, w);
-        gemm_lds_b(o, ring + WBLK, n, h, a);
-    }
-    SAVAD_STAMP(5);
-    if (!LAST) {
+        for (int G8 = 0; G8 < 16; ++G8) {
+            const f32x4 k4 = ld4(krow + 4 * ((2 * G8 + h) ^ (n & 15)));
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) store_block(hbuf + row * D + 32 * nb, o[nb], h);
-    }
-    SAVAD_STAMP(6);
-    layernorm_regs(o, xg);
-    SAVAD_STAMP(7);
-    if (!LAST) {
-        qkv_tail_m(xg, Wn, lbn, q, k, v, row, ring, LA, w, n, h);
-        SAVAD_STAMP(8);
-    } else {
-        float z0 = 0.0f, z1 = 0.0f;
+            for (int e = 0; e < 4; ++e) sc = SAVAD_MFMA(k4[e], xg[G8][e], sc);
+        }
+        if (32 * jt + 32 > T) {
 #pragma unroll
-        for (int G = 0; G < 16; ++G) {
-            const f32x4 c0 = ld4(Wn + 8 * G + 4 * h), c1 = ld4(Wn + D + 8 * G + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                z0 = __builtin_fmaf(xg[G][e], c0[e], z0);
-                z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
+            for (int r = 0; r < 16; ++r) {
+                const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
+                sc[r] = (32 * jt + jk < T) ? sc[r] : NEG_BIG;
             }
         }
-        z0 = half_sum(z0);
-        z1 = half_sum(z1);
-        z0 += bn[0];
-        z1 += bn[1];
-        const float mx = fmaxf(z0, z1);
-        const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
-        if (h == 0 && row < (size_t)rows) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+        online_softmax(sc, m_run, l_run, O, c);
+        const float* vp = vb + 4 * h * D + n;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
+        }
     }
+    // ---- hand-over: everyone is done with the K/V tiles; the staging area becomes weight ring + biases
+    float* ring = lds;
+    float* lbo = lds + 2 * WBLK;
+    float* lb1 = lbo + D;
+    float* lb2 = lb1 + DFF;
+    float* lbn = lb2 + D;
+    f32x16 h1[4];  // residual rows: requested before the barrier, consumed after the first ring block
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        h1[nb] = zero16();
+        add_block(h1[nb], hbuf + row * D + 32 * nb, h);
+    }
+    // The next layer's last key tile over-reads up to 31 V rows behind the batch; rows past B*T are never
+    // written by this kernel, and probability 0 times a non-finite value would poison the context.
+    if (!LAST && b == B - 1 && g == NG - 1) store_block(vn + ((size_t)B * T + m) * D + 32 * w, zero16(), h);
+    __syncthreads();
+    const DmaLanes LA = dma_lanes_rows32(D, true, w, lane), LB = dma_lanes_rows128(DFF, w, lane);
+    dma_block(Wo, LA, ring, w);
+    stage_bias(lbo, bo, D);
+    stage_bias(lb1, b1, DFF);
+    stage_bias(lb2, b2, D);
+    if (!LAST) stage_bias(lbn, bn, 3 * D);
+    {
+        const float inv = qvalid ? 1.0f / l_run : 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xg[4 * nb + (r >> 2)][r & 3] = qvalid ? O[nb][r] * inv : 0.0f;
+    }
+    row_chain_m<LAST>(xg, h1, row, qvalid, qvalid, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, qn, kn, vn, out, w, n, h);
 }
 
 // ---------------------------------------------------------------------------------------------
