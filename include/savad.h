@@ -93,7 +93,8 @@ int savad_set_attention_splits(savad_handle h, int splits);
  * through LDS, attention and row stages as separate launches, 3 = as 2 but with the attention stage
  * and the row chain of a query-block group fused into one launch per layer whenever T > 32 and the
  * key range is not split (what "automatic" picks for large batches).  With bf16 operands:
- * 2 = 8-wave workgroups, anything else = 4-wave workgroups. */
+ * 1 = separate attention / row launches with 4-wave workgroups, 2 = the same with 8-wave workgroups,
+ * 3 = fused launches (T > 32), 0 = fused up to ~4 workgroups per CU, separate beyond. */
 int savad_set_row_mode(savad_handle h, int mode);
 /* Fills the names/durations of the kernels of the most recent savad_forward when profiling is
  * enabled with savad_set_profiling(h, 1): the forward then brackets every launch with hipEvents on

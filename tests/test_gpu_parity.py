@@ -470,18 +470,26 @@ def test_bf16_permutation_and_determinism(torch_cuda, model):
     assert np.array_equal(run_bf16(torch_cuda, model, x), y)
 
 
-@pytest.mark.parametrize("shape", [(3, 800, 80), (2, 801, 80), (5, 16, 80), (9, 96, 80), (1, 1, 80)])
-def test_bf16_wide_workgroups_identical(torch_cuda, model, shape):
-    """row_mode 2 = the 8-wave / 4-deep-ring variant of the bf16 kernels: the same arithmetic per data row
-    in a different workgroup shape, so the log-probs must be bit-identical to the default 4-wave variant."""
+@pytest.mark.parametrize("shape", [(3, 800, 80), (2, 801, 80), (5, 16, 80), (9, 96, 80), (1, 1, 80), (11, 33, 80)])
+def test_bf16_launch_shapes_identical(torch_cuda, model, shape):
+    """bf16 row_mode 1 = separate attention / row launches (4-wave workgroups), 2 = the same with 8-wave workgroups
+    and a 4-deep ring, 3 = attention + row chain fused per layer (q/k/v^T double-buffered).  The arithmetic per data
+    row is the same in all of them, so the log-probs must be bit-identical -- also on a workspace full of NaNs
+    (nothing may depend on blocks a launch shape never writes)."""
+    torch = torch_cuda
     x = feats(sum(shape) + 1, shape)
-    y4 = run_bf16(torch_cuda, model, x)
-    model.row_mode = 2
-    try:
-        y8 = run_bf16(torch_cuda, model, x)
-    finally:
-        model.row_mode = 0
-    assert np.isfinite(y8).all() and np.array_equal(y4, y8)
+    ys = {}
+    for mode in (1, 2, 3, 0):
+        model.row_mode = mode
+        try:
+            ys[mode] = run_bf16(torch, model, x)
+            if model._workspace is not None:
+                model._workspace.fill_(255)  # 0xFFFF... = NaN in fp32, fp16 and bf16
+            again = run_bf16(torch, model, x)
+        finally:
+            model.row_mode = 0
+        assert np.isfinite(ys[mode]).all() and np.array_equal(again, ys[mode]), mode
+    assert np.array_equal(ys[1], ys[2]) and np.array_equal(ys[1], ys[3]) and np.array_equal(ys[1], ys[0])
 
 
 # ---- log-mel front-end (next-row 1; parity UNPINNED: librosa is absent, the oracle restates its defaults) ----

@@ -283,7 +283,8 @@ int prepare_frags(savad_model* m, hipStream_t st) {
 // block space of the bf16 path (savad_kernels_bf16.h)
 struct BlockPlan {
     int nblk, nblk_pad;
-    size_t h, q, k, vt, ctx, xpad, total;  // byte offsets
+    bool fused;  // attention + row chain in one launch per layer (q/k/v^T double-buffered: q2, k2, vt2)
+    size_t h, q, k, vt, q2, k2, vt2, ctx, xpad, total;  // byte offsets
 };
 BlockPlan plan_blocks(const savad_model* m, int B, int T) {
     BlockPlan p;
@@ -304,6 +305,22 @@ BlockPlan plan_blocks(const savad_model* m, int B, int T) {
     off += fb;
     p.ctx = off;
     off += fb;
+    // row_mode 1 / 2 keep attention and row chain as separate launches (4- / 8-wave workgroups), 3 fuses them.
+    // Automatic: fused up to ~4 workgroups per CU.  Measured on MI355X at T=800 (fused vs separate, ms per
+    // forward): B=32 0.128 / 0.142, B=64 0.197 / 0.204, B=128 0.355 / 0.370, B=192 0.509 / 0.501, B=256 0.642 /
+    // 0.641 -- with more work per CU the wave slots a ragged query-block group leaves idle (3 of 28 at T=800) cost
+    // the row chain as much as the context round trip and the extra launches cost the separate form.
+    const long groups = T > 32 ? (long)B * (((T + 31) / 32 + 3) / 4) : 0;
+    p.fused = T > 32 && (m->row_mode == 3 || (m->row_mode == 0 && groups <= 1024));
+    p.q2 = p.k2 = p.vt2 = off;
+    if (p.fused) {
+        p.q2 = off;
+        off += fb;
+        p.k2 = off;
+        off += fb;
+        p.vt2 = off;
+        off += fb;
+    }
     p.xpad = off;
     if (m->FP != m->cfg.feature_size) off += (size_t)B * T * m->FP * sizeof(float);
     p.total = off;
@@ -526,6 +543,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     // 4-wave workgroups (two per CU, 2-slot ring) by default.  row_mode 2 selects the 8-wave variant with a
     // 4-deep ring (half the DMA stream per data row, one workgroup per CU): measured SLOWER on MI355X at
     // every size tried (B=256, T=800: 0.86 vs 0.75 ms), kept as a tuning knob and covered by the tests.
+    // row_mode 0 / 3 fuse attention and row chain per layer when T > 32 (plan_blocks); 1 / 2 keep them apart.
     const bool wide = m->row_mode == 2;
     if (!m->lds_attrs_set) {
         constexpr int r4 = bf::Ring<4>::NRING * bf::RING_BYTES, r8 = bf::Ring<8>::NRING * bf::RING_BYTES;
@@ -534,6 +552,8 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
         if ((rc = allow_lds(bf::attention_kernel_bf16<4>, r4))) return rc;
         if ((rc = allow_lds(bf::row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
         if ((rc = allow_lds(bf::row_kernel_bf16<true, 4>, r4 + 9 * D * 4))) return rc;
+        if ((rc = allow_lds(bf::attention_row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
+        if ((rc = allow_lds(bf::attention_row_kernel_bf16<true, 4>, r4 + 9 * D * 4))) return rc;
         if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float, 8>, r8 + 3 * D * 4))) return rc;
         if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16, 8>, r8 + 3 * D * 4))) return rc;
         if ((rc = allow_lds(bf::attention_kernel_bf16<8>, r8))) return rc;
@@ -556,7 +576,43 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
                                T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf,
                                kf, vtf, c);
         prof.mark("input_qkv_bf16");
+        char* sets[2][3] = {{qf, kf, vtf}, {W + bp.q2, W + bp.k2, W + bp.vt2}};
         for (int l = 0; l < L; ++l) {
+            const auto& r = m->lr[l];
+            const auto& p = m->lp[l];
+            const auto& f = m->lf[l];
+            const bool last = l + 1 == L;
+            char** cur = bp.fused ? sets[l & 1] : sets[0];
+            char** nxt = bp.fused ? sets[(l + 1) & 1] : sets[0];
+            bf::RowArgsBf16 A;
+            A.B = B;
+            A.T = T;
+            A.nblk = bp.nblk;
+            A.hbuf = hb;
+            A.wo_frag = Fr + f.wo;
+            A.bo = R + r.bo;
+            A.w1_frag = Fr + f.w1;
+            A.b1 = P + p.b1;
+            A.w2_frag = Fr + f.w2;
+            A.b2 = R + r.b2;
+            A.wn_frag = last ? nullptr : Fr + m->lf[l + 1].wqkv;
+            A.wc = last ? P + m->p_wc : nullptr;
+            A.bn = last ? P + m->p_bc : P + m->lp[l + 1].bqkv;
+            A.qf = nxt[0];
+            A.kf = nxt[1];
+            A.vtf = nxt[2];
+            A.out = out;
+            A.qscale = c;
+            if (bp.fused) {
+                const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
+                const dim3 grid(8 * ((B + 7) / 8) * NG);
+                if (last)
+                    hipLaunchKernelGGL((bf::attention_row_kernel_bf16<true, NW>), grid, wg, ring + 9 * D * 4, st, cur[0], cur[1], cur[2], NG, A);
+                else
+                    hipLaunchKernelGGL((bf::attention_row_kernel_bf16<false, NW>), grid, wg, ring + 9 * D * 4, st, cur[0], cur[1], cur[2], NG, A);
+                prof.mark(last ? "attention_row_last_bf16" : "attention_row_bf16");
+                continue;
+            }
             if (T <= 32) {
                 hipLaunchKernelGGL(bf::attention_packed_kernel_bf16, dim3((bp.nblk + 3) / 4), dim3(256), 0, st, qf, kf, vtf, ctxf,
                                    B, T, bp.nblk);
@@ -566,20 +622,11 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
                                    T, NG);
             }
             prof.mark("attention_bf16");
-            const auto& r = m->lr[l];
-            const auto& p = m->lp[l];
-            const auto& f = m->lf[l];
-            if (l + 1 < L) {
-                hipLaunchKernelGGL((bf::row_kernel_bf16<false, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, B, T, bp.nblk,
-                                   hb, Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, Fr + m->lf[l + 1].wqkv,
-                                   (const float*)nullptr, P + m->lp[l + 1].bqkv, qf, kf, vtf, out, c);
-                prof.mark("row_bf16");
-            } else {
-                hipLaunchKernelGGL((bf::row_kernel_bf16<true, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, B, T, bp.nblk,
-                                   hb, Fr + f.wo, R + r.bo, Fr + f.w1, P + p.b1, Fr + f.w2, R + r.b2, (const char*)nullptr,
-                                   P + m->p_wc, P + m->p_bc, qf, kf, vtf, out, c);
-                prof.mark("row_last_bf16");
-            }
+            if (last)
+                hipLaunchKernelGGL((bf::row_kernel_bf16<true, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, A);
+            else
+                hipLaunchKernelGGL((bf::row_kernel_bf16<false, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, A);
+            prof.mark(last ? "row_last_bf16" : "row_bf16");
         }
     };
     if (wide)

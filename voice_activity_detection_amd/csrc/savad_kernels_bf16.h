@@ -122,7 +122,10 @@ struct Ring {
     template <class SegSrc>
     __device__ __forceinline__ void issue(int t, SegSrc seg_src) const {
         if (SAVAD_ABLATE & 1) return;
-        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)slot(t));
+        // LDS byte address = low 32 bits of the flat address (the LDS aperture is 4 GiB aligned).  An explicit
+        // generic -> address_space(3) cast adds a null check that hipcc 7.2 mis-selects in one instantiation
+        // ("V_CMP_NE_U32 0, $src_shared_base: operand has incorrect register class").
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot(t));
         const unsigned off = (unsigned)lane * 16u;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -178,7 +181,7 @@ __device__ __forceinline__ void gemm_ring_swapped(f32x16 (&acc)[4], const char* 
 // the base-2 exponent domain and spends no VALU instruction on scaling them.
 __device__ __forceinline__ void qkv_block_bf16(int rb, const char* ringblk, const bf16x8 (&xp)[8], const float* lbq,
                                                char* __restrict__ qf, char* __restrict__ kf, char* __restrict__ vtf,
-                                               int blk, int lane, float qscale) {
+                                               int blk, int lane, float qscale, bool live = true /* wave-uniform: store */) {
     const int n = lane & 31, h = lane >> 5;
     f32x16 acc[4];
     if (rb < 2) {
@@ -199,6 +202,7 @@ __device__ __forceinline__ void qkv_block_bf16(int rb, const char* ringblk, cons
 #pragma unroll
         for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] *= qscale;
     }
+    if (!live) return;
 #pragma unroll
     for (int nbl = 0; nbl < 4; ++nbl)
 #pragma unroll
@@ -468,33 +472,47 @@ __global__ __launch_bounds__(256, 2) void attention_packed_kernel_bf16(const cha
 // ReLU output repacked in registers) + residual -> next layer's LN + Q/K/V^T, or the classifier.
 // Weight stream = ring blocks  0: Wo | 1+2c: W1 chunk c | 2+2c: W2 chunk c (c = 0..3) | 9,10,11: Wq, Wk, Wv.
 // ---------------------------------------------------------------------------------------------
+struct RowArgsBf16 {
+    int B, T, nblk;
+    hres_t* hbuf;
+    const char* wo_frag;
+    const float* bo;
+    const char* w1_frag;
+    const float* b1;
+    const char* w2_frag;
+    const float* b2;
+    const char* wn_frag;  // !LAST: next layer's Wqkv' fragments
+    const float* wc;      // LAST: Wc' fp32 [2][D]
+    const float* bn;      // !LAST: bqkv' [384]; LAST: bc' [2]
+    char *qf, *kf, *vtf;  // !LAST: written (the NEXT layer's buffers)
+    float* out;           // LAST
+    float qscale;
+};
+
+// The whole row chain of block `blk` for one wave.  In: xp = the block's attention context as B-operand fragments.
+// `smem` = the workgroup's ring (NRING x 32 KiB) followed by 9*D floats of biases; nothing of it may still be in use
+// by other waves when this is entered (the first ring barrier inside publishes ring block 0 and the biases).
+// live (wave-uniform) = this wave's block exists: a wave without a block still issues its share of the DMA and takes
+// part in every barrier, but stores nothing.
 template <bool LAST, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(
-    const char* __restrict__ ctxf, int B, int T, int nblk, hres_t* __restrict__ hbuf, const char* __restrict__ wo_frag,
-    const float* __restrict__ bo, const char* __restrict__ w1_frag, const float* __restrict__ b1,
-    const char* __restrict__ w2_frag, const float* __restrict__ b2, const char* __restrict__ wn_frag /* !LAST: Wqkv' */,
-    const float* __restrict__ wc /* LAST: Wc' fp32 [2][D] */, const float* __restrict__ bn, char* __restrict__ qf,
-    char* __restrict__ kf, char* __restrict__ vtf, float* __restrict__ out, float qscale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem, bf16x8 (&xp)[8], int blk, bool live, int lane, int w) {
     using R = Ring<NW>;
     float* lbo = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
     float* lb1 = lbo + D;
     float* lb2 = lb1 + DFF;
     float* lbn = lb2 + D;
-    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = blockIdx.x * NW + w;
+    const int m = lane & 31, h = lane >> 5;
     const R ring{smem, w, lane};
     constexpr int NBLK = LAST ? 9 : 12;
     auto issue = [&](int t) {
         ring.issue(t, [&](int sgm) -> const char* {
-            if (t == 0) return wo_frag + sgm * BLK_BYTES;
+            if (t == 0) return A.wo_frag + sgm * BLK_BYTES;
             if (t < 9) {
                 const int c = (t - 1) >> 1;
-                return ((t - 1) & 1) ? w2_frag + (size_t)(sgm * 32 + 8 * c) * FRAG_BYTES  // output block sgm, K-steps 8c..8c+7
-                                     : w1_frag + (size_t)c * RING_BYTES + sgm * BLK_BYTES;
+                return ((t - 1) & 1) ? A.w2_frag + (size_t)(sgm * 32 + 8 * c) * FRAG_BYTES  // output block sgm, K-steps 8c..8c+7
+                                     : A.w1_frag + (size_t)c * RING_BYTES + sgm * BLK_BYTES;
             }
-            return wn_frag + (size_t)(t - 9) * RING_BYTES + sgm * BLK_BYTES;
+            return A.wn_frag + (size_t)(t - 9) * RING_BYTES + sgm * BLK_BYTES;
         });
     };
     // acquire block t (wave-uniform t), then keep the DMA DEPTH blocks ahead
@@ -504,21 +522,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(
     };
 #pragma unroll
     for (int t = 0; t < R::DEPTH; ++t) issue(t);
-    stage_bias(lbo, bo, D);
-    stage_bias(lb1, b1, DFF);
-    stage_bias(lb2, b2, D);
-    if (!LAST) stage_bias(lbn, bn, 3 * D);
-    hres_t* hb = hbuf + (size_t)blk * HBLK_FLOATS;
+    stage_bias(lbo, A.bo, D);
+    stage_bias(lb1, A.b1, DFF);
+    stage_bias(lb2, A.b2, D);
+    if (!LAST) stage_bias(lbn, A.bn, 3 * D);
+    hres_t* hb = A.hbuf + (size_t)blk * HBLK_FLOATS;
     f32x16 h1[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) h1[nb] = zero16();
     load_hblock(h1, hb, lane);
-    bf16x8 xp[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        xp[ks] = ldfrag(ctxf + ((size_t)blk * 8 + ks) * FRAG_BYTES + lane * 16);
-        if (blk >= nblk) xp[ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});  // pad blocks: attention never wrote them
-    }
     // ---- h1 = h + bo + ctx Wo^T
     advance(0);
 #pragma unroll
@@ -549,35 +561,132 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(
         advance(2 + 2 * ch);  // W2 chunk
         gemm_ring(o, ring.slot(2 + 2 * ch), ap, lane);
     }
-    if (!LAST) store_hblock(hb, o, lane);
+    if (!LAST && live) store_hblock(hb, o, lane);
     layernorm_regs(o, xg);
     if (!LAST) {
         pack_row(xg, xp);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
             advance(9 + rb);
-            qkv_block_bf16(rb, ring.slot(9 + rb), xp, lbn, qf, kf, vtf, blk, lane, qscale);
+            qkv_block_bf16(rb, ring.slot(9 + rb), xp, lbn, A.qf, A.kf, A.vtf, blk, lane, A.qscale, live);
         }
     } else {
         float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
         for (int G = 0; G < 16; ++G) {
-            const f32x4 c0 = ld4(wc + 8 * G + 4 * h), c1 = ld4(wc + D + 8 * G + 4 * h);
+            const f32x4 c0 = ld4(A.wc + 8 * G + 4 * h), c1 = ld4(A.wc + D + 8 * G + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 z0 = __builtin_fmaf(xg[G][e], c0[e], z0);
                 z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
             }
         }
-        z0 = half_sum(z0) + bn[0];
-        z1 = half_sum(z1) + bn[1];
+        z0 = half_sum(z0) + A.bn[0];
+        z1 = half_sum(z1) + A.bn[1];
         const float mx = fmaxf(z0, z1);
         const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
         size_t row;
         int t_frame;
-        const bool valid = (blk < nblk) && slot_row(B, T, blk, m, row, t_frame);
-        if (h == 0 && valid) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+        const bool valid = live && (blk < A.nblk) && slot_row(A.B, A.T, blk, m, row, t_frame);
+        if (h == 0 && valid) *reinterpret_cast<f32x2*>(A.out + row * 2) = f32x2{z0 - lse, z1 - lse};
     }
+}
+
+template <bool LAST, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(const char* __restrict__ ctxf, RowArgsBf16 A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * NW + w;
+    bf16x8 xp[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        xp[ks] = ldfrag(ctxf + ((size_t)blk * 8 + ks) * FRAG_BYTES + lane * 16);
+        if (blk >= A.nblk) xp[ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});  // pad blocks: attention never wrote them
+    }
+    row_stage_bf16<LAST, NW>(A, smem, xp, blk, true, lane, w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused stage (bf16; T > 32): attention of one (sequence, group of <= NW query blocks) immediately followed by the
+// row chain of those blocks in the same workgroup.  The normalised context is repacked into B-operand fragments in
+// registers (what store_ctx used to write and the row kernel to read back: 2 x 52 MB per layer at B=256), the K/V
+// ring becomes the weight ring, and the HBM-heavy row phase of one workgroup overlaps the LDS/MFMA-heavy attention
+// phase of its co-resident partner.  q/k/v^T are double-buffered between layers (read qf,kf,vtf -- write A.qf,A.kf,
+// A.vtf): a workgroup writes the next layer's K/V blocks while others still read this layer's.
+// ---------------------------------------------------------------------------------------------
+template <bool LAST, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_row_kernel_bf16(const char* __restrict__ qf, const char* __restrict__ kf,
+                                                                                      const char* __restrict__ vtf, int NG, RowArgsBf16 A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using R = Ring<NW>;
+    const int B = A.B, T = A.T;
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int QB = (T + 31) / 32;
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int b = (i / NG) * 8 + xcd;
+    if (b >= B) return;
+    const int g = i % NG;
+    const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;
+    const int qb = qb0 + w;
+    const bool active = qb < qb1;
+    const int blk_q = b * QB + (active ? qb : qb0);
+    const int NST = (QB + 1) / 2;
+    const R ring{smem, w, lane};
+
+    bf16x8 qp[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qp[ks] = ldfrag(qf + ((size_t)blk_q * 8 + ks) * FRAG_BYTES + lane * 16);
+    AttnState st;
+    attn_state_init(st);
+    auto issue = [&](int stage) {
+        const size_t kb0 = (size_t)b * QB + 2 * stage;
+        ring.issue(stage, [&](int sgm) { return (sgm < 2 ? kf : vtf) + (kb0 + (sgm & 1)) * BLK_BYTES; });
+    };
+    for (int s0 = 0; s0 < R::DEPTH && s0 < NST; ++s0) issue(s0);
+    for (int stg = 0; stg < NST; ++stg) {
+        const int newer = NST - 1 - stg < R::DEPTH - 1 ? NST - 1 - stg : R::DEPTH - 1;
+        ring.acquire(newer);
+        if (stg + R::DEPTH < NST) issue(stg + R::DEPTH);
+        if (!active) continue;
+        const char* buf = ring.slot(stg);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int jt = 2 * stg + tt;
+            if (jt >= QB) break;
+            auto mask = [&](f32x16& sc) {  // a REAL branch: see attention_kernel_bf16
+                if (32 * jt + 32 > T) {
+                    asm volatile("" ::: "memory");
+                    const int lim = T - 32 * jt - 4 * h;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = (8 * (r >> 2) + (r & 3) < lim) ? sc[r] : NEG_BIG;
+                }
+            };
+            attn_tile(st, qp, buf + tt * BLK_BYTES, buf + (2 + tt) * BLK_BYTES, mask, jt == 0, lane);
+        }
+    }
+    // context -> B-operand fragments, in registers (invalid slots and waves without a block: exact zeros)
+    bf16x8 xp[8];
+    {
+        const bool qvalid = active && 32 * qb + (lane & 31) < T;
+        const float inv = qvalid ? 1.0f / st.l_run : 0.0f;
+#pragma unroll
+        for (int nbd = 0; nbd < 4; ++nbd) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.O[nbd][r] = qvalid ? st.O[nbd][r] * inv : 0.0f;
+            xp[2 * nbd] = pack_half(st.O[nbd], 0);
+            xp[2 * nbd + 1] = pack_half(st.O[nbd], 1);
+        }
+    }
+    // A key stage of two blocks may over-read ONE V^T block behind the batch in the next layer: never written by
+    // this kernel, and probability 0 times a non-finite value would poison the context.
+    if (!LAST && b == B - 1 && g == NG - 1 && w == 0) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) stfrag(A.vtf + ((size_t)B * QB * 8 + f) * FRAG_BYTES + lane * 16, __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u}));
+    }
+    __syncthreads();  // everyone is done with the K/V ring: it becomes the weight ring
+    row_stage_bf16<LAST, NW>(A, smem, xp, blk_q, active, lane, w);
 }
 
 // ---------------------------------------------------------------------------------------------
