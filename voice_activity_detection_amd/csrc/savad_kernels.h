@@ -553,6 +553,49 @@ __device__ __forceinline__ void wmma_w2(f32x16 (&o)[4], const WBlock& wb, const 
             for (int e = 0; e < 4; ++e) o[nb] = SAVAD_MFMA(wb.v[4 * nb + g][e], a[4 * g + e], o[nb]);
 }
 
+// ctx = sum_s w_s O_s / sum_s w_s l_s over the S key-split partials of the lane's row (lane-local scalars).
+// Pad rows (row >= rows) were never written by the attention stage: they get ctx = 0 so that the whole pipeline
+// stays finite (their V rows are multiplied by probability 0 downstream).  S == 1 (no key split: every packed
+// T <= 32 launch and every large batch) needs no weights, hence ONE memory round trip instead of two.
+__device__ __forceinline__ void combine_splits(f32x4 (&xg)[16], const float* __restrict__ Opart, const float* __restrict__ ml,
+                                               int S, size_t row, int rows, int rows_pad, float c, int h) {
+    const bool valid = row < (size_t)rows;
+    if (S == 1) {
+        const float l = ml[row * 2 + 1];
+        const float* op = Opart + row * D + 4 * h;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) xg[G] = ld4(op + 8 * G);
+        const float inv = valid ? 1.0f / l : 0.0f;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) xg[G] = valid ? xg[G] * inv : f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    float M = NEG_BIG;
+    for (int s = 0; s < S; ++s) {
+        const float ms = ml[((size_t)s * rows_pad + row) * 2];
+        M = fmaxf(M, valid ? ms : 0.0f);
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int G = 0; G < 16; ++G) xg[G] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        f32x2 t = *reinterpret_cast<const f32x2*>(ml + ((size_t)s * rows_pad + row) * 2);
+        if (!valid) t = f32x2{0.0f, 1.0f};
+        const float ws = __builtin_amdgcn_exp2f((t[0] - M) * c);
+        den += ws * t[1];
+        const float* op = Opart + ((size_t)s * rows_pad + row) * D + 4 * h;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            f32x4 o4 = ld4(op + 8 * G);
+            if (!valid) o4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            xg[G] += ws * o4;
+        }
+    }
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int G = 0; G < 16; ++G) xg[G] *= inv;
+}
+
 template <bool LAST>
 __global__ __launch_bounds__(256, 1) void row_kernel(
     const float* __restrict__ Opart, const float* __restrict__ ml, int S, int rows, int rows_pad, float c,
@@ -571,51 +614,26 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t row = (size_t)blockIdx.x * TILE + m;
 
+    SAVAD_STAMP(32);
     WBlock wa, wb;
     stage_bias(lb1, b1, DFF);
     stage_bias(lb2, b2, D);
     if (!LAST) stage_bias(lbn, bn, 3 * D);
     wload_k128(wa, Wo + (size_t)(32 * w + n) * D + 4 * h);  // requested before the partials: consumed after phase 0
-    // ---- phase 0: ctx = sum_s w_s O_s / sum_s w_s l_s   (rows are lane-local: all scalars per lane)
-    // Pad rows (row >= rows) were never written by the attention stage: give them ctx = 0 so the
-    // whole pipeline stays finite (their V rows are multiplied by probability 0 downstream).
+    f32x16 h1 = zero16();  // the out-projection accumulator starts at the residual stream (requested now, consumed after phase 0)
+    add_block(h1, hbuf + row * D + 32 * w, h);
+    // ---- phase 0: ctx = combination of the key-split partials (rows are lane-local: all scalars per lane)
     f32x4 xg[16];
-    {
-        const bool valid = row < (size_t)rows;
-        float M = NEG_BIG;
-        for (int s = 0; s < S; ++s) {
-            const float ms = ml[((size_t)s * rows_pad + row) * 2];
-            M = fmaxf(M, valid ? ms : 0.0f);
-        }
-        float den = 0.0f;
-#pragma unroll
-        for (int G = 0; G < 16; ++G) xg[G] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < S; ++s) {
-            f32x2 t = *reinterpret_cast<const f32x2*>(ml + ((size_t)s * rows_pad + row) * 2);
-            if (!valid) t = f32x2{0.0f, 1.0f};
-            const float ws = __builtin_amdgcn_exp2f((t[0] - M) * c);
-            den += ws * t[1];
-            const float* op = Opart + ((size_t)s * rows_pad + row) * D + 4 * h;
-#pragma unroll
-            for (int G = 0; G < 16; ++G) {
-                f32x4 o4 = ld4(op + 8 * G);
-                if (!valid) o4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                xg[G] += ws * o4;
-            }
-        }
-        const float inv = 1.0f / den;
-#pragma unroll
-        for (int G = 0; G < 16; ++G) xg[G] *= inv;
-    }
+    combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
+    SAVAD_STAMP(33);
     // ---- phase 1: h1 = ctx Wo^T + bo + h   (wave's 32 features)
-    f32x16 h1 = zero16();
     wload_k128(wb, W1 + (size_t)(128 * w + n) * D + 4 * h);  // first FFN block
     wmma_k128(h1, wa, xg);
     add_bias(h1, bo + 32 * w, h);
-    add_block(h1, hbuf + row * D + 32 * w, h);
     store_block(xbuf + m * XLD + 32 * w, h1, h);
     __syncthreads();
     read_rows_layernorm(xbuf, m, h, xg);
+    SAVAD_STAMP(34);
     // ---- phase 2: FFN, hidden units [128w, 128w+128) in 4 chunks of 32; ReLU output feeds the
     //      second GEMM as B operand straight from the accumulator registers
     f32x16 o[4];
@@ -635,6 +653,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
             wload_k128(wb, Wn + (size_t)(32 * w + n) * D + 4 * h);  // query block of the next layer
         wmma_w2(o, wa, a);
     }
+    SAVAD_STAMP(35);
     // reduce-scatter the 4 K-split partials: wave w ends up with feature block w
     f32x16 own = o[0];
 #pragma unroll
@@ -652,10 +671,12 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     own += bias_block(lb2 + 32 * w, h);
     own += h1;  // residual onto the un-normalised stream (transformer.py:235-237)
     if (!LAST) store_block(hbuf + row * D + 32 * w, own, h);
+    SAVAD_STAMP(36);
     // ---- phase 3
     store_block(xbuf + m * XLD + 32 * w, own, h);  // xbuf's last readers all passed the barrier above
     __syncthreads();
     read_rows_layernorm(xbuf, m, h, xg);
+    SAVAD_STAMP(37);
     if (!LAST) {
         // Q (already in wb), K, V blocks of this wave's 32 features, each prefetched one block ahead
         float* dst[3] = {q, k, v};
@@ -687,6 +708,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
         const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
         if (h == 0 && row < (size_t)rows) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
     }
+    SAVAD_STAMP(38);
 }
 
 // =============================================================================================
@@ -935,33 +957,7 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
     }
     // ---- combine the attention splits: ctx = sum_s w_s O_s / sum_s w_s l_s (lane-local)
     f32x4 xg[16];
-    {
-        const bool valid = row < (size_t)rows;
-        float M = NEG_BIG;
-        for (int s = 0; s < S; ++s) {
-            const float ms = ml[((size_t)s * rows_pad + row) * 2];
-            M = fmaxf(M, valid ? ms : 0.0f);
-        }
-        float den = 0.0f;
-#pragma unroll
-        for (int G = 0; G < 16; ++G) xg[G] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < S; ++s) {
-            f32x2 t = *reinterpret_cast<const f32x2*>(ml + ((size_t)s * rows_pad + row) * 2);
-            if (!valid) t = f32x2{0.0f, 1.0f};
-            const float ws = __builtin_amdgcn_exp2f((t[0] - M) * c);
-            den += ws * t[1];
-            const float* op = Opart + ((size_t)s * rows_pad + row) * D + 4 * h;
-#pragma unroll
-            for (int G = 0; G < 16; ++G) {
-                f32x4 o4 = ld4(op + 8 * G);
-                if (!valid) o4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                xg[G] += ws * o4;
-            }
-        }
-        const float inv = 1.0f / den;
-#pragma unroll
-        for (int G = 0; G < 16; ++G) xg[G] *= inv;
-    }
+    combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
     row_chain_m<LAST>(xg, h1, row, true, row < (size_t)rows, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, q, k, v, out,
                       w, n, h);
 }
