@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[4]: 1 h of synthetic audio (360 001 log-mel frames @100 fps) through the
 streaming long-form mode (T=800, hop=400 -> 900 windows), device-resident features -> per-frame
-probabilities.  Reports the real-time factor WITHOUT the log-mel front-end (which is outside this
-build).  Multi-GPU: launch with torch.distributed.run (windows sharded, one all_gather)."""
+probabilities.  Reports the real-time factor with and without the GPU log-mel front-end.
+Usage: bench_stream.py [max_batch=256] [fp32|bf16].  Multi-GPU: launch with torch.distributed.run."""
 import json
 import os
 import sys
@@ -26,6 +26,7 @@ if world > 1:
 m = SelfAttentiveVAD(80, 3, 128, 0.5)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()})
 m = m.cuda().eval()
+m.precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 from voice_activity_detection_amd.features import log_mel  # noqa: E402
 
 N = 3600 * 100 + 1
@@ -50,7 +51,7 @@ for _ in range(reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 if rank == 0:
-    print(json.dumps({"mode": "streaming T=800 hop=400", "audio_seconds": 3600, "frames": N, "windows": 900,
+    print(json.dumps({"mode": "streaming T=800 hop=400", "precision": m.precision, "audio_seconds": 3600, "frames": N, "windows": 900,
                       "n_gpus": world, "seconds": round(dt, 5), "rtf_without_logmel": dt / 3600.0,
                       "logmel_seconds": round(dt_mel, 5), "rtf_with_logmel": (dt + dt_mel) / 3600.0,
                       "frames_per_s_of_audio": N / dt, "finite": bool(torch.isfinite(p).all().item())}))
