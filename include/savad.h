@@ -78,7 +78,7 @@ int savad_forward(savad_handle h, const float* x, int B, int T, float* out, void
 
 /* Arithmetic of the forward pass: 0 = fp32 operands on the exact-fp32 MFMA (default; log-probs within
  * 1e-4 of the reference), 1 = bf16 operands (weights, Q/K/V, probabilities, FFN activations) with fp32
- * accumulation, fp32 softmax / LayerNorm statistics and an fp32 residual stream (BASELINE.json
+ * accumulation, fp32 softmax / LayerNorm statistics, residual stream fp32 in registers / fp16 in memory (BASELINE.json
  * configs[2..3]; judged on AUC, not on 1e-4). */
 int savad_set_precision(savad_handle h, int precision);
 /* savad_forward with an explicit feature dtype: x_dtype 0 = fp32 [B,T,F], 1 = bf16 [B,T,F] (bf16

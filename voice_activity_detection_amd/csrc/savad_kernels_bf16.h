@@ -1,6 +1,6 @@
 // savad_kernels_bf16.h -- bf16-operand variant of the forward pass (BASELINE.json configs[2..3]:
-// bf16 weights / activations, fp32 accumulation, fp32 softmax and LayerNorm statistics, fp32
-// residual stream).  Same row-layout idea as savad_kernels.h, on v_mfma_f32_32x32x16_bf16
+// bf16 weights / activations, fp32 accumulation, fp32 softmax and LayerNorm statistics, residual
+// stream fp32 in registers and fp16 in HBM).  Same row-layout idea as savad_kernels.h, on v_mfma_f32_32x32x16_bf16
 // (32 cycles, 32768 FLOP: 16x the fp32 MFMA rate), with everything the kernels exchange stored in
 // FRAGMENT-MAJOR order so that every load / store / DMA is a contiguous 1 KiB wave access:
 //
@@ -13,7 +13,7 @@
 //   q, k, ctx : [block][ks 8][lane 64][8 bf16]      (B / A operand fragments, 8 KiB per block)
 //   vt        : [block][nbd 4][j 2][lane 64][8 bf16] (V^T fragments: lane = feature, 8 keys; obtained
 //               for free by issuing the V projection with the MFMA operands swapped)
-//   h         : [block][nb 4][g 4][lane 64][4 f32]   (residual stream, fp32)
+//   h         : [block][nb 4][gp 2][lane 64][8 f16]  (residual stream as stored between kernels)
 //   weights   : [n-block][ks][lane 64][8 bf16], packed once by pack_weight_frags_kernel
 #pragma once
 #include "savad_kernels.h"
@@ -29,7 +29,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int FRAG_BYTES = 1024;             // one K-step fragment of 32 rows: 64 lanes x 16 B
 constexpr int BLK_BYTES = 8 * FRAG_BYTES;    // 32 rows x 128 features in bf16
 constexpr int RING_BYTES = 4 * BLK_BYTES;    // one ring block = 128 output features x 128 k = 32 KiB
-constexpr int HBLK_FLOATS = 32 * D;          // fp32 residual block
+constexpr int HBLK_FLOATS = 32 * D;          // elements of one residual block
 
 __device__ __forceinline__ bf16x8 ldfrag(const void* p) {
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
