@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU box): random (B, T, mode, splits, precision) against the C oracle."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, seeded_features
+from oracle import oracle
+
+st = seeded_state_dict(1234)
+m = SelfAttentiveVAD(80, 3, 128, 0.5)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+m = m.cuda().eval()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+worst = {"fp32": 0.0, "bf16": 0.0}
+for it in range(n):
+    T = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 40, 63, 64, 65, 96, 127, 128, 129, 200, 257, 400, 513, 800, 801, 1000]))
+    maxB = max(1, min(48, 40000 // T))
+    B = int(rng.integers(1, maxB + 1))
+    prec = "bf16" if rng.random() < 0.35 else "fp32"
+    mode = int(rng.integers(0, 4))
+    splits = int(rng.choice([0, 0, 1, 1, 2, 3, 5]))
+    x = seeded_features(int(rng.integers(1 << 30)), (B, T, 80))
+    m.precision, m.row_mode, m.attention_splits = prec, mode, splits
+    with torch.no_grad():
+        y = m(features=torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = oracle.forward(st, x, threads=32)
+    err = float(np.abs(y - ref).max())
+    tol = 2e-2 if prec == "bf16" else 3e-5
+    worst[prec] = max(worst[prec], err)
+    flag = "" if (np.isfinite(y).all() and err < tol) else "   <<<<<< FAIL"
+    print(f"B={B:3d} T={T:4d} {prec} row_mode={mode} splits={splits}: max|dlogp|={err:.2e}{flag}", flush=True)
+    if flag:
+        sys.exit(1)
+print("worst", worst)
