@@ -154,7 +154,13 @@ Workspace plan(const savad_model* m, int B, int T) {
     w.msplit = m->row_mode >= 2 || (m->row_mode == 0 && w.rows_pad / 128 >= 192);
     // In the M-split regime without key splits the attention stage and the row chain of a query-block group
     // run back to back in one workgroup (attention_row_kernel).  row_mode 2 keeps them as separate launches.
-    w.fused = w.msplit && T > 32 && w.S == 1 && m->row_mode != 2;
+    // Automatic: only when a query-block group keeps at least 80 % of its 4 wave slots busy -- waves without a
+    // query block sit out the whole row chain (measured: T=50, two blocks per group, B=512: 0.63 ms fused against
+    // 0.42 ms separate; T=200 (7 blocks in 2 groups) 0.434 / 0.453; T=400 (13 in 4) 0.508 / 0.524; T=800 (25 in
+    // 7) 0.640 / 0.668).
+    const int QBp = (T + 31) / 32, NGp = (QBp + 3) / 4;
+    const bool ragged = QBp * 5 < NGp * 4 * 4;  // QB / (4 NG) < 0.8
+    w.fused = w.msplit && T > 32 && w.S == 1 && (m->row_mode == 3 || (m->row_mode != 2 && !ragged));
     size_t off = 0;
     w.h = off;
     off += w.rows_pad * D;
@@ -310,8 +316,12 @@ BlockPlan plan_blocks(const savad_model* m, int B, int T) {
     // forward): B=32 0.128 / 0.142, B=64 0.197 / 0.204, B=128 0.355 / 0.370, B=192 0.509 / 0.501, B=256 0.642 /
     // 0.641 -- with more work per CU the wave slots a ragged query-block group leaves idle (3 of 28 at T=800) cost
     // the row chain as much as the context round trip and the extra launches cost the separate form.
-    const long groups = T > 32 ? (long)B * (((T + 31) / 32 + 3) / 4) : 0;
-    p.fused = T > 32 && (m->row_mode == 3 || (m->row_mode == 0 && groups <= 1024));
+    const int QBp = (T + 31) / 32, NGp = (QBp + 3) / 4;
+    const long groups = T > 32 ? (long)B * NGp : 0;
+    const bool ragged = QBp * 5 < NGp * 4 * 4;  // fewer than 80 % of a group's wave slots hold a query block
+    // (below one workgroup per CU the forward is launch / latency bound and fusing wins even with idle slots:
+    // B=64, T=50: 0.070 / 0.074 ms; B=32, T=160: 0.072 / 0.080 ms)
+    p.fused = T > 32 && (m->row_mode == 3 || (m->row_mode == 0 && groups <= 1024 && (!ragged || groups <= 256)));
     p.q2 = p.k2 = p.vt2 = off;
     if (p.fused) {
         p.q2 = off;
