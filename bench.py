@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--gather", default="final", choices=["final", "step"],
+                    help="multi-GPU: one all_gather of all K batches' log-probs at the end of the timed region, or one per batch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,21 +195,33 @@ def main():
     x = torch.from_numpy(np.random.default_rng(rank).uniform(-13.8, 4.2, (B, T, F_MEL)).astype(np.float32)).to(dev)
     if args.precision == "bf16":
         x = x.to(torch.bfloat16)
-    # The single collective of the path: one RCCL all_gather of this step's log-probs [B,T,2] per rank, ordered
-    # after the step's kernels.  Measured on 1 GPU through RCCL (SAVAD_BENCH_FORCE_DIST=1): +2 us per step; an
-    # async, double-buffered variant that lets the gather overlap the next step's kernels measured +45 us per step
-    # (the extra stream's barrier packets cost more than the 205 KB transfer), so the plain form stays.
+    # The single collective of the path (north_star: "utterance batches shard embarrassingly across the 8 GPUs of
+    # one node with a single RCCL gather over xGMI at the end"): every rank keeps the log-probs of its K batches on
+    # the device and ONE all_gather of all of them ([K,B,T,2] per rank: 10 MB at the default sizes) closes the
+    # timed region.  `--gather step` gathers after every batch instead (stream-ordered; measured +2 us per step on
+    # 1 GPU through RCCL; an async double-buffered variant measured +45 us per step and was dropped).
+    final = use_dist and args.gather == "final"
+    n_keep = max(args.steps, args.warmup, 1)
     gathered = torch.empty((world, B, T, 2), dtype=torch.float32, device=dev) if use_dist else None
+    local_all = torch.empty((n_keep, B, T, 2), dtype=torch.float32, device=dev) if final else None  # this rank's K batches
+    gathered_all = torch.empty((world, n_keep, B, T, 2), dtype=torch.float32, device=dev) if final else None
+    done = [0]
 
     def step():
         with torch.no_grad():
-            y = model(features=x)
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, y)
+            if final:  # the forward writes straight into this batch's slot of the gather's send buffer
+                y = model(features=x, out=local_all[done[0] % n_keep])
+                done[0] += 1
+            else:
+                y = model(features=x)
+                if use_dist:
+                    dist.all_gather_into_tensor(gathered, y)
         return y
 
     def drain():
-        pass
+        if final and done[0]:
+            dist.all_gather_into_tensor(gathered_all, local_all)
+            done[0] = 0
 
     for _ in range(max(args.warmup, 1)):
         step()
@@ -222,9 +236,9 @@ def main():
             y = step()
         drain()
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t0  # this rank's K steps (+ the gather, which completes only when every rank has contributed)
         if use_dist:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+            dist.barrier()  # closing bracket; its own latency (a host-synchronised RCCL all_reduce) is not part of the K steps
         if use_dist:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -243,7 +257,8 @@ def main():
     ktimes = [] if args.no_events else model.kernel_times()
     ok = bool(torch.isfinite(y).all().item())
     if use_dist:  # the last gather really delivered this rank's shard
-        ok = ok and bool(torch.equal(gathered[rank], y))
+        got = gathered[rank] if args.gather == "step" else gathered_all[rank, args.steps - 1]
+        ok = ok and bool(torch.equal(got, y))
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -293,7 +308,8 @@ def main():
             "config": {"workload": f"BASELINE configs[{1 if args.precision == 'fp32' else 2}]: synthetic [B={B}, T={T}, F={F_MEL}] {args.precision} per GPU, "
                                    f"SelfAttentiveVAD(80, 3, 128) forward -> log-probs [B,T,2]",
                        "global_batch": world * B, "frames_per_sequence": T,
-                       "parallelism": f"batch-shard x{world}" + (" + 1 RCCL all_gather" if world > 1 else "")},
+                       "parallelism": f"batch-shard x{world}" + ((" + 1 RCCL all_gather of all K batches' log-probs at the end" if args.gather == "final"
+                                                                   else " + 1 RCCL all_gather per batch") if world > 1 else "")},
             "finite": ok,
             "roofline": roof,
         }

@@ -132,7 +132,9 @@ class SelfAttentiveVAD(nn.Module):
         self._synced_versions = versions
 
     # ---- forward ------------------------------------------------------------------------------
-    def forward(self, features: Tensor) -> Tensor:
+    def forward(self, features: Tensor, out: Optional[Tensor] = None) -> Tensor:
+        """features [B, T, F] -> log-probabilities [B, T, 2] (fp32, on features.device).  `out` (optional, not in the
+        reference's signature) is a contiguous fp32 [B, T, 2] tensor to write into instead of allocating one."""
         if features.dim() != 3 or features.size(2) != self.feature_size:
             raise ValueError(f"features must be [B, T, {self.feature_size}], got {tuple(features.shape)}")
         if features.device.type != "cuda":
@@ -152,7 +154,10 @@ class SelfAttentiveVAD(nn.Module):
             x = x.float()
         x = x.contiguous()
         B, T, _ = x.shape
-        out = torch.empty((B, T, 2), dtype=torch.float32, device=device)
+        if out is None:
+            out = torch.empty((B, T, 2), dtype=torch.float32, device=device)
+        elif (tuple(out.shape) != (B, T, 2) or out.dtype != torch.float32 or out.device != device or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous float32 [{B}, {T}, 2] tensor on {device}")
         if B == 0 or T == 0:
             return out
         lib = _lib.load()
