@@ -245,6 +245,14 @@ def test_empty_and_call_forms(torch_cuda, model):
     assert a.cpu().numpy().shape == (2, 9, 2)
     with pytest.raises(ValueError):
         model(features=torch.zeros(2, 9, 81, device="cuda"))
+    # optional `out=` (this build's addition): write into a caller-owned slot, e.g. of a gather send buffer
+    slots = torch.full((3, 2, 9, 2), 7.0, device="cuda")
+    with torch.no_grad():
+        c = model(features=x, out=slots[1])
+    assert c.data_ptr() == slots[1].data_ptr() and torch.equal(slots[1], a) and bool((slots[0] == 7).all()) and bool((slots[2] == 7).all())
+    for bad in (torch.empty(2, 9, 3, device="cuda"), torch.empty(2, 9, 2, device="cuda", dtype=torch.float16), torch.empty(2, 9, 4, device="cuda")[..., ::2]):
+        with pytest.raises(ValueError):
+            model(features=x, out=bad)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
