@@ -213,6 +213,35 @@ def test_fused_attention_row_launches(torch_cuda, model, golden, state1234):
         model.row_mode, model.attention_splits = 0, 0
 
 
+def test_packed_attention_inside_row_kernel(torch_cuda, model, golden, state1234):
+    """T <= 32, small batches: the N-split row kernel computes its tile's attention itself (row_mode 0 / 1) instead
+    of reading what a separate launch wrote (row_mode 4).  Same arithmetic -> bit-identical; goldens for the
+    reference's own window shape; tiles that are not a multiple of 32 rows (T=7: 28), a last tile with missing
+    sequences, and a NaN-poisoned workspace."""
+    from oracle import oracle
+
+    torch = torch_cuda
+    y = run(torch, model, feats(101, (4, 7, 80)), row_mode=1)
+    assert np.abs(y - golden["g1_out"]).max() < TIGHT
+    y = run(torch, model, feats(78, (1000, 7, 80)), row_mode=0)
+    assert np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < TIGHT
+    for shape in ((1, 1, 80), (3, 7, 80), (5, 16, 80), (37, 3, 80), (9, 32, 80), (1001, 7, 80), (250, 11, 80), (2, 31, 80)):
+        x = feats(sum(shape) + 3, shape)
+        fused = run(torch, model, x, row_mode=1)
+        assert np.array_equal(fused, run(torch, model, x, row_mode=4)), shape
+        assert np.abs(fused - oracle.forward(state1234, x)).max() < TIGHT, shape
+    model.row_mode = 1
+    try:
+        xt = torch.from_numpy(feats(5, (13, 7, 80))).cuda()
+        with torch.no_grad():
+            y0 = model(features=xt).clone()
+            model._workspace.fill_(255)
+            y1 = model(features=xt)
+        assert torch.isfinite(y1).all() and torch.equal(y0, y1)
+    finally:
+        model.row_mode = 0
+
+
 def test_properties_full_size(torch_cuda, model):
     # size-independent properties at config-2 size: normalisation, batch-permutation equivariance
     # (sequences are independent: bit-exact), determinism

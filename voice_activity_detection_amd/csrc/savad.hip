@@ -151,7 +151,7 @@ Workspace plan(const savad_model* m, int B, int T) {
     // the batch is small and the critical path per workgroup matters more than weight traffic.
     // Measured crossover on MI355X at T=800: B=24 (150 tiles) N-split 105 us vs M-split 119 us per
     // layer; B=32 (200 tiles) 134 vs 120.
-    w.msplit = m->row_mode >= 2 || (m->row_mode == 0 && w.rows_pad / 128 >= 192);
+    w.msplit = m->row_mode == 2 || m->row_mode == 3 || (m->row_mode == 0 && w.rows_pad / 128 >= 192);
     // In the M-split regime without key splits the attention stage and the row chain of a query-block group
     // run back to back in one workgroup (attention_row_kernel).  row_mode 2 keeps them as separate launches.
     // Automatic: only when a query-block group keeps at least 80 % of its 4 wave slots busy -- waves without a
@@ -495,7 +495,7 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
-    if (!m || mode < 0 || mode > 3) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 4) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -735,8 +735,15 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
         HIP_TRY(hipGetLastError());
         return SAVAD_OK;
     }
+    // T <= 32 in the N-split regime: the row kernel computes its tile's attention itself (tile = floor(32/T) whole
+    // sequences; each of the 4 waves needs the whole context tile and computes it), so a layer is ONE launch.  Only
+    // while the tiles fit one round of the 256 CUs: there the 4x redundant 128 MFMAs and the 28-row tiles of T=7 cost
+    // nothing ([1000,7,80]: 0.171 -> 0.162 ms); with several rounds per CU they do ([600,16,80]: 0.266 -> 0.276 ms).
+    const int Gp = T <= 32 ? 32 / T : 0, rowsPB = Gp * T, nblk_packed = T <= 32 ? (B + Gp - 1) / Gp : 0;
+    const bool packed_fused = T <= 32 && !msplit && nblk_packed <= 256 && m->row_mode != 4;
     for (int l = 0; l < L; ++l) {
-        if (T <= 32) {
+        if (packed_fused) {
+        } else if (T <= 32) {
             const int G = 32 / T, nblk = (B + G - 1) / G;
             hipLaunchKernelGGL(attention_packed_kernel, dim3(nblk), dim3(64), 0, st, q, k, v, op, ml, B, T, (int)ws.rows, c);
         } else {
@@ -745,7 +752,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
             hipLaunchKernelGGL(attention_kernel, dim3(grid), dim3(256), 0, st, q, k, v, op, ml, B, T, (int)ws.rows_pad,
                                ws.S, NG, c);
         }
-        prof.mark("attention");
+        if (!packed_fused) prof.mark("attention");
         const auto& r = m->lr[l];
         const auto& p = m->lp[l];
 #define SAVAD_ROW_ARGS(WN, BN) op, ml, ws.S, (int)ws.rows, (int)ws.rows_pad, c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, \
@@ -755,16 +762,18 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
                 hipLaunchKernelGGL(row_kernel_m<false>, dim3(tiles_m), dim3(256), 0, st,
                                    SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv));
             else
-                hipLaunchKernelGGL(row_kernel<false>, dim3(tiles), dim3(256), 0, st,
-                                   SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv));
-            prof.mark("row");
+                hipLaunchKernelGGL(row_kernel<false>, dim3(packed_fused ? nblk_packed : tiles), dim3(256), 0, st,
+                                   SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv), packed_fused ? rowsPB : TILE,
+                                   packed_fused ? T : 0);
+            prof.mark(packed_fused ? "attention_row" : "row");
         } else {
             if (msplit)
                 hipLaunchKernelGGL(row_kernel_m<true>, dim3(tiles_m), dim3(256), 0, st,
                                    SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc));
             else
-                hipLaunchKernelGGL(row_kernel<true>, dim3(tiles), dim3(256), 0, st, SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc));
-            prof.mark("row_last");
+                hipLaunchKernelGGL(row_kernel<true>, dim3(packed_fused ? nblk_packed : tiles), dim3(256), 0, st,
+                                   SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc), packed_fused ? rowsPB : TILE, packed_fused ? T : 0);
+            prof.mark(packed_fused ? "attention_row_last" : "row_last");
         }
 #undef SAVAD_ROW_ARGS
     }

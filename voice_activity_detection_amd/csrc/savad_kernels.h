@@ -259,20 +259,16 @@ __device__ __forceinline__ void store_attention_partial(float* __restrict__ Opar
 // the blocks are spread over as many CUs as possible) and every operand of the tile is requested up front
 // (Q, K: 16 x 16-byte loads each, V: 64 dword loads) so that the wave pays the L2 latency once, not per MFMA
 // group; with one wave per SIMD the 256-VGPR budget of the multi-wave kernels does not apply.
-__global__ __launch_bounds__(64) void attention_packed_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                              const float* __restrict__ v, float* __restrict__ Opart,
-                                                              float* __restrict__ ml, int B, int T, int rows, float c) {
-    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
-    const int G = 32 / T, rowsPB = G * T;
-    const int blk = blockIdx.x;
-    const size_t k0 = (size_t)blk * rowsPB;
+// Attention of one packed tile (floor(32/T) whole sequences, rows k0 .. k0+rowsPB-1) for the calling wave:
+// O^T (unnormalised, row layout) and the row sums.  Q and K are requested together, V after the scores (the
+// caller may hold other live registers); over-read rows only produce masked scores / zero probabilities.
+__device__ __forceinline__ void packed_attention_tile(f32x16 (&O)[4], float& m_run, float& l_run, const float* __restrict__ q,
+                                                      const float* __restrict__ k, const float* __restrict__ v, size_t k0,
+                                                      int rowsPB, int T, int rows, float c, int n, int h) {
+    const int m = n;
     const size_t qrow = k0 + m;
-    const bool qvalid = (m < rowsPB) && (qrow < (size_t)rows);
     const int tq = m / T;
-    // q/k/v carry 32 rows of slack behind rows_pad, so the tile may over-read without clamping:
-    // over-read K rows only produce masked scores, over-read V rows are zero (input_qkv_kernel).
     f32x4 qg[16], kg[16];
-    float vv[4][16];
     const float* kp = k + (k0 + n) * D + 4 * h;
     const float* vp = v + (k0 + 4 * h) * D + n;
 #pragma unroll
@@ -280,14 +276,15 @@ __global__ __launch_bounds__(64) void attention_packed_kernel(const float* __res
         qg[G8] = ld4(q + qrow * D + 8 * G8 + 4 * h);
         kg[G8] = ld4(kp + 8 * G8);
     }
+    float vv[4][16];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) vv[nb][r] = vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb];
-    f32x16 O[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
-    float m_run = NEG_BIG, l_run = 0.0f;
+    m_run = NEG_BIG;
+    l_run = 0.0f;
     f32x16 sc = zero16();
 #pragma unroll
     for (int G8 = 0; G8 < 16; ++G8)
@@ -305,6 +302,21 @@ __global__ __launch_bounds__(64) void attention_packed_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vv[nb][r], sc[r], O[nb]);
     }
+}
+
+__global__ __launch_bounds__(64) void attention_packed_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, float* __restrict__ Opart,
+                                                              float* __restrict__ ml, int B, int T, int rows, float c) {
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int G = 32 / T, rowsPB = G * T;
+    const size_t k0 = (size_t)blockIdx.x * rowsPB;
+    const size_t qrow = k0 + m;
+    const bool qvalid = (m < rowsPB) && (qrow < (size_t)rows);
+    // q/k/v carry 32 rows of slack behind rows_pad, so the tile may over-read without clamping:
+    // over-read K rows only produce masked scores, over-read V rows are zero (input_qkv_kernel).
+    f32x16 O[4];
+    float m_run, l_run;
+    packed_attention_tile(O, m_run, l_run, q, k, v, k0, rowsPB, T, rows, c, n, h);
     if (qvalid) store_attention_partial(Opart, ml, qrow, O, m_run, l_run, h);
 }
 
@@ -603,7 +615,8 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
     const float* __restrict__ b2, const float* __restrict__ Wn /* LAST ? Wc'[2][D] : Wqkv'[3D][D] */,
     const float* __restrict__ bn, float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
-    float* __restrict__ out /* [rows][2] */) {
+    float* __restrict__ out /* [rows][2] */, int tile_rows /* 32, or floor(32/T)*T with Tpack */,
+    int Tpack /* > 0: T <= 32 and the tile's attention is computed HERE from q, k, v instead of read from Opart */) {
     __shared__ __attribute__((aligned(16))) float lds[TILE * XLD + 12 * TILE * PLD + 8 * D];
     float* xbuf = lds;
     float* pbuf = lds + TILE * XLD;  // [dest block 4][src slot 3][32 rows][PLD]
@@ -612,7 +625,10 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     float* lbn = lb2 + D;
     const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t row = (size_t)blockIdx.x * TILE + m;
+    const size_t row = (size_t)blockIdx.x * tile_rows + m;
+    // Packed mode: the tile is floor(32/T) whole sequences (tile_rows <= 32 rows); the remaining lanes alias the next
+    // tile's rows and rows past the batch may lie outside the buffers: neither is ever stored.
+    const bool lane_ok = Tpack > 0 ? (m < tile_rows && row < (size_t)rows) : true;
 
     SAVAD_STAMP(32);
     WBlock wa, wb;
@@ -624,7 +640,20 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     add_block(h1, hbuf + row * D + 32 * w, h);
     // ---- phase 0: ctx = combination of the key-split partials (rows are lane-local: all scalars per lane)
     f32x4 xg[16];
-    combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
+    if (Tpack > 0) {
+        // every wave needs the whole context tile as B operand: each computes it (128 MFMAs) instead of all four
+        // reading back what a separate 1-wave launch wrote -- no launch, no partial round trip
+        f32x16 O[4];
+        float m_run, l_run;
+        packed_attention_tile(O, m_run, l_run, q, k, v, (size_t)blockIdx.x * tile_rows, tile_rows, Tpack, rows, c, n, h);
+        const float inv = lane_ok ? 1.0f / l_run : 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xg[4 * nb + (r >> 2)][r & 3] = lane_ok ? O[nb][r] * inv : 0.0f;
+    } else {
+        combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
+    }
     SAVAD_STAMP(33);
     // ---- phase 1: h1 = ctx Wo^T + bo + h   (wave's 32 features)
     wload_k128(wb, W1 + (size_t)(128 * w + n) * D + 4 * h);  // first FFN block
@@ -670,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     for (int slot = 0; slot < 3; ++slot) add_block(own, pbuf + ((w * 3 + slot) * TILE + m) * PLD, h);
     own += bias_block(lb2 + 32 * w, h);
     own += h1;  // residual onto the un-normalised stream (transformer.py:235-237)
-    if (!LAST) store_block(hbuf + row * D + 32 * w, own, h);
+    if (!LAST && lane_ok) store_block(hbuf + row * D + 32 * w, own, h);
     SAVAD_STAMP(36);
     // ---- phase 3
     store_block(xbuf + m * XLD + 32 * w, own, h);  // xbuf's last readers all passed the barrier above
@@ -687,7 +716,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
             if (j + 1 < 3) wload_k128(nxt, Wn + (size_t)(D * (j + 1) + 32 * w + n) * D + 4 * h);
             f32x16 acc = bias_block(lbn + D * j + 32 * w, h);
             wmma_k128(acc, cur, xg);
-            store_block(dst[j] + row * D + 32 * w, acc, h);
+            if (lane_ok) store_block(dst[j] + row * D + 32 * w, acc, h);
         }
     } else if (w == 0) {
         float z0 = 0.0f, z1 = 0.0f;
@@ -706,7 +735,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
         z1 += bn[1];
         const float mx = fmaxf(z0, z1);
         const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
-        if (h == 0 && row < (size_t)rows) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+        if (h == 0 && lane_ok && row < (size_t)rows) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
     }
     SAVAD_STAMP(38);
 }
