@@ -128,3 +128,53 @@ def test_predict_cli_writes_json_v03(tmp_path, state1234):
     data = json.loads(out.read_text())
     assert data["version"] == "v0.3" and data["duration"] == "00:00:06.000" and data["probs_sample_rate"] == 100
     assert len(data["probs"]) == 602 and len(VoiceActivity.load(out).activities) == len(data["activities"])
+
+
+def test_audio_loading_formats_and_resampling(tmp_path):
+    """AudioData.load restated (vad/data_models/audio_data.py:18-34): .pcm, PCM WAV of several widths / channel counts,
+    and other sample rates -> float32 mono @16 kHz.  (The resampler is scipy's polyphase filter, not resampy: values
+    are unpinned against the reference; length and spectral content are checked.)"""
+    import wave
+
+    import numpy as np
+
+    from voice_activity_detection_amd.features import load_wav_mono16k, resample_to_16k
+
+    t = np.arange(16000) / 16000.0
+    tone = 0.5 * np.sin(2 * np.pi * 440.0 * t)
+    pcm16 = np.round(tone * 32767).astype("<i2")
+    pcm16.tofile(tmp_path / "a.pcm")
+    a = load_wav_mono16k(tmp_path / "a.pcm")
+    assert a.dtype == np.float32 and a.shape == (16000,) and np.array_equal(a, pcm16.astype(np.float32) / 32768.0)
+
+    def write(name, data, width, ch, rate):
+        with wave.open(str(tmp_path / name), "wb") as w:
+            w.setnchannels(ch)
+            w.setsampwidth(width)
+            w.setframerate(rate)
+            w.writeframes(data)
+
+    write("mono16.wav", pcm16.tobytes(), 2, 1, 16000)
+    assert np.array_equal(load_wav_mono16k(tmp_path / "mono16.wav"), a)
+    stereo = np.stack([pcm16, np.zeros_like(pcm16)], axis=1)  # channels are averaged (audio_data.py:26)
+    write("stereo16.wav", stereo.astype("<i2").tobytes(), 2, 2, 16000)
+    assert np.allclose(load_wav_mono16k(tmp_path / "stereo16.wav"), a / 2, atol=1e-7)
+    write("u8.wav", np.round(tone * 127 + 128).astype(np.uint8).tobytes(), 1, 1, 16000)
+    assert np.abs(load_wav_mono16k(tmp_path / "u8.wav") - tone).max() < 1.0 / 100
+    v24 = np.round(tone * 8388607).astype(np.int32)
+    b24 = np.stack([v24 & 255, (v24 >> 8) & 255, (v24 >> 16) & 255], axis=1).astype(np.uint8)
+    write("s24.wav", b24.tobytes(), 3, 1, 16000)
+    assert np.abs(load_wav_mono16k(tmp_path / "s24.wav") - tone).max() < 1e-6
+    write("s32.wav", np.round(tone * 2147483647).astype("<i4").tobytes(), 4, 1, 16000)
+    assert np.abs(load_wav_mono16k(tmp_path / "s32.wav") - tone).max() < 1e-6
+    # 44.1 kHz and 8 kHz sources: length as ceil(n * 16000 / rate), the 440 Hz tone survives with its amplitude
+    for rate in (44100, 48000, 8000, 22050):
+        n = rate  # one second
+        src = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(n) / rate)
+        write(f"r{rate}.wav", np.round(src * 32767).astype("<i2").tobytes(), 2, 1, rate)
+        y = load_wav_mono16k(tmp_path / f"r{rate}.wav")
+        assert y.dtype == np.float32 and len(y) == 16000
+        spec = np.abs(np.fft.rfft(y[2000:14000] * np.hanning(12000)))
+        assert abs(np.argmax(spec) * 16000 / 12000 - 440.0) < 2.0
+        assert abs(np.abs(y[2000:14000]).max() - 0.5) < 0.01
+    assert len(resample_to_16k(np.zeros(44101, np.float32), 44100)) == int(np.ceil(44101 * 16000 / 44100))

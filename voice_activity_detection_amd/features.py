@@ -13,20 +13,51 @@ from . import _lib
 SAMPLE_RATE = 16000  # vad/data_models/audio_data.py:9
 
 
-def load_wav_mono16k(path) -> np.ndarray:
-    """PCM WAV -> float32 mono in [-1, 1) (stdlib only).  The reference's AudioData.load
-    (vad/data_models/audio_data.py:18-34) also resamples other rates with librosa; that is not restated:
-    only 16 kHz input is accepted."""
-    import wave
+def resample_to_16k(audio: np.ndarray, sample_rate: int) -> np.ndarray:
+    """Rational-ratio polyphase resampling to 16 kHz (scipy.signal.resample_poly, Kaiser-windowed FIR).  The
+    reference calls librosa.resample(..., res_type="kaiser_fast") (vad/data_models/audio_data.py:27-30; resampy, a
+    windowed-sinc interpolator); neither librosa nor resampy exists here, so sample values are NOT pinned against
+    it -- only length (ceil(n * 16000 / rate), as resampy) and spectral content are tested."""
+    from math import gcd
 
+    from scipy.signal import resample_poly
+
+    if sample_rate == SAMPLE_RATE:
+        return np.asarray(audio, dtype=np.float32)
+    g = gcd(SAMPLE_RATE, int(sample_rate))
+    out = resample_poly(np.asarray(audio, dtype=np.float64), SAMPLE_RATE // g, int(sample_rate) // g)
+    n = int(np.ceil(len(audio) * SAMPLE_RATE / sample_rate))
+    return out[:n].astype(np.float32)
+
+
+def load_wav_mono16k(path) -> np.ndarray:
+    """Audio file -> float32 mono @16 kHz in [-1, 1): the reference's AudioData.load (vad/data_models/audio_data.py:
+    18-34) with the stdlib instead of soundfile: ``.pcm`` = headerless 16-bit mono @16 kHz (:21-24); otherwise a PCM
+    WAV of 8 / 16 / 24 / 32 bits, any channel count (averaged, :26) and any rate (resampled, :27-30)."""
+    import wave
+    from pathlib import Path
+
+    path = Path(path)
+    if path.suffix == ".pcm":
+        return (np.fromfile(path, dtype=np.int16).astype(np.float32) / 32768.0).astype(np.float32)
     with wave.open(str(path)) as w:
-        if w.getframerate() != SAMPLE_RATE:
-            raise ValueError(f"{path}: only {SAMPLE_RATE} Hz WAV is supported, got {w.getframerate()}")
-        if w.getsampwidth() != 2:
-            raise ValueError(f"{path}: only 16-bit PCM is supported")
-        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
-        ch = w.getnchannels()
-    return pcm.reshape(-1, ch).mean(axis=1).astype(np.float32) if ch > 1 else pcm
+        rate, width, ch = w.getframerate(), w.getsampwidth(), w.getnchannels()
+        raw = w.readframes(w.getnframes())
+    if width == 2:
+        pcm = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 1:  # unsigned
+        pcm = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif width == 3:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        pcm = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    elif width == 4:
+        pcm = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    else:
+        raise ValueError(f"{path}: unsupported PCM sample width {width}")
+    if ch > 1:
+        pcm = pcm.reshape(-1, ch).mean(axis=1).astype(np.float32)
+    return resample_to_16k(pcm, rate)
 
 
 @torch.no_grad()
