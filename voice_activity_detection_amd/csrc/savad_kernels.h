@@ -838,6 +838,7 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t row = (size_t)blockIdx.x * 128 + 32 * w + m;
     const bool valid = row < (size_t)rows;
+    SAVAD_STAMP(40);
     const DmaLanes LA = dma_lanes_rows32(D, true, w, lane);
     dma_block(Wqkv, LA, ring, w);  // first QKV block flies while the input projection runs
     stage_bias(bq, bqkv, 3 * D);
@@ -851,6 +852,7 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
         add_bias(h0[nb], bin + 32 * nb, h);
         add_block(h0[nb], pe + (size_t)t * D + 32 * nb, h);
     }
+    SAVAD_STAMP(41);
     for (int G = 0; G < F / 8; ++G) {  // the input weights (40 KB) come straight from L2: 2.6 % of the MFMAs
         f32x4 x4 = ld4(xp + 8 * G);
         if (!valid) x4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -861,14 +863,18 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
             for (int e = 0; e < 4; ++e) h0[nb] = SAVAD_MFMA(w4[e], x4[e], h0[nb]);
         }
     }
+    SAVAD_STAMP(42);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         store_block(hbuf + row * D + 32 * nb, h0[nb], h);
         if (blockIdx.x == gridDim.x - 1 && w == 3) store_block(v + (row + TILE) * D + 32 * nb, zero16(), h);  // V slack
     }
+    SAVAD_STAMP(43);
     f32x4 xg[16];
     layernorm_regs(h0, xg);
+    SAVAD_STAMP(44);
     qkv_tail_m(xg, Wqkv, bq, q, k, v, row, ring, LA, w, n, h);
+    SAVAD_STAMP(45);
 }
 
 // The row-wise chain of one layer for the 32 rows of a wave, weights through the workgroup's LDS ring:
