@@ -70,6 +70,7 @@ struct savad_model {
     size_t frag_bytes = 0;
     bool frag_dirty = true;
     bool lds_attrs_set = false;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the bf16 kernels
+    bool lds_attrs_set_h = false;  // ... and for the helper-wave fp32 kernel
     size_t f_win = 0;
     struct LayerFrag {
         size_t wqkv, wo, w1, w2;
@@ -151,7 +152,7 @@ Workspace plan(const savad_model* m, int B, int T) {
     // the batch is small and the critical path per workgroup matters more than weight traffic.
     // Measured crossover on MI355X at T=800: B=24 (150 tiles) N-split 105 us vs M-split 119 us per
     // layer; B=32 (200 tiles) 134 vs 120.
-    w.msplit = m->row_mode == 2 || m->row_mode == 3 || (m->row_mode == 0 && w.rows_pad / 128 >= 192);
+    w.msplit = m->row_mode == 2 || m->row_mode == 3 || m->row_mode == 5 || (m->row_mode == 0 && w.rows_pad / 128 >= 192);
     // In the M-split regime without key splits the attention stage and the row chain of a query-block group
     // run back to back in one workgroup (attention_row_kernel).  row_mode 2 keeps them as separate launches.
     // Automatic: only when a query-block group keeps at least 80 % of its 4 wave slots busy -- waves without a
@@ -160,7 +161,7 @@ Workspace plan(const savad_model* m, int B, int T) {
     // 7) 0.640 / 0.668).
     const int QBp = (T + 31) / 32, NGp = (QBp + 3) / 4;
     const bool ragged = QBp * 5 < NGp * 4 * 4;  // QB / (4 NG) < 0.8
-    w.fused = w.msplit && T > 32 && w.S == 1 && (m->row_mode == 3 || (m->row_mode != 2 && !ragged));
+    w.fused = w.msplit && T > 32 && w.S == 1 && (m->row_mode == 3 || m->row_mode == 5 || (m->row_mode != 2 && !ragged));
     size_t off = 0;
     w.h = off;
     off += w.rows_pad * D;
@@ -495,7 +496,7 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
-    if (!m || mode < 0 || mode > 4) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 5) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -712,13 +713,32 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     prof.mark("input_qkv");
     if (ws.fused) {
         float* qkv[2][3] = {{q, k, v}, {W + ws.q2, W + ws.k2, W + ws.v2}};
-        const int QB = (T + 31) / 32, NG = (QB + 3) / 4;
+        const bool helpers = m->row_mode == 5;  // 3 query-block waves + 1 helper wave per workgroup (attention_row_kernel_h)
+        const int QB = (T + 31) / 32, NG = helpers ? (QB + 2) / 3 : (QB + 3) / 4;
         const int grid = 8 * ((B + 7) / 8) * NG;
+        constexpr int lds_h = 8 * KV_TILE_FLOATS * (int)sizeof(float);
+        if (helpers && !m->lds_attrs_set_h) {
+            if ((rc = allow_lds(attention_row_kernel_h<false>, lds_h))) return rc;
+            if ((rc = allow_lds(attention_row_kernel_h<true>, lds_h))) return rc;
+            m->lds_attrs_set_h = true;
+        }
         for (int l = 0; l < L; ++l) {
             const auto& r = m->lr[l];
             const auto& p = m->lp[l];
             float** cur = qkv[l & 1];
             float** nxt = qkv[(l + 1) & 1];
+            if (helpers) {
+                if (l + 1 < L)
+                    hipLaunchKernelGGL(attention_row_kernel_h<false>, dim3(grid), dim3(256), lds_h, st, cur[0], cur[1], cur[2], B, T, NG,
+                                       c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2, P + m->lp[l + 1].wqkv,
+                                       P + m->lp[l + 1].bqkv, nxt[0], nxt[1], nxt[2], out, op, ml);
+                else
+                    hipLaunchKernelGGL(attention_row_kernel_h<true>, dim3(grid), dim3(256), lds_h, st, cur[0], cur[1], cur[2], B, T, NG,
+                                       c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2, P + m->p_wc, P + m->p_bc,
+                                       nxt[0], nxt[1], nxt[2], out, op, ml);
+                prof.mark(l + 1 < L ? "attention_row" : "attention_row_last");
+                continue;
+            }
             if (l + 1 < L) {
                 hipLaunchKernelGGL(attention_row_kernel<false>, dim3(grid), dim3(256), 0, st, cur[0], cur[1], cur[2], B, T, NG, c, hb,
                                    R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2, P + m->lp[l + 1].wqkv,

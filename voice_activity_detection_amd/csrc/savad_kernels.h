@@ -406,7 +406,8 @@ __device__ __forceinline__ void dma_block(const float* __restrict__ base /* wave
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(L.off[0]), "v"(L.off[1]), "v"(L.off[2]), "v"(L.off[3]), "s"(base), "s"(m0v)
-        : "memory");
+        : "memory", "scc");  // s_add_u32 writes SCC: without the clobber the compiler keeps a compare's result live
+                             // across the statement (seen: the null check of a generic->LDS cast, selecting -1)
 }
 
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -1104,6 +1105,183 @@ __global__ __launch_bounds__(256, 2) void attention_row_kernel(
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) xg[4 * nb + (r >> 2)][r & 3] = qvalid ? O[nb][r] * inv : 0.0f;
+    }
+    row_chain_m<LAST>(xg, h1, row, qvalid, qvalid, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, qn, kn, vn, out, w, n, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused stage with HELPER waves, for launches of at most one workgroup per CU (e.g. the headline [32,800,80]: 800
+// query blocks for 1024 SIMDs, so a wave that walks all 25 key tiles of its block IS the critical path).
+// A workgroup = up to 3 query-block waves ("mains") + 1 helper wave.  The mains walk key tiles [0, a) of their
+// blocks on K/V stream A; the helper walks the remaining tiles [a, NT) of each of those blocks in turn on a second
+// K/V stream B (same sequence, other tiles; 2 x 64 KiB of LDS), stores one (O, m, l) partial per block to global
+// memory, and the mains fold it in after the last step -- a = ceil(nq NT / (nq + 1)) gives every wave the same
+// number of steps (19 instead of 25 at T = 800, nq = 3).  Then the row chain runs exactly as in attention_row_kernel
+// (the helper takes part in the ring but owns no rows).
+// ---------------------------------------------------------------------------------------------
+#ifndef SAVAD_DBG_SLOTMASK
+#define SAVAD_DBG_SLOTMASK 1
+#endif
+template <bool LAST>
+__global__ __launch_bounds__(256, 2) void attention_row_kernel_h(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int B, int T, int NG, float c,
+    float* __restrict__ hbuf, const float* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ Wn,
+    const float* __restrict__ bn, float* __restrict__ qn, float* __restrict__ kn, float* __restrict__ vn,
+    float* __restrict__ out, float* __restrict__ Opart /* helper partials, [rows_pad][D] */, float* __restrict__ ml) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [stream A, B][buffer 2][K, V]: 8 tiles of 16 KiB
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int QB = (T + 31) / 32, NT = QB;
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int b = (i / NG) * 8 + xcd;
+    if (b >= B) return;
+    const int g = i % NG;
+    const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;  // NG = ceil(QB / 3): 1..3 blocks per group
+    const int nq = qb1 - qb0;
+    const bool helper = w == 3;
+    const bool active = w < nq;                         // a main with a query block (wave-uniform)
+    const int a = (nq * NT + nq) / (nq + 1);            // mains: tiles [0, a); helper: [a, NT) of each block
+    const int HT = NT - a, HS = nq * HT;                // helper tiles per block, helper steps (<= a)
+    const size_t kbase = (size_t)b * T;
+    int qb = qb0 + (helper || !active ? 0 : w);         // helper starts with the group's first block
+    size_t row = kbase + 32 * (size_t)qb + m;
+    bool qvalid = (active || (helper && HS > 0)) && (32 * qb + m) < T;
+
+    f32x4 xg[16];  // Q rows first, the normalised context afterwards
+#pragma unroll
+    for (int G8 = 0; G8 < 16; ++G8) xg[G8] = ld4(q + row * D + 8 * G8 + 4 * h);
+    f32x16 O[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
+    float m_run = NEG_BIG, l_run = 0.0f;
+
+    const DmaLanes LK = dma_lanes_rows32(D, true, w, lane), LV = dma_lanes_rows32(D, false, w, lane);
+    float* const sA = lds;
+    float* const sB = lds + 4 * KV_TILE_FLOATS;
+    auto stage = [&](float* sbuf, int slot, int tile) {
+        float* dst = sbuf + (slot & SAVAD_DBG_SLOTMASK) * 2 * KV_TILE_FLOATS;
+        dma_block(k + (kbase + 32 * (size_t)tile) * D, LK, dst, w);
+        dma_block(v + (kbase + 32 * (size_t)tile) * D, LV, dst + KV_TILE_FLOATS, w);
+    };
+    stage(sA, 0, 0);
+    if (HS > 0) stage(sB, 0, a);
+    for (int s = 0; s < a; ++s) {
+        wait_vmem_all();
+        __syncthreads();  // step s of both streams has landed for every wave; everyone is done with the other buffers
+        if (s + 1 < a) stage(sA, s + 1, s + 1);
+        if (s + 1 < HS) stage(sB, s + 1, a + (s + 1) % HT);
+        int jt;
+        const float* kb;
+#ifdef SAVAD_DBG_SIMPLE
+        if (helper || !active) continue;
+        jt = s;
+        kb = sA + (s & SAVAD_DBG_SLOTMASK) * 2 * KV_TILE_FLOATS;
+        if (false) {
+#else
+        if (helper) {
+#endif
+            if (s >= HS) continue;
+            jt = a + s % HT;
+            kb = sB + (s & 1) * 2 * KV_TILE_FLOATS;
+            if (s > 0 && s % HT == 0) {  // next block of the group: hand the finished partial over, start afresh
+                if (qvalid) store_attention_partial(Opart, ml, row, O, m_run, l_run, h);
+                qb = qb0 + s / HT;
+                row = kbase + 32 * (size_t)qb + m;
+                qvalid = (32 * qb + m) < T;
+#pragma unroll
+                for (int G8 = 0; G8 < 16; ++G8) xg[G8] = ld4(q + row * D + 8 * G8 + 4 * h);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
+                m_run = NEG_BIG;
+                l_run = 0.0f;
+            }
+        } else {
+            if (!active) continue;
+            jt = s;
+            kb = sA + (s & SAVAD_DBG_SLOTMASK) * 2 * KV_TILE_FLOATS;
+        }
+        const float* vb = kb + KV_TILE_FLOATS;
+        f32x16 sc = zero16();
+        const float* krow = kb + n * D;
+#pragma unroll
+        for (int G8 = 0; G8 < 16; ++G8) {
+            const f32x4 k4 = ld4(krow + 4 * ((2 * G8 + h) ^ (n & 15)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc = SAVAD_MFMA(k4[e], xg[G8][e], sc);
+        }
+        if (32 * jt + 32 > T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
+                sc[r] = (32 * jt + jk < T) ? sc[r] : NEG_BIG;
+            }
+        }
+        online_softmax(sc, m_run, l_run, O, c);
+        const float* vp = vb + 4 * h * D + n;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
+        }
+    }
+#ifdef SAVAD_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_savad_dbg[50] = nq; g_savad_dbg[51] = a; g_savad_dbg[52] = HT; g_savad_dbg[53] = HS; g_savad_dbg[54] = NT; g_savad_dbg[55] = NG;
+        g_savad_dbg[56] = (long long)(l_run * 1000.0f); g_savad_dbg[57] = T; g_savad_dbg[58] = B;
+    }
+#endif
+    if (helper && HS > 0 && qvalid) store_attention_partial(Opart, ml, row, O, m_run, l_run, h);
+    // ---- hand-over: the helper's partials become visible to its workgroup; the staging area becomes ring + biases
+    float* ring = lds;
+    float* lbo = lds + 2 * WBLK;
+    float* lb1 = lbo + D;
+    float* lb2 = lb1 + DFF;
+    float* lbn = lb2 + D;
+    if (helper) {  // the helper owns no rows: it rides along the row chain on the group's first block, storing nothing
+        qb = qb0;
+        row = kbase + 32 * (size_t)qb + m;
+        qvalid = false;
+    } else {
+        qvalid = active && (32 * qb + m) < T;
+    }
+    f32x16 h1[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        h1[nb] = zero16();
+        add_block(h1[nb], hbuf + row * D + 32 * nb, h);
+    }
+    if (!LAST && b == B - 1 && g == NG - 1) store_block(vn + ((size_t)B * T + m) * D + 32 * w, zero16(), h);
+    wait_vmem_all();          // this wave's partial stores have left
+    __threadfence_block();
+    __syncthreads();
+    const DmaLanes LA = dma_lanes_rows32(D, true, w, lane), LB = dma_lanes_rows128(DFF, w, lane);
+    dma_block(Wo, LA, ring, w);
+    stage_bias(lbo, bo, D);
+    stage_bias(lb1, b1, DFF);
+    stage_bias(lb2, b2, D);
+    if (!LAST) stage_bias(lbn, bn, 3 * D);
+    {
+        float w0 = 1.0f, w1 = 0.0f, lh = 0.0f;
+        const float* op = Opart + row * D + 4 * h;
+        if (HS > 0 && qvalid) {
+            const f32x2 th = *reinterpret_cast<const f32x2*>(ml + row * 2);
+            const float M = fmaxf(m_run, th[0]);
+            w0 = __builtin_amdgcn_exp2f((m_run - M) * c);
+            w1 = __builtin_amdgcn_exp2f((th[0] - M) * c);
+            lh = th[1];
+        }
+        const float inv = qvalid ? 1.0f / (l_run * w0 + lh * w1) : 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                f32x4 oh = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (HS > 0 && qvalid) oh = ld4(op + 8 * (4 * nb + gg));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    xg[4 * nb + gg][e] = qvalid ? (O[nb][4 * gg + e] * w0 + oh[e] * w1) * inv : 0.0f;
+            }
     }
     row_chain_m<LAST>(xg, h1, row, qvalid, qvalid, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, qn, kn, vn, out, w, n, h);
 }
