@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
     ap.add_argument("--frames", type=int, default=800, help="T")
     ap.add_argument("--splits", type=int, default=0, help="attention key splits (0 = auto)")
-    ap.add_argument("--row-mode", type=int, default=0, help="0 auto, 1 N-split 32-row tiles, 2 M-split 128-row tiles (separate attention / row launches), 3 M-split fused with attention, 4 N-split with the T<=32 attention as its own launch")
+    ap.add_argument("--row-mode", type=int, default=0, help="0 auto, 1 N-split 32-row tiles, 2 M-split 128-row tiles (separate attention / row launches), 3 M-split fused with attention, 4 N-split with the T<=32 attention as its own launch, 5 fused with helper waves (experimental)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = BASELINE configs[1] (default); bf16 = configs[2]: bf16 MFMA operands, bf16 features")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)

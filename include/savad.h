@@ -94,7 +94,9 @@ int savad_set_attention_splits(savad_handle h, int splits);
  * and the row chain of a query-block group fused into one launch per layer whenever T > 32 and the
  * key range is not split (what "automatic" picks for large batches), 4 = as 1 but with the T <= 32
  * attention kept as its own launch (1 and "automatic" let the row kernel compute its tile's attention
- * itself when the tiles fit one round of the CUs or fill all 32 MFMA rows).  With bf16 operands:
+ * itself when the tiles fit one round of the CUs), 5 = as 3 with workgroups of 3 query-block waves + 1
+ * helper wave that walks the tail of their key ranges (experimental; needs at most one workgroup per
+ * CU to pay).  With bf16 operands:
  * 1 = separate attention / row launches with 4-wave workgroups, 2 = the same with 8-wave workgroups,
  * 3 = fused launches (T > 32), 0 = fused up to ~4 workgroups per CU, separate beyond. */
 int savad_set_row_mode(savad_handle h, int mode);

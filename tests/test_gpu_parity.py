@@ -242,6 +242,33 @@ def test_packed_attention_inside_row_kernel(torch_cuda, model, golden, state1234
         model.row_mode = 0
 
 
+def test_helper_wave_schedule(torch_cuda, model, golden, state1234):
+    """row_mode 5 (experimental): 3 query-block waves + 1 helper wave per workgroup; the helper's key-range tails
+    come back as partials through global memory.  Different fp32 summation order than the other schedules, same
+    math: goldens / oracle at the tight tolerance, incl. groups of 1 and 2 blocks, ragged tails, a poisoned workspace."""
+    from oracle import oracle
+
+    torch = torch_cuda
+    y = run(torch, model, feats(102, (2, 800, 80)), splits=1, row_mode=5)
+    assert np.abs(y - golden["g2_out"]).max() < TIGHT
+    for T in (33, 65, 100, 801):
+        y = run(torch, model, feats(400 + T, (3, T, 80)), splits=1, row_mode=5)
+        assert np.abs(y - golden[f"g4_T{T}"]).max() < TIGHT
+    for shape in ((3, 768, 80), (1, 192, 80), (9, 97, 80), (1, 2049, 80), (17, 160, 80)):
+        x = feats(sum(shape), shape)
+        assert np.abs(run(torch, model, x, splits=1, row_mode=5) - oracle.forward(state1234, x)).max() < TIGHT, shape
+    model.row_mode, model.attention_splits = 5, 1
+    try:
+        xt = torch.from_numpy(feats(78, (3, 801, 80))).cuda()
+        with torch.no_grad():
+            y0 = model(features=xt).clone()
+            model._workspace.fill_(255)
+            y1 = model(features=xt)
+        assert torch.isfinite(y1).all() and torch.equal(y0, y1)
+    finally:
+        model.row_mode, model.attention_splits = 0, 0
+
+
 def test_properties_full_size(torch_cuda, model):
     # size-independent properties at config-2 size: normalisation, batch-permutation equivariance
     # (sequences are independent: bit-exact), determinism
