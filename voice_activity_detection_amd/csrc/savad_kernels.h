@@ -386,7 +386,7 @@ __device__ __forceinline__ DmaLanes dma_lanes_rows128(int ld, int w, int lane) {
 __device__ __forceinline__ void dma_block(const float* __restrict__ base /* wave-uniform */, const DmaLanes& L,
                                           float* lds_block, int w) {
     if (SAVAD_ABLATE & 1) return;
-    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_block;
+    const unsigned lds_addr = (unsigned)(size_t)lds_block;  // LDS byte address = low half of the flat address (no cast: no null check)
     const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr) + 1024u * (unsigned)w;
     unsigned keep;
     asm volatile(
