@@ -88,17 +88,20 @@ int savad_forward_ex(savad_handle h, const void* x, int x_dtype, int B, int T, f
 
 /* Tuning knob: number of key-range splits of the attention stage (0 = automatic). */
 int savad_set_attention_splits(savad_handle h, int splits);
-/* Tuning knob: tiling of the row-wise stages: 0 = automatic, 1 = 32-row tiles with the output
- * features split over the workgroup's waves, 2 = 128-row tiles with the weight stream shared
- * through LDS, attention and row stages as separate launches, 3 = as 2 but with the attention stage
- * and the row chain of a query-block group fused into one launch per layer whenever T > 32 and the
- * key range is not split (what "automatic" picks for large batches), 4 = as 1 but with the T <= 32
- * attention kept as its own launch (1 and "automatic" let the row kernel compute its tile's attention
- * itself when the tiles fit one round of the CUs), 5 = as 3 with workgroups of 3 query-block waves + 1
- * helper wave that walks the tail of their key ranges (experimental; needs at most one workgroup per
- * CU to pay).  With bf16 operands:
- * 1 = separate attention / row launches with 4-wave workgroups, 2 = the same with 8-wave workgroups,
- * 3 = fused launches (T > 32), 0 = fused up to ~4 workgroups per CU, separate beyond. */
+/* Tuning knob: the launch schedule (results differ only in fp32 summation order; default 0 = automatic).
+ *   fp32 operands
+ *     1  row-wise stages on 32-row tiles, output features split over the workgroup's 4 waves; for T <= 32 the
+ *        row kernel computes its tile's attention itself while the tiles fit one round of the CUs
+ *     4  as 1, but the T <= 32 attention always stays its own launch
+ *     2  row-wise stages on 128-row tiles, weight stream shared through LDS; attention and row stages are
+ *        separate launches
+ *     3  as 2, with attention and row chain of a query-block group fused into one launch per layer whenever
+ *        T > 32 and the key range is not split (what automatic picks for large batches)
+ *     5  as 3, with workgroups of 3 query-block waves + 1 helper wave that walks the tail of their key ranges
+ *        (experimental: pays only with at most one workgroup per CU)
+ *   bf16 operands
+ *     1  separate attention / row launches, 4-wave workgroups      2  the same with 8-wave workgroups
+ *     3  fused launches (T > 32)                                    0  fused up to ~4 workgroups per CU */
 int savad_set_row_mode(savad_handle h, int mode);
 /* Fills the names/durations of the kernels of the most recent savad_forward when profiling is
  * enabled with savad_set_profiling(h, 1): the forward then brackets every launch with hipEvents on
