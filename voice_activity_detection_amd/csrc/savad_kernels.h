@@ -410,6 +410,25 @@ __device__ __forceinline__ void dma_block(const float* __restrict__ base /* wave
                              // across the statement (seen: the null check of a generic->LDS cast, selecting -1)
 }
 
+// ONE of the four 1 KiB pieces a wave contributes to a 16 KiB block (piece i4 lands 4 KiB * i4 behind the wave's
+// first one).  Issued back to back, DMA instructions stall the wave (~100 cycles each); as separate statements they
+// can sit between the MFMAs of the tile being computed.
+__device__ __forceinline__ void dma_piece(const float* __restrict__ base /* wave-uniform */, const DmaLanes& L, float* lds_block,
+                                          int w, int i4) {
+    if (SAVAD_ABLATE & 1) return;
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_block) + 1024u * (unsigned)w + 4096u * (unsigned)i4;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(L.off[i4]), "s"(base), "s"(m0v)
+        : "memory");
+}
+
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v, float* __restrict__ Opart,
                                                            float* __restrict__ ml, int B, int T, int rows_pad, int S,
@@ -1048,17 +1067,24 @@ __global__ __launch_bounds__(256, 2) void attention_row_kernel(
         float* vb = kb + KV_TILE_FLOATS;
         wait_vmem_all();
         __syncthreads();  // tile jt has landed for every wave; everyone is done reading the other buffer
-        if (jt + 1 < NT) {
-            float* kn2 = lds + ((jt + 1) & 1) * 2 * KV_TILE_FLOATS;
-            dma_block(k + (kbase + 32 * (size_t)(jt + 1)) * D, LK, kn2, w);
-            dma_block(v + (kbase + 32 * (size_t)(jt + 1)) * D, LV, kn2 + KV_TILE_FLOATS, w);
+        const bool more = jt + 1 < NT;
+        float* kn2 = lds + ((jt + 1) & 1) * 2 * KV_TILE_FLOATS;
+        const float* knext = k + (kbase + 32 * (size_t)(jt + 1)) * D;
+        const float* vnext = v + (kbase + 32 * (size_t)(jt + 1)) * D;
+        if (!active) {  // a wave without a query block still moves its share of the next tile
+            if (more) {
+                dma_block(knext, LK, kn2, w);
+                dma_block(vnext, LV, kn2 + KV_TILE_FLOATS, w);
+            }
+            continue;
         }
-        if (!active) continue;
+        // the wave's 8 DMA pieces of the next tile are spread over the 128 MFMAs of this one
         f32x16 sc = zero16();
         const float* krow = kb + n * D;
 #pragma unroll
         for (int G8 = 0; G8 < 16; ++G8) {
             const f32x4 k4 = ld4(krow + 4 * ((2 * G8 + h) ^ (n & 15)));
+            if (more && (G8 & 3) == 1) dma_piece(knext, LK, kn2, w, G8 >> 2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) sc = SAVAD_MFMA(k4[e], xg[G8][e], sc);
         }
@@ -1073,6 +1099,7 @@ __global__ __launch_bounds__(256, 2) void attention_row_kernel(
         const float* vp = vb + 4 * h * D + n;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
+            if (more) dma_piece(vnext, LV, kn2 + KV_TILE_FLOATS, w, nb);
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
         }
