@@ -479,19 +479,25 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         wait_vmem_all();
         __syncthreads();  // tile jt has landed for every wave; everyone is done reading the other buffer
         SAVAD_TACC(0);
-        if (jt + 1 < jt1) {
-            float* kn = lds + ((jt + 1 - jt0) & 1) * 2 * KV_TILE_FLOATS;
-            dma_block(k + (kbase + 32 * (size_t)(jt + 1)) * D, LK, kn, w);
-            dma_block(v + (kbase + 32 * (size_t)(jt + 1)) * D, LV, kn + KV_TILE_FLOATS, w);
+        const bool more = jt + 1 < jt1;
+        float* kn = lds + ((jt + 1 - jt0) & 1) * 2 * KV_TILE_FLOATS;
+        const float* knext = k + (kbase + 32 * (size_t)(jt + 1)) * D;
+        const float* vnext = v + (kbase + 32 * (size_t)(jt + 1)) * D;
+        if (!active) {  // a wave without a query block still moves its share of the next tile
+            if (more) {
+                dma_block(knext, LK, kn, w);
+                dma_block(vnext, LV, kn + KV_TILE_FLOATS, w);
+            }
+            continue;
         }
         SAVAD_TACC(1);
-        if (!active) continue;
         // ---- S^T tile = K Q^T
         f32x16 sc = zero16();
         const float* krow = kb + n * D;
 #pragma unroll
         for (int G8 = 0; G8 < 16; ++G8) {
             const f32x4 k4 = ld4(krow + 4 * ((2 * G8 + h) ^ (n & 15)));
+            if (more && (G8 & 3) == 1) dma_piece(knext, LK, kn, w, G8 >> 2);  // the next tile's pieces ride between the MFMAs
 #pragma unroll
             for (int e = 0; e < 4; ++e) sc = SAVAD_MFMA(k4[e], qg[G8][e], sc);
         }
@@ -510,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         const float* vp = vb + 4 * h * D + n;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
+            if (more) dma_piece(vnext, LV, kn + KV_TILE_FLOATS, w, nb);
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
         }
