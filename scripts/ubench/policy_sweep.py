@@ -16,7 +16,7 @@ def bench(x, n=30):
     return (time.perf_counter() - t) / n * 1e3
 shapes = []
 for T in (7, 20, 40, 64, 100, 200, 400, 800, 1600):
-    for rows in (2000, 8000, 25600, 102400):
+    for rows in (2000, 8000, 14000, 20000, 25600, 102400):
         B = max(1, rows // T)
         shapes.append((B, T))
 worst = 1.0

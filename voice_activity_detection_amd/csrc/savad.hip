@@ -150,9 +150,10 @@ Workspace plan(const savad_model* m, int B, int T) {
     // Row-wise stages: 128-row tiles with the weight stream shared through LDS (M split) when that
     // fills the chip; 32-row tiles with the output features split over the 4 waves (N split) when
     // the batch is small and the critical path per workgroup matters more than weight traffic.
-    // Measured crossover on MI355X at T=800: B=24 (150 tiles) N-split 105 us vs M-split 119 us per
-    // layer; B=32 (200 tiles) 134 vs 120.
-    w.msplit = m->row_mode == 2 || m->row_mode == 3 || m->row_mode == 5 || (m->row_mode == 0 && w.rows_pad / 128 >= 192);
+    // N-split works through ceil(tiles / 256) rounds of ~45 us, M-split through one round of ~118 us per 256 workgroups
+    // of 128 rows: M wins from the third N-split round on (more than 512 tiles of 32 rows).  Measured at T=800: B=20
+    // (500 tiles) N 0.504 / M 0.648 ms; B=24 (600 tiles) N 0.611 / M 0.589 ms.
+    w.msplit = m->row_mode == 2 || m->row_mode == 3 || m->row_mode == 5 || (m->row_mode == 0 && w.rows_pad / 32 > 512);
     // In the M-split regime without key splits the attention stage and the row chain of a query-block group
     // run back to back in one workgroup (attention_row_kernel).  row_mode 2 keeps them as separate launches.
     // Automatic: only when a query-block group keeps at least 80 % of its 4 wave slots busy -- waves without a
@@ -616,7 +617,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
             A.qscale = c;
             if (bp.fused) {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
-                const dim3 grid(8 * ((B + 7) / 8) * NG);
+                const dim3 grid(8 * (((long)B * NG + 7) / 8));
                 if (last)
                     hipLaunchKernelGGL((bf::attention_row_kernel_bf16<true, NW>), grid, wg, ring + 9 * D * 4, st, cur[0], cur[1], cur[2], NG, A);
                 else
@@ -629,7 +630,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
                                    B, T, bp.nblk);
             } else {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
-                hipLaunchKernelGGL((bf::attention_kernel_bf16<NW>), dim3(8 * ((B + 7) / 8) * NG), wg, ring, st, qf, kf, vtf, ctxf, B,
+                hipLaunchKernelGGL((bf::attention_kernel_bf16<NW>), dim3(8 * (((long)B * NG + 7) / 8)), wg, ring, st, qf, kf, vtf, ctxf, B,
                                    T, NG);
             }
             prof.mark("attention_bf16");
@@ -715,7 +716,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
         float* qkv[2][3] = {{q, k, v}, {W + ws.q2, W + ws.k2, W + ws.v2}};
         const bool helpers = m->row_mode == 5;  // 3 query-block waves + 1 helper wave per workgroup (attention_row_kernel_h)
         const int QB = (T + 31) / 32, NG = helpers ? (QB + 2) / 3 : (QB + 3) / 4;
-        const int grid = 8 * ((B + 7) / 8) * NG;
+        const int grid = (int)(8 * (((long)B * NG + 7) / 8));
         constexpr int lds_h = 8 * KV_TILE_FLOATS * (int)sizeof(float);
         if (helpers && !m->lds_attrs_set_h) {
             if ((rc = allow_lds(attention_row_kernel_h<false>, lds_h))) return rc;
@@ -768,7 +769,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
             hipLaunchKernelGGL(attention_packed_kernel, dim3(nblk), dim3(64), 0, st, q, k, v, op, ml, B, T, (int)ws.rows, c);
         } else {
             const int QB = (T + 31) / 32, NG = (QB + 3) / 4;
-            const int grid = 8 * ((B + 7) / 8) * NG * ws.S;
+            const int grid = (int)(8 * (((long)B * NG * ws.S + 7) / 8));
             hipLaunchKernelGGL(attention_kernel, dim3(grid), dim3(256), 0, st, q, k, v, op, ml, B, T, (int)ws.rows_pad,
                                ws.S, NG, c);
         }

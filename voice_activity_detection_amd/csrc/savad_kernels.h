@@ -334,6 +334,23 @@ __global__ __launch_bounds__(64) void attention_packed_kernel(const float* __res
 //                           32 consecutive floats of one key row: conflict-free), row-major.
 constexpr int KV_TILE_FLOATS = 32 * D;
 
+// Workgroup -> (sequence, index among the sequence's `per_seq` workgroups) for the attention-type kernels.
+// Workgroups go to the 8 XCDs round-robin by blockIdx (each XCD has its own L2); the linear order (sequence major)
+// is cut into 8 equal chunks, one per XCD, so that a sequence's workgroups -- which all read the same K/V -- share an
+// L2 (a sequence straddles at most two XCDs) AND every XCD gets the same number of workgroups for any batch size.
+// (Binding whole sequences to XCDs, b = 8 j + xcd, left XCDs 0-1 with twice the work at B = 10: 76 us against 47.)
+// Launch 8 * ceil(B * per_seq / 8) workgroups.
+__device__ __forceinline__ bool xcd_balanced_map(int B, int per_seq, int& b, int& rr) {
+    const long W = (long)B * per_seq;
+    const int per_xcd = (int)((W + 7) / 8);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long lin = (long)xcd * per_xcd + slot;
+    if (slot >= per_xcd || lin >= W) return false;
+    b = (int)(lin / per_seq);
+    rr = (int)(lin % per_seq);
+    return true;
+}
+
 // Phase timing (experiments only, scripts/ablate.sh -DSAVAD_TIMING): wave 0 of workgroup 0 stamps
 // s_memtime at phase boundaries into g_savad_dbg.
 #ifdef SAVAD_TIMING
@@ -438,10 +455,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int QB = (T + 31) / 32, NT = QB;
     const int per_seq = NG * S;
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;  // all workgroups of a sequence on one XCD (its K/V stay in that L2)
-    const int b = (i / per_seq) * 8 + xcd;
-    if (b >= B) return;
-    const int rr = i % per_seq;
+    int b, rr;
+    if (!xcd_balanced_map(B, per_seq, b, rr)) return;
     const int s = rr / NG, g = rr % NG;
     const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;
     const int qb = qb0 + w;
@@ -1047,10 +1062,8 @@ __global__ __launch_bounds__(256, 2) void attention_row_kernel(
     const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int QB = (T + 31) / 32, NT = QB;
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;  // all workgroups of a sequence on one XCD (its K/V stay in that L2)
-    const int b = (i / NG) * 8 + xcd;
-    if (b >= B) return;
-    const int g = i % NG;
+    int b, g;
+    if (!xcd_balanced_map(B, NG, b, g)) return;
     const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;
     const int qb = qb0 + w;
     const bool active = qb < qb1;  // wave-uniform
@@ -1167,10 +1180,8 @@ __global__ __launch_bounds__(256, 2) void attention_row_kernel_h(
     const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int QB = (T + 31) / 32, NT = QB;
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-    const int b = (i / NG) * 8 + xcd;
-    if (b >= B) return;
-    const int g = i % NG;
+    int b, g;
+    if (!xcd_balanced_map(B, NG, b, g)) return;
     const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;  // NG = ceil(QB / 3): 1..3 blocks per group
     const int nq = qb1 - qb0;
     const bool helper = w == 3;

@@ -375,10 +375,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_kernel_bf1
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int QB = (T + 31) / 32;
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-    const int b = (i / NG) * 8 + xcd;
-    if (b >= B) return;
-    const int g = i % NG;
+    int b, g;
+    if (!xcd_balanced_map(B, NG, b, g)) return;
     const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;
     const int qb = qb0 + w;
     const bool active = qb < qb1;
@@ -624,10 +622,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_row_kernel
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int QB = (T + 31) / 32;
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-    const int b = (i / NG) * 8 + xcd;
-    if (b >= B) return;
-    const int g = i % NG;
+    int b, g;
+    if (!xcd_balanced_map(B, NG, b, g)) return;
     const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;
     const int qb = qb0 + w;
     const bool active = qb < qb1;
