@@ -311,14 +311,15 @@ def test_empty_and_call_forms(torch_cuda, model):
             model(features=x, out=bad)
 
 
+@pytest.mark.parametrize("shape", [(6, 96, 80), (32, 800, 80), (40, 7, 80)])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_forward_is_graph_capturable(torch_cuda, model, precision):
+def test_forward_is_graph_capturable(torch_cuda, model, precision, shape):
     """savad_forward neither allocates nor synchronises (include/savad.h), so after one warm-up call (weights
     packed, PE table grown) the 7 launches can be captured in a hipGraph and replayed on new data."""
     torch = torch_cuda
     model.precision = precision
     try:
-        x0, x1 = (torch.from_numpy(feats(s, (6, 96, 80))).cuda() for s in (41, 42))
+        x0, x1 = (torch.from_numpy(feats(s, shape)).cuda() for s in (41, 42))  # small / fused / packed schedules
         static_x = x0.clone()
         with torch.no_grad():
             eager0, eager1 = model(features=x0).clone(), model(features=x1).clone()
