@@ -18,7 +18,7 @@ for it in range(n):
     maxB = max(1, min(48, 40000 // T))
     B = int(rng.integers(1, maxB + 1))
     prec = "bf16" if rng.random() < 0.35 else "fp32"
-    mode = int(rng.integers(0, 4))
+    mode = int(rng.integers(0, 6))
     splits = int(rng.choice([0, 0, 1, 1, 2, 3, 5]))
     x = seeded_features(int(rng.integers(1 << 30)), (B, T, 80))
     m.precision, m.row_mode, m.attention_splits = prec, mode, splits
