@@ -176,7 +176,7 @@ class VADFromScratchPredictor:
                 _lib.check(lib.savad_gather_windows(ctypes.c_void_p(feat.data_ptr()), N, F, half, jump, first, count,
                                                     ctypes.c_void_p(win.data_ptr()),
                                                     ctypes.c_void_p(pos[first:first + count].data_ptr()), stream))
-                logp[first:first + count] = self.model(features=win)
+                self.model(features=win, out=logp[first:first + count])  # straight into the boost's input
             probs = torch.empty((N, W), dtype=torch.float32, device=self.device)
             mean = torch.empty((N,), dtype=torch.float32, device=self.device)
             if N > 0:
