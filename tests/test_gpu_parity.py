@@ -637,6 +637,48 @@ def test_evaluate_command_end_to_end(torch_cuda, state1234, tmp_path):
     assert len((tmp_path / "eval.jsonl").read_text().splitlines()) == 2
 
 
+def test_config1_reference_clip_end_to_end(torch_cuda, model, state1234, tmp_path):
+    """SURVEY.md section 8d config 1 on the reference's own test clip (tests/golden/data; seeded weights, there is no
+    trained checkpoint): WAV -> GPU log-mel (1022 frames) -> 984 windows [984,7,80] -> model -> boosted probabilities,
+    against the oracle on the oracle's log-mel; `predict` emits JSON v0.3; `evaluate` reads the clip's own labels."""
+    import json
+    from pathlib import Path
+
+    from oracle import logmel, oracle
+    from voice_activity_detection_amd import VADFromScratchPredictor, VADPredictParameters
+    from voice_activity_detection_amd.data_models import VoiceActivity
+    from voice_activity_detection_amd.evaluate import evaluate_vad_from_scratch
+    from voice_activity_detection_amd.features import load_wav_mono16k, log_mel
+    from voice_activity_detection_amd.metrics import roc_auc
+
+    torch = torch_cuda
+    root = Path(__file__).resolve().parent / "golden" / "data"
+    wav = root / "WhenTheWeatherIsFine" / "When_the_Weather_Is_Fine_12_4.wav"
+    audio = load_wav_mono16k(wav)
+    feat = log_mel(audio)
+    assert feat.shape == (1022, 80)
+    pred = VADFromScratchPredictor(model, "cuda")
+    probs = pred.predict_probabilities(feat)
+    ref_probs, ref_mean = oracle.predict_probabilities(state1234, logmel.log_mel(audio))
+    assert probs.shape == (1022, 7) and np.abs(probs - ref_probs).max() < 1e-4
+    assert (probs[:19, 3] == 0.5).all() and (probs[-19:, 3] == 0.5).all()  # no window is centred there: the slot stays [0,0] -> 0.5
+    va = pred.predict_from_path(wav, VADPredictParameters(threshold=0.5, min_vally_ms=100, hang_over_ms=50, return_probs=True,
+                                                          probs_sample_rate=100))
+    va.save(tmp_path / "va.json")
+    back = json.loads((tmp_path / "va.json").read_text())
+    assert back["version"] == "v0.3" and back["duration"] == "00:00:10.213" and back["probs_sample_rate"] == 100
+    # frames -> samples at 100 Hz: int((1022 - 1) * 1 + 2.5) (vad/postprocessing/convert.py:6-24)
+    assert len(back["probs"]) == 1023 and VoiceActivity.load(tmp_path / "va.json").to_json() == back
+    cfg = {"model": {"name": "self-attention", "self_attention": {"num_layers": 3, "d_model": 128, "dropout": 0.5}},
+           "feature_extractor": {"transform": {"n_mels": 80}},
+           "context_resolution": {"context_window_half_frames": 19, "context_window_jump_frames": 9}}
+    torch.save({"config": cfg, "state_dict": {k: torch.from_numpy(v) for k, v in state1234.items()}}, tmp_path / "model.checkpoint")
+    out = evaluate_vad_from_scratch(root / "eval_list.jsonl", tmp_path / "model.checkpoint", tmp_path / "eval.jsonl", echo=lambda s: None)
+    labels = VoiceActivity.load(root / "WhenTheWeatherIsFine" / "voice_activity.json").to_labels(100)
+    assert abs(out["files"][0]["auc"] - roc_auc(labels, ref_mean[: len(labels)])) < 1e-3
+    assert 0.0 <= out["total"]["boosted_auc"] <= 1.0 and len((tmp_path / "eval.jsonl").read_text().splitlines()) == 2
+
+
 def test_config3_size_batch(torch_cuda, model, state1234):
     """BASELINE configs[2]/[3] per-GPU size [256,800,80]: sampled sequences against the oracle (fp32 path and
     bf16 path), plus the size-independent properties on the whole batch."""
