@@ -675,8 +675,17 @@ def test_config1_reference_clip_end_to_end(torch_cuda, model, state1234, tmp_pat
     torch.save({"config": cfg, "state_dict": {k: torch.from_numpy(v) for k, v in state1234.items()}}, tmp_path / "model.checkpoint")
     out = evaluate_vad_from_scratch(root / "eval_list.jsonl", tmp_path / "model.checkpoint", tmp_path / "eval.jsonl", echo=lambda s: None)
     labels = VoiceActivity.load(root / "WhenTheWeatherIsFine" / "voice_activity.json").to_labels(100)
-    assert abs(out["files"][0]["auc"] - roc_auc(labels, ref_mean[: len(labels)])) < 1e-3
+    auc_ref = roc_auc(labels, ref_mean[: len(labels)])
+    assert abs(out["files"][0]["auc"] - auc_ref) < 1e-3
     assert 0.0 <= out["total"]["boosted_auc"] <= 1.0 and len((tmp_path / "eval.jsonl").read_text().splitlines()) == 2
+    # north_star: per-frame AUC within 1e-3 of the reference's -- also with bf16 operands, on real audio and real labels
+    model.precision = "bf16"
+    try:
+        probs_bf16 = pred.predict_probabilities(feat)
+    finally:
+        model.precision = "fp32"
+    assert abs(roc_auc(labels, probs_bf16.mean(axis=1)[: len(labels)]) - auc_ref) < 1e-3
+    assert np.abs(probs_bf16 - ref_probs).max() < 5e-3
 
 
 def test_config3_size_batch(torch_cuda, model, state1234):
