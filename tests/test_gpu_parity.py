@@ -675,6 +675,15 @@ def test_config1_reference_clip_end_to_end(torch_cuda, model, state1234, tmp_pat
     torch.save({"config": cfg, "state_dict": {k: torch.from_numpy(v) for k, v in state1234.items()}}, tmp_path / "model.checkpoint")
     out = evaluate_vad_from_scratch(root / "eval_list.jsonl", tmp_path / "model.checkpoint", tmp_path / "eval.jsonl", echo=lambda s: None)
     labels = VoiceActivity.load(root / "WhenTheWeatherIsFine" / "voice_activity.json").to_labels(100)
+    # the CLI (python main.py predict ... / evaluate ...: main.py:8-10) gives the same JSON as the API calls above
+    from voice_activity_detection_amd.__main__ import main as cli
+
+    assert cli(["predict", str(wav), str(tmp_path / "model.checkpoint"), "--output-path", str(tmp_path / "cli" / "va.json"),
+                "--min-vally-ms", "100", "--hang-over-ms", "50", "--return-probs", "--probs-sample-rate", "100"]) == 0
+    assert json.loads((tmp_path / "cli" / "va.json").read_text()) == back
+    assert cli(["evaluate", str(root / "eval_list.jsonl"), str(tmp_path / "model.checkpoint"), "--output-path",
+                str(tmp_path / "cli" / "eval.jsonl")]) == 0
+    assert (tmp_path / "cli" / "eval.jsonl").read_text() == (tmp_path / "eval.jsonl").read_text()
     auc_ref = roc_auc(labels, ref_mean[: len(labels)])
     assert abs(out["files"][0]["auc"] - auc_ref) < 1e-3
     assert 0.0 <= out["total"]["boosted_auc"] <= 1.0 and len((tmp_path / "eval.jsonl").read_text().splitlines()) == 2
