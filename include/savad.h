@@ -17,8 +17,11 @@
  * stated; row-major contiguous; fp32.  Every call returns 0 on success or a negative
  * SAVAD_E_* code, with a thread-local message in savad_last_error().  Kernels are enqueued
  * on the caller's HIP stream (`stream` is a hipStream_t passed as void*; NULL = default
- * stream); nothing here synchronises the device or allocates device memory inside
- * savad_forward (the caller supplies the workspace).
+ * stream).  savad_forward allocates no device memory and never synchronises (the caller supplies the
+ * workspace) for every T covered by an earlier savad_reserve(h, T_max); a longer T first grows the
+ * library's positional-encoding table on that call (one hipMalloc + one stream synchronisation, the
+ * counterpart of the reference's cache growth: vad/modeling/transformer.py:392-397), and the first
+ * forward after savad_set_param enqueues the weight re-packing kernels on `stream`.
  */
 #ifndef SAVAD_H
 #define SAVAD_H
@@ -65,6 +68,11 @@ int savad_set_param(savad_handle h, const char* key, const float* data, size_t n
 int savad_num_params(savad_handle h);
 const char* savad_param_key(savad_handle h, int i);
 size_t savad_param_numel(savad_handle h, int i);
+
+/* Pre-sizes the positional-encoding table (vad/modeling/transformer.py:392-397: the reference grows its cache
+ * when T exceeds it) for sequences of up to T_max frames, so that savad_forward with T <= T_max neither
+ * allocates nor synchronises.  May allocate and synchronise `stream` itself. */
+int savad_reserve(savad_handle h, int T_max, void* stream);
 
 /* Bytes of scratch savad_forward needs for a [B,T,F] batch (activations + attention partials). */
 int savad_workspace_bytes(savad_handle h, int B, int T, size_t* bytes);

@@ -90,10 +90,17 @@ for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
                     cnt[short(row["Kernel_Name"])] += 1
         for k in acc:
             traffic.setdefault(k, {})[cname + "_KB_per_launch"] = acc[k] / cnt[k]
-for k, v in traffic.items():
+for k, v in list(traffic.items()):
     # MI355X_MICROARCH.md (HBM): FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950 -> doubled;
     # WRITE_SIZE is taken as reported (uncalibrated).  Units: KB.
     v["hbm_bytes_per_launch"] = (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
 if traffic:
+    # stamp the kernel sources the counters were measured on: bench.py quotes the traffic only for matching code
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from bench import kernel_source_hash
+        traffic["csrc_hash"] = kernel_source_hash()
+    except Exception as exc:  # noqa: BLE001
+        print("could not stamp csrc_hash:", exc)
     with open(os.path.join(out, "traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1, sort_keys=True)

@@ -103,3 +103,34 @@ def test_roc_auc_matches_definition():
     y = rng.integers(0, 2, 500)
     s = rng.random(500)
     assert abs(roc_auc(y, s) - roc_auc_score(y, s)) < 1e-12
+
+
+def test_module_copies_and_pickles_drop_runtime_state(state1234):
+    """copy.deepcopy / pickle of the module (the ctypes handle and the cached workspace are per-process runtime state and
+    are recreated lazily), and the weight re-push triggers that do not need a GPU to check."""
+    import copy
+    import ctypes
+    import pickle
+
+    import torch
+
+    from voice_activity_detection_amd import SelfAttentiveVAD
+
+    m = SelfAttentiveVAD(80, 3, 128, 0.5)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state1234.items()})
+    m._handle = ctypes.c_void_p(1234)  # what a forward leaves behind (never dereferenced here)
+    m._workspace, m._synced_versions = torch.zeros(4), m._param_versions()
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert clone._handle is None and clone._workspace is None and clone._synced_versions is None
+        assert all(torch.equal(a, b) for a, b in zip(clone.state_dict().values(), m.state_dict().values()))
+        assert clone.precision == "fp32" and clone.feature_size == 80
+    synced = m._synced_versions
+    m.classifier.bias.data.add_(1.0)  # invisible to (data_ptr, _version) ...
+    assert m._param_versions() == synced
+    m.eval()                          # ... so mode switches force a re-push
+    assert m._synced_versions is None
+    m._synced_versions = m._param_versions()
+    with torch.no_grad():
+        m.classifier.bias.add_(1.0)   # ordinary in-place edits are seen
+    assert m._param_versions() != m._synced_versions
+    m._handle = None  # nothing real to destroy

@@ -67,3 +67,59 @@ def test_two_rank_gloo_matches_unsharded(tmp_path, batch):
         assert np.abs(y - ref).max() < 1e-6  # same ATen ops on a sub-batch
     sizes = [int(np.load(tmp_path / f"n{r}.npy").sum()) for r in range(world)]
     assert sum(sizes) == batch and max(sizes) - min(sizes) <= 1
+
+
+def _stream_worker(rank, world, port, n_frames, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle, torch_port
+    from voice_activity_detection_amd.distributed import sharded_rows
+    from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
+
+    T, hop = 24, 12
+    state_np = seeded_state_dict(1234)
+    state = {k: torch.from_numpy(v) for k, v in state_np.items()}
+    feat = seeded_features(5, (n_frames, 80))
+    W = oracle.lib().savad_oracle_stream_window_count(n_frames, T, hop)
+    spans = []
+
+    def windows_logp(lo, hi):  # the CPU stand-in of StreamingPredictor.predict_device's closure: same contract
+        spans.append((lo, hi))
+        win = np.zeros((hi - lo, T, 80), np.float32)
+        for w in range(lo, hi):
+            seg = feat[hop * w: hop * w + T]
+            win[w - lo, : len(seg)] = seg
+        return torch_port.forward(state, torch.from_numpy(win))
+
+    logp = sharded_rows(W, windows_logp, (T, 2), torch.float32, torch.device("cpu"))
+    np.save(os.path.join(out_dir, f"logp{rank}.npy"), logp.numpy())
+    np.save(os.path.join(out_dir, f"span{rank}.npy"), np.array(spans))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [24 + 12 * 4, 24 + 12 * 3 + 5, 10])
+def test_two_rank_streaming_shard_and_merge(tmp_path, n_frames):
+    """The sharded branch of StreamingPredictor (configs[4]): windows split contiguously over 2 ranks, ONE all_gather of the
+    log-probs (uneven split and the single-window case included), then the overlap merge -- against the unsharded oracle."""
+    import ctypes
+
+    from oracle import oracle
+    from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
+
+    world, T, hop = 2, 24, 12
+    mp.spawn(_stream_worker, args=(world, _free_port(), n_frames, str(tmp_path)), nprocs=world, join=True)
+    ref_probs, ref_logp = oracle.predict_streaming(seeded_state_dict(1234), seeded_features(5, (n_frames, 80)), T=T, hop=hop)
+    W = ref_logp.shape[0]
+    covered = []
+    for r in range(world):
+        logp = np.load(tmp_path / f"logp{r}.npy")
+        assert logp.shape == ref_logp.shape and np.abs(logp - ref_logp).max() < 2e-5
+        probs = np.empty((n_frames,), np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        oracle.lib().savad_oracle_overlap_merge(np.ascontiguousarray(logp).ctypes.data_as(fp), W, n_frames, T, hop, probs.ctypes.data_as(fp))
+        assert np.abs(probs - ref_probs).max() < 2e-5
+        covered += [tuple(s) for s in np.load(tmp_path / f"span{r}.npy").reshape(-1, 2)]
+    covered.sort()
+    assert covered[0][0] == 0 and covered[-1][1] == W and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))

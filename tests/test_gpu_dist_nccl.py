@@ -1,0 +1,130 @@
+"""The multi-GPU path on the REAL backend: `torch.distributed` with backend "nccl" (= RCCL on ROCm) initialised in
+this process with world_size 1 -- the largest world a 1-GPU box offers -- and the product's own collective code
+(voice_activity_detection_amd.distributed: forward_sharded, all_gather_rows, sharded_rows; the sharded branch of
+StreamingPredictor.predict_device) pushed through it, against the unsharded results.  The world-size-2 logic
+(uneven splits, empty shards) is covered on CPU by tests/test_dist_gloo.py; the 8-GPU run itself belongs to the
+driver's scaling bench.  SURVEY.md section 8e: weights replicated, sequences split contiguously, ONE all_gather."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (torch.cuda.is_available() is False)")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def model(torch_cuda, state1234):
+    from voice_activity_detection_amd import SelfAttentiveVAD
+
+    m = SelfAttentiveVAD(80, 3, 128, 0.5)
+    m.load_state_dict({k: torch_cuda.from_numpy(v) for k, v in state1234.items()}, strict=True)
+    return m.to("cuda").eval()
+
+
+@pytest.fixture()
+def rccl(torch_cuda):
+    """A world-size-1 RCCL process group for the duration of ONE test (other tests must see no process group)."""
+    import torch.distributed as dist
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch_cuda.device("cuda", 0))
+    assert dist.get_backend() == "nccl"
+    try:
+        yield dist
+    finally:
+        torch_cuda.cuda.synchronize()
+        dist.destroy_process_group()
+
+
+def feats(seed, shape):
+    from voice_activity_detection_amd.seeded import seeded_features
+
+    return seeded_features(seed, shape)
+
+
+def test_forward_sharded_through_rccl(torch_cuda, model, state1234, rccl):
+    from oracle import oracle
+    from voice_activity_detection_amd.distributed import forward_sharded
+
+    torch = torch_cuda
+    x = feats(21, (5, 96, 80))
+    xd = torch.from_numpy(x).cuda()
+    calls = []
+
+    def fwd(t):
+        calls.append(tuple(t.shape))
+        with torch.no_grad():
+            return model(features=t)
+
+    y = forward_sharded(fwd, xd)
+    torch.cuda.synchronize()
+    assert calls == [(5, 96, 80)] and y.shape == (5, 96, 2) and y.is_cuda
+    with torch.no_grad():
+        direct = model(features=xd)
+    assert torch.equal(y, direct)  # the gather moved the bits, nothing else
+    assert np.abs(y.cpu().numpy() - oracle.forward(state1234, x)).max() < 3e-5
+
+
+def test_all_gather_rows_and_barrier_through_rccl(torch_cuda, rccl):
+    from voice_activity_detection_amd.distributed import all_gather_rows, sharded_rows
+
+    torch = torch_cuda
+    local = torch.arange(7 * 6, dtype=torch.float32, device="cuda").reshape(7, 3, 2)
+    got = all_gather_rows(local, 7)
+    rccl.barrier()
+    assert torch.equal(got, local) and got.data_ptr() != local.data_ptr()
+    nonc = torch.arange(14 * 6, dtype=torch.float32, device="cuda").reshape(14, 3, 2)[::2]  # a strided shard is padded/copied
+    assert torch.equal(all_gather_rows(nonc, 7), nonc)
+    got2 = sharded_rows(7, lambda lo, hi: local[lo:hi] * 2, (3, 2), torch.float32, local.device)
+    assert torch.equal(got2, local * 2)
+    t = torch.ones(4, device="cuda")
+    rccl.all_reduce(t)  # the bench's max-over-ranks reduction uses the same group
+    assert float(t.sum()) == 4.0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_streaming_predictor_sharded_branch_through_rccl(torch_cuda, model, state1234, precision):
+    """configs[4]: the long-form predictor's window sharding + single all_gather + overlap merge with a live RCCL
+    group must reproduce the run without a process group bit for bit, and the oracle within tolerance."""
+    import torch.distributed as dist
+
+    from oracle import oracle
+    from voice_activity_detection_amd.predictor import StreamingPredictor
+
+    torch = torch_cuda
+    feat = feats(33, (96 * 3 + 17, 80))
+    model.precision = precision
+    try:
+        sp = StreamingPredictor(model, "cuda", T=96, hop=48, max_batch=4)
+        assert not dist.is_initialized()
+        plain = sp.predict_device(feat).clone()
+        # (fixture used by hand so that the un-initialised run above comes first in the same test)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        try:
+            sharded = sp.predict_device(feat)
+            torch.cuda.synchronize()
+        finally:
+            dist.destroy_process_group()
+    finally:
+        model.precision = "fp32"
+    assert torch.equal(plain, sharded)
+    ref, _ = oracle.predict_streaming(state1234, feat, T=96, hop=48)
+    assert np.abs(sharded.cpu().numpy() - ref).max() < (1e-4 if precision == "fp32" else 2e-2)

@@ -352,6 +352,31 @@ def test_pe_cache_growth(torch_cuda, state1234):
         assert np.abs(run(torch_cuda, m, x) - oracle.forward(state1234, x)).max() < TIGHT
 
 
+def test_reserve_makes_forward_capturable(torch_cuda, state1234):
+    """include/savad.h: after savad_reserve(h, T_max) a forward with T <= T_max neither allocates nor synchronises --
+    checked the hard way: it is captured into a HIP graph (capture fails on hipMalloc / hipStreamSynchronize) and the
+    replayed graph reproduces the eager result bit for bit."""
+    from oracle import oracle
+
+    torch = torch_cuda
+    m = make_model(torch, state1234)
+    m.reserve(512)
+    x = feats(77, (3, 300, 80))
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((3, 300, 2), dtype=torch.float32, device="cuda")
+    with torch.no_grad():
+        eager = m(features=xd).clone()  # packs the weights, sizes the torch-owned workspace
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            m(features=xd, out=out)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    assert np.abs(out.cpu().numpy() - oracle.forward(state1234, x)).max() < TIGHT
+
+
 def test_weight_update_is_seen(torch_cuda, state1234):
     from oracle import oracle
     from voice_activity_detection_amd.seeded import seeded_state_dict
@@ -614,10 +639,9 @@ def test_evaluate_command_end_to_end(torch_cuda, state1234, tmp_path):
     from voice_activity_detection_amd.metrics import roc_auc
 
     torch = torch_cuda
-    cfg = {"model": {"name": "self-attention", "self_attention": {"num_layers": 3, "d_model": 128, "dropout": 0.5}},
-           "feature_extractor": {"transform": {"n_mels": 80}},
-           "context_resolution": {"context_window_half_frames": 19, "context_window_jump_frames": 9}}
-    torch.save({"config": cfg, "state_dict": {k: torch.from_numpy(v) for k, v in state1234.items()}}, tmp_path / "model.checkpoint")
+    from tests.conftest import write_reference_checkpoint
+
+    write_reference_checkpoint(tmp_path / "model.checkpoint", state1234)
     rng = np.random.default_rng(9)
     pcm = (rng.standard_normal(16000 * 4) * 2500 * (1 + np.sin(np.arange(64000) / 4000.0))).astype(np.int16)
     with wave.open(str(tmp_path / "clip.wav"), "wb") as w:
@@ -669,10 +693,9 @@ def test_config1_reference_clip_end_to_end(torch_cuda, model, state1234, tmp_pat
     assert back["version"] == "v0.3" and back["duration"] == "00:00:10.213" and back["probs_sample_rate"] == 100
     # frames -> samples at 100 Hz: int((1022 - 1) * 1 + 2.5) (vad/postprocessing/convert.py:6-24)
     assert len(back["probs"]) == 1023 and VoiceActivity.load(tmp_path / "va.json").to_json() == back
-    cfg = {"model": {"name": "self-attention", "self_attention": {"num_layers": 3, "d_model": 128, "dropout": 0.5}},
-           "feature_extractor": {"transform": {"n_mels": 80}},
-           "context_resolution": {"context_window_half_frames": 19, "context_window_jump_frames": 9}}
-    torch.save({"config": cfg, "state_dict": {k: torch.from_numpy(v) for k, v in state1234.items()}}, tmp_path / "model.checkpoint")
+    from tests.conftest import write_reference_checkpoint
+
+    write_reference_checkpoint(tmp_path / "model.checkpoint", state1234)
     out = evaluate_vad_from_scratch(root / "eval_list.jsonl", tmp_path / "model.checkpoint", tmp_path / "eval.jsonl", echo=lambda s: None)
     labels = VoiceActivity.load(root / "WhenTheWeatherIsFine" / "voice_activity.json").to_labels(100)
     # the CLI (python main.py predict ... / evaluate ...: main.py:8-10) gives the same JSON as the API calls above

@@ -112,10 +112,9 @@ def test_predict_cli_writes_json_v03(tmp_path, state1234):
     from voice_activity_detection_amd.__main__ import main
     from voice_activity_detection_amd.data_models import VoiceActivity
 
-    cfg = {"model": {"name": "self-attention", "self_attention": {"num_layers": 3, "d_model": 128, "dropout": 0.5}},
-           "context_resolution": {"context_window_half_frames": 19, "context_window_jump_frames": 9},
-           "feature_extractor": {"transform": {"name": "log-mel", "n_fft": 512, "hop_ms": 10, "window_ms": 25, "n_mels": 80}}}
-    torch.save({"config": cfg, "state_dict": {k: torch.from_numpy(v) for k, v in state1234.items()}}, tmp_path / "m.checkpoint")
+    from tests.conftest import write_reference_checkpoint
+
+    write_reference_checkpoint(tmp_path / "m.checkpoint", state1234)
     pcm = (_audio(0, 6.0) * 20000).astype(np.int16)
     with wave.open(str(tmp_path / "a.wav"), "wb") as w:
         w.setnchannels(1)
@@ -199,3 +198,52 @@ def test_reference_clip_fixture_host_side():
     labels = va.to_labels(100)
     assert len(va.activities) == 5 and len(labels) == 1021 and 0 < labels.mean() < 1
     assert VoiceActivity.from_json(va.to_json()).to_json() == va.to_json()  # JSON v0.3 round trip
+
+
+def test_voice_activity_formats_match_reference():
+    """Every VoiceActivity reader / writer (vad/data_models/voice_activity.py:49-237: JSON v0.1, v0.2 timecode and
+    millisecond, v0.3; milliseconds v0.2, v0.3) against documents written and re-read by the reference's own class
+    (tests/golden/make_golden_formats.py)."""
+    from voice_activity_detection_amd.data_models import VoiceActivity
+
+    cases = json.loads((Path(__file__).resolve().parent / "golden" / "golden_formats.json").read_text())
+    assert len(cases) == 8
+    for c in cases:
+        va = VoiceActivity.from_json(c["docs"]["json_v0.3"])
+        assert va.to_json("v0.1") == c["docs"]["json_v0.1"] and va.to_json("v0.2") == c["docs"]["json_v0.2"]
+        assert va.to_json() == c["docs"]["json_v0.3"]
+        assert va.to_milliseconds("v0.2") == c["docs"]["ms_v0.2"] and va.to_milliseconds("v0.3") == c["docs"]["ms_v0.3"]
+        for k, doc in c["docs"].items():
+            back = VoiceActivity.from_milliseconds(doc) if k == "ms_v0.3" else VoiceActivity.from_json(doc)
+            assert back.to_json() == c["read"][k]["as_v0.3"], k
+            lab = back.to_labels(100)
+            assert int(lab.sum()) == c["read"][k]["label_sum"] and len(lab) == c["read"][k]["n_labels"]
+        assert VoiceActivity.from_milliseconds(c["docs"]["ms_v0.2"]).to_json() == c["read"]["ms_v0.2_via_from_milliseconds"]
+    import pytest
+
+    with pytest.raises(NotImplementedError):
+        VoiceActivity.from_json({"version": "v9"})
+
+
+def test_from_checkpoint_reads_reference_checkpoints_and_refuses_other_transforms(tmp_path, state1234):
+    """vad/predictor.py:264-280 on a checkpoint with the reference ModelCheckpointer's full key set (numpy-scalar
+    metrics, optimizer state ...: torch.load's weights_only default would refuse it), and a clear error -- not a late
+    shape error or silently wrong features -- for feature configurations the device front-end does not implement."""
+    import copy
+
+    from tests.conftest import REFERENCE_CONFIG, write_reference_checkpoint
+    from voice_activity_detection_amd.predictor import VADFromScratchPredictor
+
+    p = VADFromScratchPredictor.from_checkpoint(write_reference_checkpoint(tmp_path / "ok.checkpoint", state1234), "cpu")
+    assert (p.hop_ms, p.window_ms, p.context_window_frames) == (10, 25, 7)
+    assert sorted(p.model.state_dict()) == sorted(state1234)
+    for path, value in ((("transform", "hop_ms"), 20), (("transform", "n_fft"), 1024), (("transform", "name"), "mfcc"),
+                        (("transform", "n_mels"), 40), (("temporal_differences",), True),
+                        (("silence_remover",), {"silence_threshold": 0.1})):
+        cfg = copy.deepcopy(REFERENCE_CONFIG)
+        node = cfg["feature_extractor"]
+        for key in path[:-1]:
+            node = node[key]
+        node[path[-1]] = value
+        with pytest.raises(NotImplementedError, match="unsupported"):
+            VADFromScratchPredictor.from_checkpoint(write_reference_checkpoint(tmp_path / "bad.checkpoint", state1234, cfg), "cpu")

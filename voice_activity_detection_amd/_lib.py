@@ -28,6 +28,7 @@ SYMBOLS = {
     "savad_num_params": (c_int, [c_void_p]),
     "savad_param_key": (c_char_p, [c_void_p, c_int]),
     "savad_param_numel": (c_size_t, [c_void_p, c_int]),
+    "savad_reserve": (c_int, [c_void_p, c_int, c_void_p]),
     "savad_workspace_bytes": (c_int, [c_void_p, c_int, c_int, POINTER(c_size_t)]),
     "savad_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "savad_set_precision": (c_int, [c_void_p, c_int]),

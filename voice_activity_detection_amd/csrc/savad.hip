@@ -514,6 +514,14 @@ SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* byt
     return SAVAD_OK;
 }
 
+// Sizes everything savad_forward may otherwise have to (re)allocate for sequences of up to T_max frames -- today the
+// positional-encoding table -- so that later forwards with T <= T_max neither allocate nor synchronise.
+SAVAD_EXPORT int savad_reserve(savad_handle m, int T_max, void* stream) {
+    if (!m || T_max < 0) return fail(SAVAD_E_INVALID, "bad argument");
+    if ((double)T_max * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "T_max=%d too large", T_max);
+    return ensure_pe(m, T_max, (hipStream_t)stream);
+}
+
 SAVAD_EXPORT int savad_set_precision(savad_handle m, int precision) {
     if (!m || precision < 0 || precision > 1) return fail(SAVAD_E_INVALID, "precision %d (0 = fp32, 1 = bf16)", precision);
     m->precision = precision;

@@ -26,15 +26,24 @@ def forward_sharded(forward: Callable[[torch.Tensor], torch.Tensor], features: t
                     group=None) -> torch.Tensor:
     """`features` is the GLOBAL batch [B, T, F] (same on every rank, or at least this rank's
     slice valid); every rank evaluates its shard with `forward` and receives the full
-    [B, T, 2] log-probabilities.  One collective per call."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    [B, T, 2] log-probabilities.  One collective per call (also with a single rank whenever a process
+    group exists, so that the code path on an N-GPU node is the one a 1-GPU run exercises)."""
     B, T = features.shape[0], features.shape[1]
-    lo, hi = shard_bounds(B, rank, world)
-    local = forward(features[lo:hi]) if hi > lo else features.new_zeros((0, T, 2), dtype=torch.float32)
-    if world == 1:
-        return local
-    return all_gather_rows(local, B, group)
+    return sharded_rows(B, lambda lo, hi: forward(features[lo:hi]), (T, 2), torch.float32, features.device, group)
+
+
+def sharded_rows(total_rows: int, compute: Callable[[int, int], torch.Tensor], tail: Tuple[int, ...], dtype, device,
+                 group=None) -> torch.Tensor:
+    """The whole multi-GPU pattern of this path: rows [0, total_rows) (sequences of a batch, windows of a long
+    recording) are split contiguously over the ranks (shard_bounds), rank r evaluates `compute(lo, hi)` ->
+    [hi - lo, *tail] for its own span only, and ONE all_gather hands every rank all rows.  Without an initialised
+    process group it is just compute(0, total_rows)."""
+    if not dist.is_initialized():
+        return compute(0, total_rows)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(total_rows, rank, world)
+    local = compute(lo, hi) if hi > lo else torch.zeros((0,) + tuple(tail), dtype=dtype, device=device)
+    return all_gather_rows(local, total_rows, group)
 
 
 def all_gather_rows(local: torch.Tensor, total_rows: int, group=None) -> torch.Tensor:
@@ -43,8 +52,11 @@ def all_gather_rows(local: torch.Tensor, total_rows: int, group=None) -> torch.T
     world = dist.get_world_size(group)
     per = -(-total_rows // world)  # ceil
     tail = tuple(local.shape[1:])
-    padded = local.new_zeros((per,) + tail)
-    padded[: local.shape[0]] = local
+    if local.shape[0] == per and local.is_contiguous():
+        padded = local
+    else:
+        padded = local.new_zeros((per,) + tail)
+        padded[: local.shape[0]] = local
     gathered = local.new_empty((world * per,) + tail)
     dist.all_gather_into_tensor(gathered, padded, group=group)
     if total_rows % world == 0:

@@ -97,21 +97,3 @@ def precision_recall(labels, predictions):
     predictions = np.asarray(predictions).astype(bool)
     tp = float((labels & predictions).sum())
     return (tp / predictions.sum() if predictions.sum() else 0.0), (tp / labels.sum() if labels.sum() else 0.0)
-
-
-def evaluate_file(true_labels, all_frame_probabilities, threshold: float = 0.5) -> dict:
-    """Per-file metrics of vad/evaluate.py:56-80 from the label vector (VoiceActivity.to_labels(100)) and the
-    [N, W] probability matrix predict_probabilities returns: single-frame = middle column, boosted = row mean."""
-    p = np.asarray(all_frame_probabilities)
-    y = np.asarray(true_labels)
-    single = p[:, int(p.shape[1] / 2)][: len(y)]
-    boosted = p.mean(axis=1)[: len(y)]
-    y = y[: len(boosted)]
-    sp, bp_ = single > threshold, boosted > threshold
-    prec, rec = precision_recall(y, bp_)
-    vacc, acc, sba, eba, bp = vad_accuracy(y, sp)
-    bvacc, bacc, bsba, beba, bbp = vad_accuracy(y, bp_)
-    return {"auc": roc_auc(y, boosted), "accuracy": float((y.astype(bool) == bp_).mean()), "precision": prec, "recall": rec,
-            "vacc": vacc, "acc": acc, "sba": sba, "eba": eba, "bp": bp, "eer": equal_error_rate(y, sp),
-            "boosted_vacc": bvacc, "boosted_acc": bacc, "boosted_sba": bsba, "boosted_eba": beba, "boosted_bp": bbp,
-            "boosted_eer": equal_error_rate(y, bp_)}

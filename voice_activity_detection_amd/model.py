@@ -110,12 +110,36 @@ class SelfAttentiveVAD(nn.Module):
         except Exception:
             pass
 
+    # The library handle, its device and the cached workspace are per-process runtime state: copies and pickles of
+    # the module (copy.deepcopy, torch.save(model), nn.DataParallel replicas) drop them and recreate them lazily.
+    _RUNTIME_ATTRS = ("_handle", "_handle_device", "_synced_versions", "_workspace")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for name in self._RUNTIME_ATTRS:
+            state[name] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        for name in self._RUNTIME_ATTRS:
+            self.__dict__.setdefault(name, None)
+
+    def train(self, mode: bool = True):
+        # switching modes is where parameters were most likely edited behind autograd's back (p.data.copy_ in EMA /
+        # init code leaves data_ptr and _version unchanged): re-push the weights at the next forward
+        self._synced_versions = None
+        return super().train(mode)
+
     def _param_versions(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def sync_weights(self, force: bool = False):
-        """Push the module's parameters into the library's packed weight store when they changed
-        (load_state_dict / .to() / in-place edits all bump data_ptr or _version)."""
+        """Push the module's parameters into the library's packed weight store when they changed.  Changes are detected
+        through (data_ptr, _version): load_state_dict, .to(), optimizer steps and in-place tensor ops are all caught.
+        NOT caught: writes through `.data` / `.detach()` views (p.data.mul_(...), p.data.copy_(...)), which bump neither --
+        call `model.sync_weights(force=True)` after such edits (`.train()` / `.eval()` also force a re-push).
+        One module instance = one library handle + one cached workspace: use it from one stream at a time."""
         versions = self._param_versions()
         if not force and versions == self._synced_versions:
             return
@@ -181,6 +205,15 @@ class SelfAttentiveVAD(nn.Module):
                                             ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
                                             ws.numel(), ctypes.c_void_p(stream)))
         return out
+
+    def reserve(self, max_frames: int, device=None):
+        """Pre-size the library's positional-encoding table for sequences of up to `max_frames` frames (savad_reserve):
+        forwards with T <= max_frames then run without any allocation or synchronisation inside the library."""
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        with torch.cuda.device(device):
+            self._ensure_handle(device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(_lib.load().savad_reserve(self._handle, int(max_frames), ctypes.c_void_p(stream)))
 
     # ---- profiling hooks used by bench.py -------------------------------------------------------
     def set_profiling(self, capacity: int):

@@ -79,25 +79,52 @@ class VADFromScratchPredictor:
 
     @classmethod
     def from_checkpoint(cls, checkpoint_path, device):
-        """vad/predictor.py:264-280: a training checkpoint holds {"config": ..., "state_dict": ...}; the model size
-        and the window geometry come from the config, the weights load strictly."""
-        ckpt = torch.load(checkpoint_path, map_location="cpu")
+        """vad/predictor.py:264-280: a training checkpoint holds {"config": ..., "state_dict": ...} plus what
+        ModelCheckpointer adds (epoch, global_step, monitor_metric, a `metrics` dict of numpy scalars, optimizer /
+        scheduler / grad-scaler state: vad/training/checkpointers/model_checkpointer.py:97-110); the model size, the
+        feature transform and the window geometry come from the config, the weights load strictly.  Like the
+        reference's plain torch.load, the file is unpickled in full (weights_only=False: numpy scalars are not on
+        torch's safe list) -- load only checkpoints you trust."""
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
         cfg = ckpt["config"]
 
-        def get(c, *names):
+        def get(c, *names, default=None):
             for n in names:
-                c = c[n] if isinstance(c, dict) else getattr(c, n)
+                if isinstance(c, dict):
+                    if n not in c:
+                        return default
+                    c = c[n]
+                elif hasattr(c, n):
+                    c = getattr(c, n)
+                else:
+                    return default
             return c
 
         if get(cfg, "model", "name") != "self-attention":
             raise NotImplementedError("only the self-attention model is built for MI355X")
         sa = get(cfg, "model", "self_attention")
-        n_mels = get(cfg, "feature_extractor", "transform", "n_mels")
-        model = SelfAttentiveVAD(n_mels, get(sa, "num_layers"), get(sa, "d_model"), get(sa, "dropout"))
+        # The device front-end (savad_logmel) implements the reference's one shipped transform configuration
+        # (tests/configs/vad/train_config.yaml:18-28).  Anything else would load cleanly and then produce wrong features
+        # or timings, so it is refused here rather than failing late with a shape error.
+        fe = get(cfg, "feature_extractor")
+        tr = get(fe, "transform")
+        want = {"name": "log-mel", "n_fft": 512, "hop_ms": 10, "window_ms": 25, "n_mels": 80}
+        got = {k: get(tr, k) for k in want}
+        if got != want:
+            raise NotImplementedError(f"unsupported transform {got}: the MI355X front-end implements {want} "
+                                      "(vad/acoustics/transforms/transform_factory.py:30-59 has further transforms)")
+        if get(fe, "temporal_differences", default=False) or get(fe, "stack_differences", default=False):
+            raise NotImplementedError("unsupported feature_extractor: temporal_differences / stack_differences "
+                                      "(vad/acoustics/feature_extractor.py:135-147) are not built")
+        if get(fe, "silence_remover", default=None):
+            raise NotImplementedError("unsupported feature_extractor: silence_remover (vad/acoustics/feature_extractor.py:115-116) is not built")
+        model = SelfAttentiveVAD(got["n_mels"], get(sa, "num_layers"), get(sa, "d_model"), get(sa, "dropout"))
         model.load_state_dict(ckpt["state_dict"])
         ctx = ContextResolution(get(cfg, "context_resolution", "context_window_half_frames"),
                                 get(cfg, "context_resolution", "context_window_jump_frames"))
-        return cls(model.to(device).eval(), device, ctx)
+        predictor = cls(model.to(device).eval(), device, ctx)
+        predictor.hop_ms, predictor.window_ms = got["hop_ms"], got["window_ms"]  # vad/predictor.py:103-104
+        return predictor
 
     def predict_from_path(self, audio_path, parameters: VADPredictParameters) -> VoiceActivity:
         """vad/predictor.py:71-75 (16 kHz PCM WAV only; the reference also resamples via librosa)."""
@@ -203,9 +230,7 @@ class StreamingPredictor:
 
     @torch.no_grad()
     def predict_device(self, feature):
-        import torch.distributed as dist
-
-        from .distributed import all_gather_rows, shard_bounds
+        from .distributed import sharded_rows
 
         lib = _lib.load()
         feat = torch.as_tensor(feature, dtype=torch.float32).to(self.device).contiguous()
@@ -214,22 +239,23 @@ class StreamingPredictor:
         W = lib.savad_stream_window_count(N, T, hop)
         if W < 0:
             _lib.check(W)
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        rank = dist.get_rank() if dist.is_initialized() else 0
-        lo, hi = shard_bounds(W, rank, world)
         self.model.eval()
         with torch.cuda.device(self.device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            local = torch.empty((hi - lo, T, 2), dtype=torch.float32, device=self.device)
-            for first in range(lo, hi, self.max_batch):
-                count = min(self.max_batch, hi - first)
-                win = torch.empty((count, T, F), dtype=torch.float32, device=self.device)
-                _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), N, F, T, hop, first, count,
-                                                    ctypes.c_void_p(win.data_ptr()), stream))
-                local[first - lo:first - lo + count] = self.model(features=win)
-            logp = all_gather_rows(local, W) if world > 1 else local
+
+            def windows_logp(lo, hi):  # this rank's contiguous span of windows -> [hi - lo, T, 2] log-probs
+                local = torch.empty((hi - lo, T, 2), dtype=torch.float32, device=self.device)
+                for first in range(lo, hi, self.max_batch):
+                    count = min(self.max_batch, hi - first)
+                    win = torch.empty((count, T, F), dtype=torch.float32, device=self.device)
+                    _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), N, F, T, hop, first, count,
+                                                        ctypes.c_void_p(win.data_ptr()), stream))
+                    self.model(features=win, out=local[first - lo:first - lo + count])
+                return local
+
+            logp = sharded_rows(W, windows_logp, (T, 2), torch.float32, self.device).contiguous()
             probs = torch.empty((N,), dtype=torch.float32, device=self.device)
-            _lib.check(lib.savad_overlap_merge(ctypes.c_void_p(logp.contiguous().data_ptr()), W, N, T, hop,
+            _lib.check(lib.savad_overlap_merge(ctypes.c_void_p(logp.data_ptr()), W, N, T, hop,
                                                ctypes.c_void_p(probs.data_ptr()), stream))
         return probs
 
