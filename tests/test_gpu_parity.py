@@ -582,6 +582,23 @@ def test_bf16_launch_shapes_identical(torch_cuda, model, shape):
     assert np.array_equal(ys[1], ys[2]) and np.array_equal(ys[1], ys[3]) and np.array_equal(ys[1], ys[0])
 
 
+def test_logmel_device_matches_scipy_fixture(torch_cuda):
+    """The DEVICE log-mel of the reference's test clip against the fixture derived from scipy.signal.stft and the
+    from-the-definition Slaney filterbank (tests/golden/make_golden_logmel.py) -- independent of oracle/logmel.py.
+    librosa itself is absent: the row stays "parity unpinned" against it."""
+    from pathlib import Path
+
+    from voice_activity_detection_amd.features import load_wav_mono16k, log_mel
+
+    here = Path(__file__).resolve().parent
+    y = load_wav_mono16k(here / "golden" / "data" / "WhenTheWeatherIsFine" / "When_the_Weather_Is_Fine_12_4.wav")
+    with np.load(here / "golden" / "golden_logmel.npz") as z:
+        frames, want = z["frames"], z["logmel"]
+    got = log_mel(y).cpu().numpy()[frames]
+    d = np.abs(got - want)
+    assert np.median(d) < 5e-6 and d.max() < 1e-3, (np.median(d), d.max())  # fp32 DFT on the MFMA vs float64 scipy
+
+
 @pytest.mark.parametrize("shape", [(3, 800, 80), (2, 801, 80), (9, 96, 80), (11, 33, 80), (2, 64, 80), (1, 2049, 80), (5, 100, 80),
                                    (7, 65, 80), (40, 200, 80)])
 def test_bf16_second_generation_attention(torch_cuda, model, state1234, shape):
@@ -769,6 +786,47 @@ def test_config1_reference_clip_end_to_end(torch_cuda, model, state1234, tmp_pat
         model.precision = "fp32"
     assert abs(roc_auc(labels, probs_bf16.mean(axis=1)[: len(labels)]) - auc_ref) < 1e-3
     assert np.abs(probs_bf16 - ref_probs).max() < 5e-3
+
+
+def test_auc_parity_on_the_reference_labelled_files(torch_cuda, model, state1234, tmp_path):
+    """AUC parity is defined over the reference's three labelled recordings -- the two
+    JamakeSpeechSample files of its tests/test_evaluate.py:11-31 (70 s, 60 s) and the WhenTheWeatherIsFine clip -- on
+    identical seeded weights: per-frame AUC of the fp32 path AND of the bf16 path within 1e-3 of the CPU oracle's
+    (= the reference arithmetic), through the `evaluate` command's own code path for the fp32 run."""
+    from pathlib import Path
+
+    from oracle import logmel, oracle
+    from tests.conftest import write_reference_checkpoint
+    from voice_activity_detection_amd import VADFromScratchPredictor
+    from voice_activity_detection_amd.data_models import VoiceActivity
+    from voice_activity_detection_amd.evaluate import evaluate_vad_from_scratch, load_data_list
+    from voice_activity_detection_amd.features import load_wav_mono16k, log_mel
+    from voice_activity_detection_amd.metrics import roc_auc
+
+    root = Path(__file__).resolve().parent / "golden" / "data"
+    write_reference_checkpoint(tmp_path / "model.checkpoint", state1234)
+    jam = root / "JamakeSpeechSample"
+    out = evaluate_vad_from_scratch(jam / "vad-train-sample.jsonl", tmp_path / "model.checkpoint", tmp_path / "eval.jsonl", echo=lambda s: None)
+    assert len(out["files"]) == 2 and 0.0 < out["total"]["auc"] < 1.0  # the reference's own assertion is auc > 0.1 on a TRAINED model
+    files = [(jam / p["audio_path"], jam / p["voice_activity_path"]) for p in load_data_list(jam / "vad-train-sample.jsonl")]
+    files.append((root / "WhenTheWeatherIsFine" / "When_the_Weather_Is_Fine_12_4.wav", root / "WhenTheWeatherIsFine" / "voice_activity.json"))
+    pred = VADFromScratchPredictor(model, "cuda")
+    for i, (wav, lab) in enumerate(files):
+        audio = load_wav_mono16k(wav)
+        labels = VoiceActivity.load(lab).to_labels(100)
+        _, ref_mean = oracle.predict_probabilities(state1234, logmel.log_mel(audio))
+        n = min(len(labels), len(ref_mean))
+        auc_ref = roc_auc(labels[:n], ref_mean[:n])
+        feat = log_mel(audio)
+        auc32 = roc_auc(labels[:n], pred.predict_probabilities(feat).mean(axis=1)[:n])
+        model.precision = "bf16"
+        try:
+            auc16 = roc_auc(labels[:n], pred.predict_probabilities(feat).mean(axis=1)[:n])
+        finally:
+            model.precision = "fp32"
+        assert abs(auc32 - auc_ref) < 1e-3 and abs(auc16 - auc_ref) < 1e-3, (wav.name, auc_ref, auc32, auc16)
+        if i < 2:
+            assert abs(out["files"][i]["boosted_auc"] - auc32) < 1e-6
 
 
 def test_config3_size_batch(torch_cuda, model, state1234):

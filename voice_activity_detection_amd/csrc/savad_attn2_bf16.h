@@ -189,6 +189,11 @@ __device__ __forceinline__ void a2_move(f32x16& sc, f32x16& negm, float& l, floa
 }
 
 __device__ __forceinline__ void a2_load_frags8(bf16x8 (&f)[8], const char* p, int lane) {
+    if (SAVAD_ABLATE & 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, 0x3c003c00u, (unsigned)i, 0u});
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] = ldfrag(p + (i * 64 + lane) * 16);
 }
@@ -213,6 +218,12 @@ __device__ __forceinline__ void a2_scores(f32x16& da, f32x16& db, const bf16x8 (
     a2_mfma_s<A2_QB + 28>(db, k[7]);
 }
 
+#ifdef SAVAD_TIMING
+#define A2_T(i) do { tn_ = __builtin_readcyclecounter(); tacc_[i] += tn_ - tp_; tp_ = tn_; } while (0)
+#else
+#define A2_T(i) do {} while (0)
+#endif
+
 // T > 32.  Workgroup = (sequence b, group g of NG): the group's query PAIRS [p0, p1) are processed in rounds of 4
 // (one pair per wave); every round streams the sequence's QB key blocks through the ring.
 __global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __restrict__ qf, const char* __restrict__ kf,
@@ -233,8 +244,12 @@ __global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __r
 
     int issued = 0;
     for (; issued < A2_NRING && issued < GS; ++issued) a2_issue_stage(smem, issued, NST, kseq, vtseq, w, lane);
+#ifdef SAVAD_TIMING
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = __builtin_readcyclecounter(), tn_;
+#endif
 
     for (int r = 0; r < NR; ++r) {
+        A2_T(7);
         const int pair = p0 + 4 * r + w;
         const bool live = pair < p1;              // wave-uniform
         const int qbA = 2 * (live ? pair : p0);
@@ -256,7 +271,9 @@ __global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __r
         float la = 0.0f, lb = 0.0f;               // this lane's half of the row sums
 
         // ---- round start: key stage G0 must have landed (and, for r > 0, everyone is done with the previous round)
+        A2_T(0);
         a2_acquire(issued - 1 > G0);
+        A2_T(1);
         for (; issued < G0 + A2_NRING && issued < GS; ++issued) a2_issue_stage(smem, issued, NST, kseq, vtseq, w, lane);
         if (!live) {  // no query pair in this round: keep the stream and the barriers going
             for (int s = 0; s + 1 < NST; ++s) {
@@ -276,6 +293,7 @@ __global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __r
         a2_load_frags8(kfr, st0 + BLK_BYTES, lane);  // K of tile 1 (T > 32: it exists)
         s1a = s0a;
         s1b = s0b;
+        A2_T(0);
 
         // One tile step: the scores of tile j are in (ca, cb); produces the scores of tile j+1 in (na, nb).
         // FULL (every tile but those of the round's last stage): tile j+1 exists, stage s+1 exists, and the K(j+2)
@@ -342,11 +360,14 @@ __global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __r
 #undef A2_SLOT_A
             la = a2_add(la, ra);
             const bf16x8 pa0 = a2_frag(ua[0], ua[1], ua[2], ua[3]), pa1 = a2_frag(ua[4], ua[5], ua[6], ua[7]);
+            A2_T(2);
             // ---- stage hand-over (even tiles): the next stage has landed; the stage before this one is refilled
             if (tt == 0 && (FULL || s + 1 < NST)) {
                 a2_acquire(issued - 1 > G0 + s + 1);
+                A2_T(1);
                 // everyone still needs stage G0+s (its odd tile): stages up to G0+s+3 fit the ring beside it
                 if (issued < G0 + s + A2_NRING && issued < GS) a2_issue_stage(smem, issued++, NST, kseq, vtseq, w, lane);
+                A2_T(3);
             }
             if (FULL || j + 2 < NT) {
                 const int s2 = (j + 2) >> 1;
@@ -392,6 +413,7 @@ __global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __r
             a2_mfma_o<A2_OB + 32>(vfr[5], pb1);
             if (more) { ma = a2_max3(ma, na[13], na[14]); mb = a2_max3(mb, nb[13], nb[14]); }
             a2_mfma_o<A2_OB + 48>(vfr[7], pb1);
+            A2_T(4);
             if (more) {
                 // ONE rarely taken branch closes the step: ragged last tile (mask) or a reference that has to move
                 float mxa = half_max(fmaxf(ma, na[15])), mxb = half_max(fmaxf(mb, nb[15]));
@@ -408,6 +430,7 @@ __global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __r
                     a2_move<A2_OB>(nb, negb, lb, mxb, false);
                 }
             }
+            A2_T(5);
         };
         for (int s = 0; s + 1 < NST; ++s) {
             tile_step(std::true_type{}, 2 * s, s0a, s0b, s1a, s1b);
@@ -416,6 +439,7 @@ __global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __r
         tile_step(std::false_type{}, 2 * NST - 2, s0a, s0b, s1a, s1b);
         if (2 * NST - 1 < NT) tile_step(std::false_type{}, 2 * NST - 1, s1a, s1b, s0a, s0b);
         // ---- normalise and store the context fragments (invalid query slots: exact zeros)
+        A2_T(5);
         {
             a2_nops24();  // the last O MFMAs must have retired before their accumulators are read
             const float ta = half_sum(la), tb = half_sum(lb);
@@ -441,7 +465,12 @@ __global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __r
                 store_block(std::integral_constant<int, A2_OB + 48>{}, qbB, vb, ib, 3);
             }
         }
+        A2_T(6);
     }
+#ifdef SAVAD_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i2 = 0; i2 < 8; ++i2) g_savad_dbg[i2] = tacc_[i2];
+#endif
 }
 
 }  // namespace bf
