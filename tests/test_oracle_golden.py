@@ -192,7 +192,7 @@ def test_logmel_filterbank_closed_form():
         assert bins[nz[0]] > edges[i] - 1e-9 and bins[nz[-1]] < edges[i + 2] + 1e-9          # support = (lower edge, upper edge)
         assert abs(bins[int(np.argmax(fb[i]))] - edges[i + 1]) < 31.25                            # peak at the bin beside the centre frequency
     wide = (edges[2:] - edges[:-2]) > 8 * 31.25                                               # triangles resolved by the grid
-    assert wide.sum() > 30 and np.abs((fb.sum(axis=1) * 31.25)[wide] - 1.0).max() < 0.02      # Slaney norm: unit area
+    assert wide.sum() > 20 and np.abs((fb.sum(axis=1) * 31.25)[wide] - 1.0).max() < 0.02      # Slaney norm: unit area
 
 
 def test_logmel_stft_matches_scipy_on_the_reference_clip():
