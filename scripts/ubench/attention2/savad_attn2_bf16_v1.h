@@ -1,0 +1,448 @@
+// savad_attn2_bf16.h -- bf16 flash attention, second generation: 64 query rows per wave, one wave per SIMD.
+//
+// Same data layout and arithmetic as attention_kernel_bf16 (savad_kernels_bf16.h): fragment-major Q / K / V^T in,
+// normalised context fragments out, scores in the base-2 exponent domain relative to a per-row reference.
+// What changes is the schedule (vad/modeling/transformer.py:305-346,351-363 is still what is computed):
+//   * a wave owns a PAIR of query blocks (64 rows): every K / V^T fragment it reads from LDS feeds two MFMAs, and
+//     every DMA instruction, barrier and loop instruction is shared by twice the matrix work -- the first-generation
+//     kernel issued ~10 non-MFMA instructions per MFMA (rocprofv3: 5.5 VALU + 3.7 SALU + 1 LDS) and was issue bound
+//     at 39 % MFMA-busy;
+//   * a workgroup is 4 such waves, ONE PER SIMD, and walks its query pairs in rounds; the K / V^T stream of the
+//     sequence runs continuously through a 4-stage LDS ring (64 keys = 32 KiB per stage, 128 KiB), fed by
+//     asynchronous global->LDS DMA with counted vmcnt waits;
+//   * register file by hand: the accumulator file holds O (a[0:127]) and Q (a[128:191]), owned by inline asm and
+//     invisible to the compiler's allocator -- left to itself, hipcc selects the AGPR form for every MFMA of a
+//     one-wave-per-SIMD kernel and then moves every score tile AGPR -> VGPR for the softmax and shuffles the O
+//     accumulators between the files at the loop back-edge (150-400 v_accvgpr moves per key tile, measured in the
+//     ISA); the score tiles, the reference, K / V^T fragments and the probabilities are ordinary variables in the
+//     256 architectural VGPRs, and the S^T MFMAs are issued in VGPR form (D = scores, C = -reference);
+//   * the instruction stream of a key tile is laid out by hand (every instruction of the hot loop is a volatile asm
+//     statement, so program order IS issue order): S(j+1) = K(j+1) Q^T rides in front of the softmax of tile j --
+//     per MFMA slot 3-4 VALU instructions (exponentials, row sums, bf16 packing) -- and the row maxima of tile j+1
+//     sit between the MFMAs of O += V^T(j) P(j); consecutive MFMAs never share an accumulator;
+//   * the reference of a row only moves when a score exceeds it by 2^40 (or on the first tile of a round, where it
+//     is set to the row maximum): p <= 2^40 (bf16 keeps relative precision at any scale), sums in fp32 stay far
+//     inside range.  One rarely taken branch per tile.
+// Hazards the compiler cannot see into asm (CDNA3/4 ISA, "manually inserted wait states"): an MFMA result in VGPRs
+// must not be read by a VALU instruction for passes + 3 wait states -- by construction every consumer of a score
+// tile sits at least 8 MFMAs behind its producer (s_nop padding on the two cold paths); a transcendental result is
+// never consumed by the next instruction.
+#pragma once
+#include <type_traits>
+
+#include "savad_kernels_bf16.h"
+
+namespace savad {
+namespace bf {
+
+constexpr int A2_NRING = 4;                    // LDS stages (2 key blocks of K + 2 of V^T each)
+constexpr int A2_STAGE_BYTES = 4 * BLK_BYTES;  // 32 KiB
+constexpr float A2_MOVE_LOG2 = 40.0f;
+// accumulator-file map (asm-owned)
+constexpr int A2_OA = 0, A2_OB = 64, A2_QA = 128, A2_QB = 160, A2_NACC = 192;
+
+#define A2_CLOB10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+// tells the compiler that a0..a191 are in use (kernel descriptor's AGPR count; never picked as spill slots)
+__device__ __forceinline__ void a2_reserve_acc() {
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", A2_CLOB10(1), A2_CLOB10(2), A2_CLOB10(3), A2_CLOB10(4),
+                 A2_CLOB10(5), A2_CLOB10(6), A2_CLOB10(7), A2_CLOB10(8), A2_CLOB10(9), A2_CLOB10(10), A2_CLOB10(11), A2_CLOB10(12),
+                 A2_CLOB10(13), A2_CLOB10(14), A2_CLOB10(15), A2_CLOB10(16), A2_CLOB10(17), A2_CLOB10(18), "a190", "a191");
+}
+
+// ---- the instruction set of the hot loop (volatile: program order is issue order)
+template <int Q0>  // first MFMA of a score chain: D = K-fragment x Q-fragment + (-reference)
+__device__ __forceinline__ void a2_mfma_s0(f32x16& d, const bf16x8& k, const f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%3:%4], %2" : "=&v"(d) : "v"(k), "v"(c), "n"(Q0), "n"(Q0 + 3));
+}
+template <int Q0>
+__device__ __forceinline__ void a2_mfma_s(f32x16& d, const bf16x8& k) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(d) : "v"(k), "n"(Q0), "n"(Q0 + 3));
+}
+template <int O0>  // O^T block += V^T fragment x P fragment
+__device__ __forceinline__ void a2_mfma_o(const bf16x8& v, const bf16x8& p) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(v), "v"(p), "n"(O0), "n"(O0 + 15));
+}
+__device__ __forceinline__ float a2_exp2(float x) {
+    float r;
+    asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float a2_add(float a, float b) {
+    float r;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned a2_cvt2(float lo, float hi) {
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float a2_max3(float a, float b, float c) {
+    float r;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ bf16x8 a2_frag(unsigned a, unsigned b, unsigned c, unsigned d) { return __builtin_bit_cast(bf16x8, u32x4{a, b, c, d}); }
+
+template <int A0, int N>  // a[A0 .. A0+N) = 0
+__device__ __forceinline__ void a2_acc_zero() {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(A0 + i));
+}
+template <int A0>  // a[A0 .. A0+4) = one fragment
+__device__ __forceinline__ void a2_acc_put4(const bf16x8& f) {
+    const u32x4 u = __builtin_bit_cast(u32x4, f);
+    asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%5], %1\n\tv_accvgpr_write_b32 a[%6], %2\n\tv_accvgpr_write_b32 a[%7], %3"
+                 : : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "n"(A0), "n"(A0 + 1), "n"(A0 + 2), "n"(A0 + 3));
+}
+template <int A0>
+__device__ __forceinline__ void a2_acc_get16(f32x16& v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float t;
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(t) : "n"(A0 + i));
+        v[i] = t;
+    }
+}
+template <int A0>  // a[A0 .. A0+64) *= alpha (cold path)
+__device__ __forceinline__ void a2_acc_scale64(float alpha) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        float t;
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(t) : "n"(A0 + i));
+        t *= alpha;
+        asm volatile("v_accvgpr_write_b32 a[%0], %1" : : "n"(A0 + i), "v"(t));
+    }
+}
+__device__ __forceinline__ void a2_nops24() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7"); }
+
+// One DMA instruction: 64 lanes x 16 B from src (wave-uniform) + lane * 16 to LDS byte address lds_addr + lane * 16.
+// M0 is not saved / restored: nothing else in this kernel uses it (gfx9 DS instructions do not; checked in the ISA).
+__device__ __forceinline__ void a2_dma1k(const char* src, unsigned lds_addr, unsigned lane_off) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(lane_off), "s"(src), "s"(lds_addr)
+        : "memory");
+}
+
+// stage gs (global stage counter) = key blocks 2s, 2s+1 of the sequence (s = gs % NST): wave w moves 8 of the 32 KiB
+__device__ __forceinline__ void a2_issue_stage(char* smem, int gs, int NST, const char* kseq, const char* vtseq, int w, int lane) {
+    if (SAVAD_ABLATE & 1) return;
+    const int s = gs % NST;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem) + (unsigned)(gs & (A2_NRING - 1)) * A2_STAGE_BYTES;
+    const unsigned off = (unsigned)lane * 16u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = w + 4 * k;  // KiB 0..31 of the stage: [K blk 2s | K blk 2s+1 | V^T blk 2s | V^T blk 2s+1]
+        const char* base = (k < 4 ? kseq : vtseq) + (size_t)(2 * s) * BLK_BYTES + (size_t)(i & 15) * FRAG_BYTES;
+        a2_dma1k(base, lds0 + (unsigned)i * FRAG_BYTES, off);
+    }
+}
+
+// Wait until this wave's share of a stage has landed, then barrier.  younger (wave-uniform): at least one stage was
+// issued after it -- then "at most 8 DMA instructions outstanding" implies it has landed (loads return in order; other
+// vector-memory operations in flight can only make the wait longer) -- else everything is drained.
+__device__ __forceinline__ void a2_acquire(bool younger) {
+    if (SAVAD_ABLATE & 2) return;
+    if (younger)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 8);  // vmcnt(8)
+    else
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    asm volatile("" ::: "memory");
+    __syncthreads();
+}
+
+__device__ __forceinline__ float a2_max16(const f32x16& v) {
+    float m = a2_max3(v[0], v[1], v[2]);
+#pragma unroll
+    for (int r = 3; r + 1 < 16; r += 2) m = a2_max3(m, v[r], v[r + 1]);
+    return fmaxf(m, v[15]);
+}
+
+// keys that do not exist (ragged last tile) -> probability 0.  lane (m,h), register r <-> key 8(r>>2)+4h+(r&3)
+__device__ __forceinline__ void a2_mask(f32x16& sc, int lim /* T - 32*jt - 4*h */) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = (8 * (r >> 2) + (r & 3) < lim) ? sc[r] : NEG_BIG;
+}
+
+// Reference move of a freshly computed score tile (already relative to the current reference), cold path.
+// first: the reference is SET to the row maximum (O and l are still zero); otherwise l and O (a[O0..O0+64)) are rescaled.
+template <int O0>
+__device__ __forceinline__ void a2_move(f32x16& sc, f32x16& negm, float& l, float mx /* row maximum, both halves */, bool first) {
+    const bool move = first || (mx > A2_MOVE_LOG2);
+    const float d = move ? mx : 0.0f;  // new reference = old + d
+    if (!first) {
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        l *= alpha;
+        a2_nops24();  // the last O MFMAs must have retired before their accumulators are read
+        a2_acc_scale64<O0>(alpha);
+        asm volatile("s_nop 3");
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sc[r] -= d;
+        negm[r] -= d;
+    }
+}
+
+__device__ __forceinline__ void a2_load_frags8(bf16x8 (&f)[8], const char* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = ldfrag(p + (i * 64 + lane) * 16);
+}
+
+// scores of one tile for both query blocks: the two chains alternate, K fragment ks feeds both
+__device__ __forceinline__ void a2_scores(f32x16& da, f32x16& db, const bf16x8 (&k)[8], const f32x16& ca, const f32x16& cb) {
+    a2_mfma_s0<A2_QA + 0>(da, k[0], ca);
+    a2_mfma_s0<A2_QB + 0>(db, k[0], cb);
+    a2_mfma_s<A2_QA + 4>(da, k[1]);
+    a2_mfma_s<A2_QB + 4>(db, k[1]);
+    a2_mfma_s<A2_QA + 8>(da, k[2]);
+    a2_mfma_s<A2_QB + 8>(db, k[2]);
+    a2_mfma_s<A2_QA + 12>(da, k[3]);
+    a2_mfma_s<A2_QB + 12>(db, k[3]);
+    a2_mfma_s<A2_QA + 16>(da, k[4]);
+    a2_mfma_s<A2_QB + 16>(db, k[4]);
+    a2_mfma_s<A2_QA + 20>(da, k[5]);
+    a2_mfma_s<A2_QB + 20>(db, k[5]);
+    a2_mfma_s<A2_QA + 24>(da, k[6]);
+    a2_mfma_s<A2_QB + 24>(db, k[6]);
+    a2_mfma_s<A2_QA + 28>(da, k[7]);
+    a2_mfma_s<A2_QB + 28>(db, k[7]);
+}
+
+// T > 32.  Workgroup = (sequence b, group g of NG): the group's query PAIRS [p0, p1) are processed in rounds of 4
+// (one pair per wave); every round streams the sequence's QB key blocks through the ring.
+__global__ __launch_bounds__(256, 1) void attention2_kernel_bf16(const char* __restrict__ qf, const char* __restrict__ kf,
+                                                                 const char* __restrict__ vtf, char* __restrict__ ctxf, int B, int T,
+                                                                 int NG) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // A2_NRING stages
+    a2_reserve_acc();
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int QB = (T + 31) / 32, NT = QB, NP = (QB + 1) / 2, NST = (QB + 1) / 2;
+    int b, g;
+    if (!xcd_balanced_map(B, NG, b, g)) return;
+    const int p0 = (g * NP) / NG, p1 = ((g + 1) * NP) / NG;
+    const int NR = (p1 - p0 + 3) / 4;
+    const int GS = NR * NST;
+    const char* kseq = kf + (size_t)b * QB * BLK_BYTES;
+    const char* vtseq = vtf + (size_t)b * QB * BLK_BYTES;
+
+    int issued = 0;
+    for (; issued < A2_NRING && issued < GS; ++issued) a2_issue_stage(smem, issued, NST, kseq, vtseq, w, lane);
+
+    for (int r = 0; r < NR; ++r) {
+        const int pair = p0 + 4 * r + w;
+        const bool live = pair < p1;              // wave-uniform
+        const int qbA = 2 * (live ? pair : p0);
+        const bool hasB = qbA + 1 < QB;           // the last pair of an odd QB is a single block (computed twice, stored once)
+        const int qbB = hasB ? qbA + 1 : qbA;
+        const int G0 = r * NST;                   // global stage of this round's key blocks 0, 1
+
+        {  // Q fragments -> a[128:191]; O = 0
+            bf16x8 q[8];
+            a2_load_frags8(q, qf + ((size_t)b * QB + qbA) * BLK_BYTES, lane);
+            a2_acc_put4<A2_QA + 0>(q[0]); a2_acc_put4<A2_QA + 4>(q[1]); a2_acc_put4<A2_QA + 8>(q[2]); a2_acc_put4<A2_QA + 12>(q[3]);
+            a2_acc_put4<A2_QA + 16>(q[4]); a2_acc_put4<A2_QA + 20>(q[5]); a2_acc_put4<A2_QA + 24>(q[6]); a2_acc_put4<A2_QA + 28>(q[7]);
+            a2_load_frags8(q, qf + ((size_t)b * QB + qbB) * BLK_BYTES, lane);
+            a2_acc_put4<A2_QB + 0>(q[0]); a2_acc_put4<A2_QB + 4>(q[1]); a2_acc_put4<A2_QB + 8>(q[2]); a2_acc_put4<A2_QB + 12>(q[3]);
+            a2_acc_put4<A2_QB + 16>(q[4]); a2_acc_put4<A2_QB + 20>(q[5]); a2_acc_put4<A2_QB + 24>(q[6]); a2_acc_put4<A2_QB + 28>(q[7]);
+            a2_acc_zero<A2_OA, 128>();
+        }
+        f32x16 nega = zero16(), negb = zero16();  // -reference of the lane's query row, in every register
+        float la = 0.0f, lb = 0.0f;               // this lane's half of the row sums
+
+        // ---- round start: key stage G0 must have landed (and, for r > 0, everyone is done with the previous round)
+        a2_acquire(issued - 1 > G0);
+        for (; issued < G0 + A2_NRING && issued < GS; ++issued) a2_issue_stage(smem, issued, NST, kseq, vtseq, w, lane);
+        if (!live) {  // no query pair in this round: keep the stream and the barriers going
+            for (int s = 0; s + 1 < NST; ++s) {
+                a2_acquire(issued - 1 > G0 + s + 1);
+                if (issued < G0 + s + A2_NRING && issued < GS) a2_issue_stage(smem, issued++, NST, kseq, vtseq, w, lane);
+            }
+            continue;
+        }
+        const char* st0 = smem + (G0 & (A2_NRING - 1)) * A2_STAGE_BYTES;
+        bf16x8 kfr[8];
+        a2_load_frags8(kfr, st0, lane);
+        f32x16 s0a, s0b, s1a, s1b;  // scores of the even tiles (2s) / of the odd tiles (2s+1), relative to the reference
+        a2_scores(s0a, s0b, kfr, nega, negb);
+        a2_nops24();
+        a2_move<A2_OA>(s0a, nega, la, half_max(a2_max16(s0a)), true);
+        a2_move<A2_OB>(s0b, negb, lb, half_max(a2_max16(s0b)), true);
+        a2_load_frags8(kfr, st0 + BLK_BYTES, lane);  // K of tile 1 (T > 32: it exists)
+        s1a = s0a;
+        s1b = s0b;
+
+        // One tile step: the scores of tile j are in (ca, cb); produces the scores of tile j+1 in (na, nb).
+        // FULL (every tile but those of the round's last stage): tile j+1 exists, stage s+1 exists, and the K(j+2)
+        // fragments are read unconditionally (if tile j+2 does not exist they are junk nobody uses).
+        auto tile_step = [&](auto full_tag, int j, f32x16& ca, f32x16& cb, f32x16& na, f32x16& nb) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const int s = j >> 1, tt = j & 1;
+            const char* stg = smem + ((G0 + s) & (A2_NRING - 1)) * A2_STAGE_BYTES;
+            const bool more = FULL || j + 1 < NT;
+            bf16x8 vfr[8];
+            a2_load_frags8(vfr, stg + (2 + tt) * BLK_BYTES, lane);
+            // ---- phase 1: 16 score MFMAs of tile j+1; between them the exponentials of tile j (both blocks), then
+            //      the row sum and the bf16 packing of block A
+            float ea[16], eb[16];
+            if (more) {
+                a2_mfma_s0<A2_QA + 0>(na, kfr[0], nega);
+                ea[0] = a2_exp2(ca[0]); ea[1] = a2_exp2(ca[1]); eb[0] = a2_exp2(cb[0]); eb[1] = a2_exp2(cb[1]);
+                a2_mfma_s0<A2_QB + 0>(nb, kfr[0], negb);
+                ea[2] = a2_exp2(ca[2]); ea[3] = a2_exp2(ca[3]); eb[2] = a2_exp2(cb[2]); eb[3] = a2_exp2(cb[3]);
+                a2_mfma_s<A2_QA + 4>(na, kfr[1]);
+                ea[4] = a2_exp2(ca[4]); ea[5] = a2_exp2(ca[5]); eb[4] = a2_exp2(cb[4]); eb[5] = a2_exp2(cb[5]);
+                a2_mfma_s<A2_QB + 4>(nb, kfr[1]);
+                ea[6] = a2_exp2(ca[6]); ea[7] = a2_exp2(ca[7]); eb[6] = a2_exp2(cb[6]); eb[7] = a2_exp2(cb[7]);
+                a2_mfma_s<A2_QA + 8>(na, kfr[2]);
+                ea[8] = a2_exp2(ca[8]); ea[9] = a2_exp2(ca[9]); eb[8] = a2_exp2(cb[8]); eb[9] = a2_exp2(cb[9]);
+                a2_mfma_s<A2_QB + 8>(nb, kfr[2]);
+                ea[10] = a2_exp2(ca[10]); ea[11] = a2_exp2(ca[11]); eb[10] = a2_exp2(cb[10]); eb[11] = a2_exp2(cb[11]);
+                a2_mfma_s<A2_QA + 12>(na, kfr[3]);
+                ea[12] = a2_exp2(ca[12]); ea[13] = a2_exp2(ca[13]); eb[12] = a2_exp2(cb[12]); eb[13] = a2_exp2(cb[13]);
+                a2_mfma_s<A2_QB + 12>(nb, kfr[3]);
+                ea[14] = a2_exp2(ca[14]); ea[15] = a2_exp2(ca[15]); eb[14] = a2_exp2(cb[14]); eb[15] = a2_exp2(cb[15]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    ea[e] = a2_exp2(ca[e]);
+                    eb[e] = a2_exp2(cb[e]);
+                }
+            }
+            float ra, rb;
+            unsigned ua[8], ub[8];
+#define A2_SLOT_A(i)                                                                          \
+    ra = (i) == 0 ? a2_add(ea[0], ea[1]) : a2_add(a2_add(ra, ea[2 * (i)]), ea[2 * (i) + 1]); \
+    ua[i] = a2_cvt2(ea[2 * (i)], ea[2 * (i) + 1]);
+            if (more) {
+                a2_mfma_s<A2_QA + 16>(na, kfr[4]);
+                A2_SLOT_A(0)
+                a2_mfma_s<A2_QB + 16>(nb, kfr[4]);
+                A2_SLOT_A(1)
+                a2_mfma_s<A2_QA + 20>(na, kfr[5]);
+                A2_SLOT_A(2)
+                a2_mfma_s<A2_QB + 20>(nb, kfr[5]);
+                A2_SLOT_A(3)
+                a2_mfma_s<A2_QA + 24>(na, kfr[6]);
+                A2_SLOT_A(4)
+                a2_mfma_s<A2_QB + 24>(nb, kfr[6]);
+                A2_SLOT_A(5)
+                a2_mfma_s<A2_QA + 28>(na, kfr[7]);
+                A2_SLOT_A(6)
+                a2_mfma_s<A2_QB + 28>(nb, kfr[7]);
+                A2_SLOT_A(7)
+            } else {
+                A2_SLOT_A(0) A2_SLOT_A(1) A2_SLOT_A(2) A2_SLOT_A(3) A2_SLOT_A(4) A2_SLOT_A(5) A2_SLOT_A(6) A2_SLOT_A(7)
+            }
+#undef A2_SLOT_A
+            la = a2_add(la, ra);
+            const bf16x8 pa0 = a2_frag(ua[0], ua[1], ua[2], ua[3]), pa1 = a2_frag(ua[4], ua[5], ua[6], ua[7]);
+            // ---- stage hand-over (even tiles): the next stage has landed; the stage before this one is refilled
+            if (tt == 0 && (FULL || s + 1 < NST)) {
+                a2_acquire(issued - 1 > G0 + s + 1);
+                // everyone still needs stage G0+s (its odd tile): stages up to G0+s+3 fit the ring beside it
+                if (issued < G0 + s + A2_NRING && issued < GS) a2_issue_stage(smem, issued++, NST, kseq, vtseq, w, lane);
+            }
+            if (FULL || j + 2 < NT) {
+                const int s2 = (j + 2) >> 1;
+                a2_load_frags8(kfr, smem + ((G0 + s2) & (A2_NRING - 1)) * A2_STAGE_BYTES + tt * BLK_BYTES, lane);
+            }
+            // ---- phase 2: 16 O MFMAs.  Block A's eight first (consecutive ones on different accumulators), with the
+            //      row sum and packing of block B between them; then block B's, with the row maxima of tile j+1.
+#define A2_SLOT_B(i)                                                                          \
+    rb = (i) == 0 ? a2_add(eb[0], eb[1]) : a2_add(a2_add(rb, eb[2 * (i)]), eb[2 * (i) + 1]); \
+    ub[i] = a2_cvt2(eb[2 * (i)], eb[2 * (i) + 1]);
+            a2_mfma_o<A2_OA + 0>(vfr[0], pa0);
+            A2_SLOT_B(0)
+            a2_mfma_o<A2_OA + 16>(vfr[2], pa0);
+            A2_SLOT_B(1)
+            a2_mfma_o<A2_OA + 32>(vfr[4], pa0);
+            A2_SLOT_B(2)
+            a2_mfma_o<A2_OA + 48>(vfr[6], pa0);
+            A2_SLOT_B(3)
+            a2_mfma_o<A2_OA + 0>(vfr[1], pa1);
+            A2_SLOT_B(4)
+            a2_mfma_o<A2_OA + 16>(vfr[3], pa1);
+            A2_SLOT_B(5)
+            a2_mfma_o<A2_OA + 32>(vfr[5], pa1);
+            A2_SLOT_B(6)
+            a2_mfma_o<A2_OA + 48>(vfr[7], pa1);
+            A2_SLOT_B(7)
+#undef A2_SLOT_B
+            lb = a2_add(lb, rb);
+            const bf16x8 pb0 = a2_frag(ub[0], ub[1], ub[2], ub[3]), pb1 = a2_frag(ub[4], ub[5], ub[6], ub[7]);
+            float ma = 0.0f, mb = 0.0f;
+            a2_mfma_o<A2_OB + 0>(vfr[0], pb0);
+            if (more) { ma = a2_max3(na[0], na[1], na[2]); mb = a2_max3(nb[0], nb[1], nb[2]); }
+            a2_mfma_o<A2_OB + 16>(vfr[2], pb0);
+            if (more) { ma = a2_max3(ma, na[3], na[4]); mb = a2_max3(mb, nb[3], nb[4]); }
+            a2_mfma_o<A2_OB + 32>(vfr[4], pb0);
+            if (more) { ma = a2_max3(ma, na[5], na[6]); mb = a2_max3(mb, nb[5], nb[6]); }
+            a2_mfma_o<A2_OB + 48>(vfr[6], pb0);
+            if (more) { ma = a2_max3(ma, na[7], na[8]); mb = a2_max3(mb, nb[7], nb[8]); }
+            a2_mfma_o<A2_OB + 0>(vfr[1], pb1);
+            if (more) { ma = a2_max3(ma, na[9], na[10]); mb = a2_max3(mb, nb[9], nb[10]); }
+            a2_mfma_o<A2_OB + 16>(vfr[3], pb1);
+            if (more) { ma = a2_max3(ma, na[11], na[12]); mb = a2_max3(mb, nb[11], nb[12]); }
+            a2_mfma_o<A2_OB + 32>(vfr[5], pb1);
+            if (more) { ma = a2_max3(ma, na[13], na[14]); mb = a2_max3(mb, nb[13], nb[14]); }
+            a2_mfma_o<A2_OB + 48>(vfr[7], pb1);
+            if (more) {
+                // ONE rarely taken branch closes the step: ragged last tile (mask) or a reference that has to move
+                float mxa = half_max(fmaxf(ma, na[15])), mxb = half_max(fmaxf(mb, nb[15]));
+                const bool ragged = 32 * (j + 1) + 32 > T;  // wave-uniform: tile j+1 is the ragged last one
+                if (ragged || __any(mxa > A2_MOVE_LOG2 || mxb > A2_MOVE_LOG2)) {
+                    if (ragged) {
+                        const int lim = T - 32 * (j + 1) - 4 * h;
+                        a2_mask(na, lim);
+                        a2_mask(nb, lim);
+                        mxa = half_max(a2_max16(na));
+                        mxb = half_max(a2_max16(nb));
+                    }
+                    a2_move<A2_OA>(na, nega, la, mxa, false);
+                    a2_move<A2_OB>(nb, negb, lb, mxb, false);
+                }
+            }
+        };
+        for (int s = 0; s + 1 < NST; ++s) {
+            tile_step(std::true_type{}, 2 * s, s0a, s0b, s1a, s1b);
+            tile_step(std::true_type{}, 2 * s + 1, s1a, s1b, s0a, s0b);
+        }
+        tile_step(std::false_type{}, 2 * NST - 2, s0a, s0b, s1a, s1b);
+        if (2 * NST - 1 < NT) tile_step(std::false_type{}, 2 * NST - 1, s1a, s1b, s0a, s0b);
+        // ---- normalise and store the context fragments (invalid query slots: exact zeros)
+        {
+            a2_nops24();  // the last O MFMAs must have retired before their accumulators are read
+            const float ta = half_sum(la), tb = half_sum(lb);
+            const bool va = 32 * qbA + (lane & 31) < T, vb = 32 * qbB + (lane & 31) < T;
+            const float ia = va ? 1.0f / ta : 0.0f, ib = vb ? 1.0f / tb : 0.0f;
+            auto store_block = [&](auto o0_tag, int qblk, bool valid, float inv, int nbd) {
+                f32x16 o;
+                a2_acc_get16<decltype(o0_tag)::value>(o);
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) o[rr] = valid ? o[rr] * inv : 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    stfrag(ctxf + (((size_t)b * QB + qblk) * 8 + 2 * nbd + jj) * FRAG_BYTES + lane * 16, pack_half(o, jj));
+            };
+            store_block(std::integral_constant<int, A2_OA + 0>{}, qbA, va, ia, 0);
+            store_block(std::integral_constant<int, A2_OA + 16>{}, qbA, va, ia, 1);
+            store_block(std::integral_constant<int, A2_OA + 32>{}, qbA, va, ia, 2);
+            store_block(std::integral_constant<int, A2_OA + 48>{}, qbA, va, ia, 3);
+            if (hasB) {
+                store_block(std::integral_constant<int, A2_OB + 0>{}, qbB, vb, ib, 0);
+                store_block(std::integral_constant<int, A2_OB + 16>{}, qbB, vb, ib, 1);
+                store_block(std::integral_constant<int, A2_OB + 32>{}, qbB, vb, ib, 2);
+                store_block(std::integral_constant<int, A2_OB + 48>{}, qbB, vb, ib, 3);
+            }
+        }
+    }
+}
+
+}  // namespace bf
+}  // namespace savad

@@ -3,7 +3,6 @@
 //   input_qkv -> [attention(l) -> row(l)] x L      (row(L-1) ends in classifier + log-softmax)
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
-#include "savad_attn2_bf16.h"
 #include <type_traits>
 #include "savad_logmel.h"
 #include "savad_post.h"
@@ -498,7 +497,7 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
-    if (!m || mode < 0 || mode > 6) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 5) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -571,7 +570,6 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
         if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float, 4>, r4 + 3 * D * 4))) return rc;
         if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16, 4>, r4 + 3 * D * 4))) return rc;
         if ((rc = allow_lds(bf::attention_kernel_bf16<4>, r4))) return rc;
-        if ((rc = allow_lds(bf::attention2_kernel_bf16, bf::A2_NRING * bf::A2_STAGE_BYTES))) return rc;
         if ((rc = allow_lds(bf::row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
         if ((rc = allow_lds(bf::row_kernel_bf16<true, 4>, r4 + 9 * D * 4))) return rc;
         if ((rc = allow_lds(bf::attention_row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
@@ -638,15 +636,6 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
             if (T <= 32) {
                 hipLaunchKernelGGL(bf::attention_packed_kernel_bf16, dim3((bp.nblk + 3) / 4), dim3(256), 0, st, qf, kf, vtf, ctxf,
                                    B, T, bp.nblk);
-            } else if (m->row_mode == 6) {
-                // second-generation attention: 64 query rows per wave, one 4-wave workgroup per CU walking a sequence's
-                // query pairs in rounds; as many groups per sequence as it takes to give every CU a workgroup
-                const int QB = (T + 31) / 32, NP = (QB + 1) / 2;
-                int NG = B >= 256 ? 1 : (256 + B - 1) / B;
-                if (NG > (NP + 3) / 4) NG = (NP + 3) / 4;
-                if (NG < 1) NG = 1;
-                hipLaunchKernelGGL(bf::attention2_kernel_bf16, dim3(8 * (((long)B * NG + 7) / 8)), dim3(256), bf::A2_NRING * bf::A2_STAGE_BYTES, st,
-                                   qf, kf, vtf, ctxf, B, T, NG);
             } else {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
                 hipLaunchKernelGGL((bf::attention_kernel_bf16<NW>), dim3(8 * (((long)B * NG + 7) / 8)), wg, ring, st, qf, kf, vtf, ctxf, B,
