@@ -134,3 +134,31 @@ def test_module_copies_and_pickles_drop_runtime_state(state1234):
         m.classifier.bias.add_(1.0)   # ordinary in-place edits are seen
     assert m._param_versions() != m._synced_versions
     m._handle = None  # nothing real to destroy
+
+
+def test_lds_dma_owns_m0(tmp_path):
+    """The LDS-DMA statements of the bf16 kernels set M0 without saving it (savad_kernels_bf16.h, Ring::dma1k): legal only
+    while nothing else in those kernels touches M0.  Checked where it can be checked: in the disassembly."""
+    import re
+    import shutil
+    import subprocess
+
+    from voice_activity_detection_amd import build
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists()) or not Path(objdump).exists():
+        pytest.skip("no ROCm toolchain here")
+    co = tmp_path / "savad.co"
+    subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "--no-gpu-bundle-output",
+                    "-Wno-unused-value", "-w", str(build.SRC), "-o", str(co)], check=True)
+    dis = subprocess.run([objdump, "-d", str(co)], check=True, capture_output=True, text=True).stdout
+    parts = re.split(r"\n[0-9a-f]+ <([^>]+)>:\n", dis)
+    seen = 0
+    for name, body in zip(parts[1::2], parts[2::2]):
+        if "2bf" not in name:  # namespace savad::bf
+            continue
+        for line in body.splitlines():
+            if re.search(r"\bm0\b", line):
+                seen += 1
+                assert "s_add_u32 m0" in line, (name, line.strip())
+    assert seen >= 100

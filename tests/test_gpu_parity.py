@@ -599,6 +599,32 @@ def test_logmel_device_matches_scipy_fixture(torch_cuda):
     assert np.median(d) < 5e-6 and d.max() < 1e-3, (np.median(d), d.max())  # fp32 DFT on the MFMA vs float64 scipy
 
 
+def test_bf16_reference_moves(torch_cuda, state1234):
+    """The reference-move path of the bf16 attention stage (savad_kernels_bf16.h, online_softmax_shifted: the reference of
+    a row moves, and O and l are rescaled, when a score outruns it by 2^16).  Query / key weights scaled x6 (scores
+    x36) force it on most rows of most tiles -- compared with the fp32 oracle on the same weights, for the separate
+    and the fused launch shape."""
+    from oracle import oracle
+
+    torch = torch_cuda
+    st = {k: v.copy() for k, v in state1234.items()}
+    for l in range(3):
+        st[f"encoder.layers.{l}.self_attention.query_projection.weight"] *= 6.0
+        st[f"encoder.layers.{l}.self_attention.key_projection.weight"] *= 6.0
+    m = make_model(torch, st)
+    x = feats(91, (3, 800, 80))
+    ref = oracle.forward(st, x, threads=16)
+    ys = {}
+    for mode in (1, 3):
+        m.row_mode = mode
+        ys[mode] = run_bf16(torch, m, x)
+        assert np.isfinite(ys[mode]).all()
+        # peaked softmaxes amplify the bf16 rounding of q and k: the bound is looser than BF16_TOL, the decisions are not
+        assert np.abs(ys[mode] - ref).max() < 0.25, np.abs(ys[mode] - ref).max()
+        assert ((ys[mode][..., 1] > ys[mode][..., 0]) == (ref[..., 1] > ref[..., 0])).mean() > 0.99
+    assert np.array_equal(ys[1], ys[3])
+
+
 # ---- log-mel front-end (next-row 1; parity UNPINNED: librosa is absent, the oracle restates its defaults) ----
 @pytest.mark.parametrize("n", [163414, 16000, 1600, 513, 160, 159, 1])
 def test_logmel_matches_oracle(torch_cuda, n):

@@ -119,29 +119,48 @@ struct Ring {
 
     __device__ __forceinline__ char* slot(int t) const { return base + (t & (NRING - 1)) * RING_BYTES; }
 
+    // One DMA instruction moves 1 KiB; instruction i = w + NW * k of the block's 32 reads KiB (i & 7) of segment i >> 3
+    // and lands at slot + i KiB.  Per instruction: s_add_u32 m0 (LDS address = per-wave base + immediate), the hazard
+    // nop, the load -- the segment base is wave-uniform (SGPR pair, + this wave's KiB), the rest of the source offset
+    // rides in the per-lane offset register.  M0 is not saved / restored: nothing else in these kernels uses it (gfx9 DS
+    // instructions do not need it; tests/test_abi_and_host.py checks the disassembly).
+    template <int IMM>
+    static __device__ __forceinline__ void dma1k(const char* src, unsigned ldsb, unsigned voff) {
+        asm volatile(
+            "s_add_u32 m0, %2, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1"
+            :
+            : "v"(voff), "s"(src), "s"(ldsb), "n"(IMM)
+            : "memory", "scc");
+    }
     template <class SegSrc>
     __device__ __forceinline__ void issue(int t, SegSrc seg_src) const {
         if (SAVAD_ABLATE & 1) return;
         // LDS byte address = low 32 bits of the flat address (the LDS aperture is 4 GiB aligned).  An explicit
         // generic -> address_space(3) cast adds a null check that hipcc 7.2 mis-selects in one instantiation
         // ("V_CMP_NE_U32 0, $src_shared_base: operand has incorrect register class").
-        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot(t));
+        const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot(t)) + (unsigned)w * FRAG_BYTES;
         const unsigned off = (unsigned)lane * 16u;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = w + NW * k;  // instruction 0..31 of the block
-            const char* src = seg_src(i >> 3) + (i & 7) * FRAG_BYTES;
-            const unsigned m0v = lds0 + (unsigned)i * FRAG_BYTES;
-            unsigned keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %3\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, %2\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(off), "s"(src), "s"(m0v)
-                : "memory");
+        if (NW == 4) {  // i = w + 4k: segment k >> 1, KiB w + 4 (k & 1)
+            const unsigned off4 = off + 4u * FRAG_BYTES;
+            const char* s0 = seg_src(0) + (size_t)w * FRAG_BYTES;
+            dma1k<0 * 4096>(s0, ldsb, off);
+            dma1k<1 * 4096>(s0, ldsb, off4);
+            const char* s1 = seg_src(1) + (size_t)w * FRAG_BYTES;
+            dma1k<2 * 4096>(s1, ldsb, off);
+            dma1k<3 * 4096>(s1, ldsb, off4);
+            const char* s2 = seg_src(2) + (size_t)w * FRAG_BYTES;
+            dma1k<4 * 4096>(s2, ldsb, off);
+            dma1k<5 * 4096>(s2, ldsb, off4);
+            const char* s3 = seg_src(3) + (size_t)w * FRAG_BYTES;
+            dma1k<6 * 4096>(s3, ldsb, off);
+            dma1k<7 * 4096>(s3, ldsb, off4);
+        } else {  // NW == 8: i = w + 8k: segment k, KiB w
+            dma1k<0 * 8192>(seg_src(0) + (size_t)w * FRAG_BYTES, ldsb, off);
+            dma1k<1 * 8192>(seg_src(1) + (size_t)w * FRAG_BYTES, ldsb, off);
+            dma1k<2 * 8192>(seg_src(2) + (size_t)w * FRAG_BYTES, ldsb, off);
+            dma1k<3 * 8192>(seg_src(3) + (size_t)w * FRAG_BYTES, ldsb, off);
         }
     }
     // wait until block t has landed for every wave; `newer` = DMA blocks issued after block t (wave-uniform)
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf1
 struct AttnState {
     f32x16 O[4];
     f32x16 negm;  // all 16 registers of a lane hold -reference of the lane's query row
-    float l_run;
+    float l_run;  // this lane's half of the running row sum
 };
 __device__ __forceinline__ void attn_state_init(AttnState& st) {
 #pragma unroll
@@ -333,8 +352,12 @@ __device__ __forceinline__ void online_softmax_shifted(f32x16& sc, AttnState& st
         sc[r] = __builtin_amdgcn_exp2f(sc[r]);
         rs += sc[r];
     }
-    st.l_run += half_sum(rs);
+    st.l_run += rs;  // this lane's half of the row sum: the two halves meet once, when the context is normalised
 }
+// (Tried in round 2: taking the exponentials against the standing reference WITHOUT the row maxima and redoing a tile only
+// when its row sum leaves a 2^60 window -- 19 fewer VALU instructions per tile, bit-compatible cold path -- made the
+// stage 22 % SLOWER (97 -> 119 us at [256,800,80]): the rarely taken branch then sits between the exponentials and
+// the PV MFMAs, which the scheduler no longer interleaves; here it sits before the exponentials.)
 // `mask(sc)` sets the scores of keys that do not exist to NEG_BIG (lane (m,h), register r <-> key 8(r>>2)+4h+(r&3)).
 template <class Mask>
 __device__ __forceinline__ void attn_tile(AttnState& st, const bf16x8 (&qp)[8], const char* kblk, const char* vtblk,
@@ -356,7 +379,7 @@ __device__ __forceinline__ void attn_tile(AttnState& st, const bf16x8 (&qp)[8], 
 // would otherwise carry inf/NaN into h, K and V^T of that slot and poison the NEXT layer's PV product
 // (probability 0 x NaN).
 __device__ __forceinline__ void store_ctx(char* ctxf, int blk, AttnState& st, bool qvalid, int lane) {
-    const float inv = 1.0f / st.l_run;
+    const float inv = 1.0f / half_sum(st.l_run);
 #pragma unroll
     for (int nbd = 0; nbd < 4; ++nbd) {
 #pragma unroll
@@ -666,7 +689,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attention_row_kernel
     bf16x8 xp[8];
     {
         const bool qvalid = active && 32 * qb + (lane & 31) < T;
-        const float inv = qvalid ? 1.0f / st.l_run : 0.0f;
+        const float inv = qvalid ? 1.0f / half_sum(st.l_run) : 0.0f;
 #pragma unroll
         for (int nbd = 0; nbd < 4; ++nbd) {
 #pragma unroll
