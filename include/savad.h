@@ -89,6 +89,11 @@ int savad_forward(savad_handle h, const float* x, int B, int T, float* out, void
  * accumulation, fp32 softmax / LayerNorm statistics, residual stream fp32 in registers / fp16 in memory (BASELINE.json
  * configs[2..3]; judged on AUC, not on 1e-4). */
 int savad_set_precision(savad_handle h, int precision);
+/* bf16 precision only: the residual stream lives in HBM as fp16 between kernels and saturates at +-65504 where the
+ * reference's fp32 stream (vad/modeling/transformer.py:234-238) would not.  Saturation is counted, not silent: this
+ * returns the number of residual elements clamped (or non-finite) since the previous call and clears the counter;
+ * it synchronises `stream`.  0 on every parity workload; a model that reports > 0 needs precision 0 (fp32). */
+int savad_residual_saturations(savad_handle h, unsigned long long* count, void* stream);
 /* savad_forward with an explicit feature dtype: x_dtype 0 = fp32 [B,T,F], 1 = bf16 [B,T,F] (bf16
  * precision only).  Output is always fp32 log-probabilities. */
 int savad_forward_ex(savad_handle h, const void* x, int x_dtype, int B, int T, float* out, void* workspace,
@@ -105,8 +110,6 @@ int savad_set_attention_splits(savad_handle h, int splits);
  *        separate launches
  *     3  as 2, with attention and row chain of a query-block group fused into one launch per layer whenever
  *        T > 32 and the key range is not split (what automatic picks for large batches)
- *     5  as 3, with workgroups of 3 query-block waves + 1 helper wave that walks the tail of their key ranges
- *        (experimental: pays only with at most one workgroup per CU)
  *   bf16 operands
  *     1  separate attention / row launches, 4-wave workgroups      2  the same with 8-wave workgroups
  *     3  fused launches (T > 32)                                    0  fused up to ~4 workgroups per CU */

@@ -32,6 +32,7 @@ SYMBOLS = {
     "savad_workspace_bytes": (c_int, [c_void_p, c_int, c_int, POINTER(c_size_t)]),
     "savad_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "savad_set_precision": (c_int, [c_void_p, c_int]),
+    "savad_residual_saturations": (c_int, [c_void_p, POINTER(ctypes.c_ulonglong), c_void_p]),
     "savad_forward_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "savad_set_attention_splits": (c_int, [c_void_p, c_int]),
     "savad_set_row_mode": (c_int, [c_void_p, c_int]),

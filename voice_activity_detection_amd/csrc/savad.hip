@@ -66,11 +66,11 @@ struct savad_model {
     int splits = 0;
     int row_mode = 0;  // 0 auto, 1 N-split (32-row tiles), 2 M-split (128-row tiles)
     int precision = 0;  // 0 = fp32 MFMA, 1 = bf16 MFMA operands (fp32 accumulate / statistics / residual stream)
+    unsigned* d_sat = nullptr;  // bf16 path: elements of the fp16-stored residual stream that saturated since the last query
     char* d_frag = nullptr;  // bf16 weight fragments (savad_kernels_bf16.h), filled when precision == 1
     size_t frag_bytes = 0;
     bool frag_dirty = true;
     bool lds_attrs_set = false;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the bf16 kernels
-    bool lds_attrs_set_h = false;  // ... and for the helper-wave fp32 kernel
     size_t f_win = 0;
     struct LayerFrag {
         size_t wqkv, wo, w1, w2;
@@ -153,7 +153,7 @@ Workspace plan(const savad_model* m, int B, int T) {
     // N-split works through ceil(tiles / 256) rounds of ~45 us, M-split through one round of ~118 us per 256 workgroups
     // of 128 rows: M wins from the third N-split round on (more than 512 tiles of 32 rows).  Measured at T=800: B=20
     // (500 tiles) N 0.504 / M 0.648 ms; B=24 (600 tiles) N 0.611 / M 0.589 ms.
-    w.msplit = m->row_mode == 2 || m->row_mode == 3 || m->row_mode == 5 || (m->row_mode == 0 && w.rows_pad / 32 > 512);
+    w.msplit = m->row_mode == 2 || m->row_mode == 3 || (m->row_mode == 0 && w.rows_pad / 32 > 512);
     // In the M-split regime without key splits the attention stage and the row chain of a query-block group
     // run back to back in one workgroup (attention_row_kernel).  row_mode 2 keeps them as separate launches.
     // Automatic: only when a query-block group keeps at least 80 % of its 4 wave slots busy -- waves without a
@@ -162,7 +162,7 @@ Workspace plan(const savad_model* m, int B, int T) {
     // 7) 0.640 / 0.668).
     const int QBp = (T + 31) / 32, NGp = (QBp + 3) / 4;
     const bool ragged = QBp * 5 < NGp * 4 * 4;  // QB / (4 NG) < 0.8
-    w.fused = w.msplit && T > 32 && w.S == 1 && (m->row_mode == 3 || m->row_mode == 5 || (m->row_mode != 2 && !ragged));
+    w.fused = w.msplit && T > 32 && w.S == 1 && (m->row_mode == 3 || (m->row_mode != 2 && !ragged));
     size_t off = 0;
     w.h = off;
     off += w.rows_pad * D;
@@ -447,6 +447,8 @@ SAVAD_EXPORT int savad_create(const savad_config* cfg, savad_handle* out) {
     }
     hipError_t e = hipMalloc(&m->d_raw, sizeof(float) * m->raw_floats);
     if (e == hipSuccess) e = hipMalloc(&m->d_frag, m->frag_bytes);
+    if (e == hipSuccess) e = hipMalloc(&m->d_sat, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(m->d_sat, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&m->d_packed, sizeof(float) * m->packed_floats);
     if (e != hipSuccess) {
         if (m->d_raw) hipFree(m->d_raw);
@@ -463,6 +465,7 @@ SAVAD_EXPORT void savad_destroy(savad_handle m) {
     if (m->d_raw) hipFree(m->d_raw);
     if (m->d_packed) hipFree(m->d_packed);
     if (m->d_frag) hipFree(m->d_frag);
+    if (m->d_sat) hipFree(m->d_sat);
     if (m->d_pe) hipFree(m->d_pe);
     delete m;
 }
@@ -497,7 +500,7 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
-    if (!m || mode < 0 || mode > 5) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 4) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -520,6 +523,19 @@ SAVAD_EXPORT int savad_reserve(savad_handle m, int T_max, void* stream) {
     if (!m || T_max < 0) return fail(SAVAD_E_INVALID, "bad argument");
     if ((double)T_max * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "T_max=%d too large", T_max);
     return ensure_pe(m, T_max, (hipStream_t)stream);
+}
+
+// bf16 precision stores the residual stream between kernels as fp16 (+-65504); every element that had to be clamped is
+// counted.  Reads the count accumulated since the last call and clears it; synchronises `stream`.
+SAVAD_EXPORT int savad_residual_saturations(savad_handle m, unsigned long long* count, void* stream) {
+    if (!m || !count) return fail(SAVAD_E_INVALID, "null argument");
+    unsigned c = 0;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(&c, m->d_sat, sizeof(c), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(m->d_sat, 0, sizeof(unsigned), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *count = c;
+    return SAVAD_OK;
 }
 
 SAVAD_EXPORT int savad_set_precision(savad_handle m, int precision) {
@@ -590,11 +606,11 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
         if (x_is_bf16)
             hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<__bf16, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const __bf16*)x,
                                B, T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb,
-                               qf, kf, vtf, c);
+                               qf, kf, vtf, c, m->d_sat);
         else
             hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<float, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const float*)x, B,
                                T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf,
-                               kf, vtf, c);
+                               kf, vtf, c, m->d_sat);
         prof.mark("input_qkv_bf16");
         char* sets[2][3] = {{qf, kf, vtf}, {W + bp.q2, W + bp.k2, W + bp.vt2}};
         for (int l = 0; l < L; ++l) {
@@ -623,6 +639,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
             A.vtf = nxt[2];
             A.out = out;
             A.qscale = c;
+            A.satcnt = m->d_sat;
             if (bp.fused) {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
                 const dim3 grid(8 * (((long)B * NG + 7) / 8));
@@ -722,32 +739,13 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     prof.mark("input_qkv");
     if (ws.fused) {
         float* qkv[2][3] = {{q, k, v}, {W + ws.q2, W + ws.k2, W + ws.v2}};
-        const bool helpers = m->row_mode == 5;  // 3 query-block waves + 1 helper wave per workgroup (attention_row_kernel_h)
-        const int QB = (T + 31) / 32, NG = helpers ? (QB + 2) / 3 : (QB + 3) / 4;
+        const int QB = (T + 31) / 32, NG = (QB + 3) / 4;
         const int grid = (int)(8 * (((long)B * NG + 7) / 8));
-        constexpr int lds_h = 8 * KV_TILE_FLOATS * (int)sizeof(float);
-        if (helpers && !m->lds_attrs_set_h) {
-            if ((rc = allow_lds(attention_row_kernel_h<false>, lds_h))) return rc;
-            if ((rc = allow_lds(attention_row_kernel_h<true>, lds_h))) return rc;
-            m->lds_attrs_set_h = true;
-        }
         for (int l = 0; l < L; ++l) {
             const auto& r = m->lr[l];
             const auto& p = m->lp[l];
             float** cur = qkv[l & 1];
             float** nxt = qkv[(l + 1) & 1];
-            if (helpers) {
-                if (l + 1 < L)
-                    hipLaunchKernelGGL(attention_row_kernel_h<false>, dim3(grid), dim3(256), lds_h, st, cur[0], cur[1], cur[2], B, T, NG,
-                                       c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2, P + m->lp[l + 1].wqkv,
-                                       P + m->lp[l + 1].bqkv, nxt[0], nxt[1], nxt[2], out, op, ml);
-                else
-                    hipLaunchKernelGGL(attention_row_kernel_h<true>, dim3(grid), dim3(256), lds_h, st, cur[0], cur[1], cur[2], B, T, NG,
-                                       c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2, P + m->p_wc, P + m->p_bc,
-                                       nxt[0], nxt[1], nxt[2], out, op, ml);
-                prof.mark(l + 1 < L ? "attention_row" : "attention_row_last");
-                continue;
-            }
             if (l + 1 < L) {
                 hipLaunchKernelGGL(attention_row_kernel<false>, dim3(grid), dim3(256), 0, st, cur[0], cur[1], cur[2], B, T, NG, c, hb,
                                    R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2, P + m->lp[l + 1].wqkv,

@@ -854,7 +854,8 @@ __device__ __forceinline__ void layernorm_regs(const f32x16 (&x)[4], f32x4 (&xg)
 __device__ __forceinline__ void qkv_tail_m(const f32x4 (&xg)[16], const float* __restrict__ Wqkv, const float* bq,
                                            float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
                                            size_t row, float* ring, const DmaLanes& LA, int w, int n, int h,
-                                           bool store_ok = true /* per lane: this lane's row exists */) {
+                                           bool store_ok = true /* per lane: this lane's row exists */,
+                                           bool act = true /* wave-uniform: the wave owns rows (else: DMA + barriers only) */) {
     float* dst[3] = {q, k, v};
     f32x16 prev = zero16();
 #pragma unroll
@@ -863,7 +864,7 @@ __device__ __forceinline__ void qkv_tail_m(const f32x4 (&xg)[16], const float* _
         if (j + 1 < 12) dma_block(Wqkv + (size_t)(32 * (j + 1)) * D, LA, ring + ((j + 1) & 1) * WBLK, w);
         if (j > 0 && store_ok) store_block(dst[(j - 1) >> 2] + row * D + 32 * ((j - 1) & 3), prev, h);
         f32x16 acc = bias_block(bq + 32 * j, h);
-        gemm_lds_a(acc, ring + (j & 1) * WBLK, n, h, xg);
+        if (act) gemm_lds_a(acc, ring + (j & 1) * WBLK, n, h, xg);
         prev = acc;
     }
     if (store_ok) store_block(dst[2] + row * D + 96, prev, h);
@@ -924,8 +925,11 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
 // In : xg = attention context of the wave's rows (row layout), h1 = their residual-stream rows.
 // Pre: block 0 of Wo is in flight into ring buffer 0; lbo / lb1 / lb2 / lbn are being staged (the first ring
 //      barrier publishes both).  store_ok / out_ok (per lane): the lane's row exists and may be written.
+// act (wave-uniform): the wave owns rows.  A wave without a query block (ragged group) only keeps the weight stream and
+// the barriers going: it issues its share of the DMA and no MFMA (round 1 let it run the chain on zeros: 6 % of the
+// launch's MFMA instructions at T = 800, 3 idle slots in 28).
 template <bool LAST>
-__device__ __forceinline__ void row_chain_m(f32x4 (&xg)[16], f32x16 (&h1)[4], size_t row, bool store_ok, bool out_ok,
+__device__ __forceinline__ void row_chain_m(f32x4 (&xg)[16], f32x16 (&h1)[4], size_t row, bool store_ok, bool out_ok, bool act,
                                             float* ring, const float* lbo, const float* lb1, const float* lb2, const float* lbn,
                                             const DmaLanes& LA, const DmaLanes& LB, const float* __restrict__ Wo,
                                             const float* __restrict__ W1, const float* __restrict__ W2,
@@ -941,11 +945,13 @@ __device__ __forceinline__ void row_chain_m(f32x4 (&xg)[16], f32x16 (&h1)[4], si
             dma_block(Wo + (size_t)(32 * (nb + 1)) * D, LA, ring + ((nb + 1) & 1) * WBLK, w);
         else
             dma_block(W1, LA, ring, w);
-        h1[nb] += bias_block(lbo + 32 * nb, h);
-        gemm_lds_a(h1[nb], ring + (nb & 1) * WBLK, n, h, xg);
+        if (act) {
+            h1[nb] += bias_block(lbo + 32 * nb, h);
+            gemm_lds_a(h1[nb], ring + (nb & 1) * WBLK, n, h, xg);
+        }
     }
     SAVAD_STAMP(2);
-    layernorm_regs(h1, xg);
+    if (act) layernorm_regs(h1, xg);
     SAVAD_STAMP(3);
     // ---- FFN: 16 hidden chunks of 32; W1 chunk in ring buffer 0, W2 column slice in buffer 1.  The
     // accumulators START from the residual stream (h1 + b2: transformer.py:235-237), so h1 needs no
@@ -959,15 +965,17 @@ __device__ __forceinline__ void row_chain_m(f32x4 (&xg)[16], f32x16 (&h1)[4], si
         ring_acquire();
         dma_block(W2 + 32 * ch, LB, ring + WBLK, w);
         f32x16 a = bias_block(lb1 + 32 * ch, h);
-        gemm_lds_a(a, ring, n, h, xg);
+        if (act) {
+            gemm_lds_a(a, ring, n, h, xg);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
+            for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
+        }
         ring_acquire();
         if (ch + 1 < 16)
             dma_block(W1 + (size_t)(32 * (ch + 1)) * D, LA, ring, w);
         else if (!LAST)
             dma_block(Wn, LA, ring, w);
-        gemm_lds_b(o, ring + WBLK, n, h, a);
+        if (act) gemm_lds_b(o, ring + WBLK, n, h, a);
     }
     SAVAD_STAMP(5);
     if (!LAST) {
@@ -975,10 +983,10 @@ __device__ __forceinline__ void row_chain_m(f32x4 (&xg)[16], f32x16 (&h1)[4], si
         for (int nb = 0; nb < 4; ++nb) if (store_ok) store_block(hbuf + row * D + 32 * nb, o[nb], h);
     }
     SAVAD_STAMP(6);
-    layernorm_regs(o, xg);
+    if (act) layernorm_regs(o, xg);
     SAVAD_STAMP(7);
     if (!LAST) {
-        qkv_tail_m(xg, Wn, lbn, q, k, v, row, ring, LA, w, n, h, store_ok);
+        qkv_tail_m(xg, Wn, lbn, q, k, v, row, ring, LA, w, n, h, store_ok, act);
         SAVAD_STAMP(8);
     } else {
         float z0 = 0.0f, z1 = 0.0f;
@@ -1035,7 +1043,7 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
     // ---- combine the attention splits: ctx = sum_s w_s O_s / sum_s w_s l_s (lane-local)
     f32x4 xg[16];
     combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
-    row_chain_m<LAST>(xg, h1, row, true, row < (size_t)rows, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, q, k, v, out,
+    row_chain_m<LAST>(xg, h1, row, true, row < (size_t)rows, true, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, q, k, v, out,
                       w, n, h);
 }
 
@@ -1153,182 +1161,7 @@ __global__ __launch_bounds__(256, 2) void attention_row_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) xg[4 * nb + (r >> 2)][r & 3] = qvalid ? O[nb][r] * inv : 0.0f;
     }
-    row_chain_m<LAST>(xg, h1, row, qvalid, qvalid, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, qn, kn, vn, out, w, n, h);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fused stage with HELPER waves, for launches of at most one workgroup per CU (e.g. the headline [32,800,80]: 800
-// query blocks for 1024 SIMDs, so a wave that walks all 25 key tiles of its block IS the critical path).
-// A workgroup = up to 3 query-block waves ("mains") + 1 helper wave.  The mains walk key tiles [0, a) of their
-// blocks on K/V stream A; the helper walks the remaining tiles [a, NT) of each of those blocks in turn on a second
-// K/V stream B (same sequence, other tiles; 2 x 64 KiB of LDS), stores one (O, m, l) partial per block to global
-// memory, and the mains fold it in after the last step -- a = ceil(nq NT / (nq + 1)) gives every wave the same
-// number of steps (19 instead of 25 at T = 800, nq = 3).  Then the row chain runs exactly as in attention_row_kernel
-// (the helper takes part in the ring but owns no rows).
-// ---------------------------------------------------------------------------------------------
-#ifndef SAVAD_DBG_SLOTMASK
-#define SAVAD_DBG_SLOTMASK 1
-#endif
-template <bool LAST>
-__global__ __launch_bounds__(256, 2) void attention_row_kernel_h(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int B, int T, int NG, float c,
-    float* __restrict__ hbuf, const float* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ W1,
-    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ Wn,
-    const float* __restrict__ bn, float* __restrict__ qn, float* __restrict__ kn, float* __restrict__ vn,
-    float* __restrict__ out, float* __restrict__ Opart /* helper partials, [rows_pad][D] */, float* __restrict__ ml) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [stream A, B][buffer 2][K, V]: 8 tiles of 16 KiB
-    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int QB = (T + 31) / 32, NT = QB;
-    int b, g;
-    if (!xcd_balanced_map(B, NG, b, g)) return;
-    const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;  // NG = ceil(QB / 3): 1..3 blocks per group
-    const int nq = qb1 - qb0;
-    const bool helper = w == 3;
-    const bool active = w < nq;                         // a main with a query block (wave-uniform)
-    const int a = (nq * NT + nq) / (nq + 1);            // mains: tiles [0, a); helper: [a, NT) of each block
-    const int HT = NT - a, HS = nq * HT;                // helper tiles per block, helper steps (<= a)
-    const size_t kbase = (size_t)b * T;
-    int qb = qb0 + (helper || !active ? 0 : w);         // helper starts with the group's first block
-    size_t row = kbase + 32 * (size_t)qb + m;
-    bool qvalid = (active || (helper && HS > 0)) && (32 * qb + m) < T;
-
-    f32x4 xg[16];  // Q rows first, the normalised context afterwards
-#pragma unroll
-    for (int G8 = 0; G8 < 16; ++G8) xg[G8] = ld4(q + row * D + 8 * G8 + 4 * h);
-    f32x16 O[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
-    float m_run = NEG_BIG, l_run = 0.0f;
-
-    const DmaLanes LK = dma_lanes_rows32(D, true, w, lane), LV = dma_lanes_rows32(D, false, w, lane);
-    float* const sA = lds;
-    float* const sB = lds + 4 * KV_TILE_FLOATS;
-    auto stage = [&](float* sbuf, int slot, int tile) {
-        float* dst = sbuf + (slot & SAVAD_DBG_SLOTMASK) * 2 * KV_TILE_FLOATS;
-        dma_block(k + (kbase + 32 * (size_t)tile) * D, LK, dst, w);
-        dma_block(v + (kbase + 32 * (size_t)tile) * D, LV, dst + KV_TILE_FLOATS, w);
-    };
-    stage(sA, 0, 0);
-    if (HS > 0) stage(sB, 0, a);
-    for (int s = 0; s < a; ++s) {
-        wait_vmem_all();
-        __syncthreads();  // step s of both streams has landed for every wave; everyone is done with the other buffers
-        if (s + 1 < a) stage(sA, s + 1, s + 1);
-        if (s + 1 < HS) stage(sB, s + 1, a + (s + 1) % HT);
-        int jt;
-        const float* kb;
-#ifdef SAVAD_DBG_SIMPLE
-        if (helper || !active) continue;
-        jt = s;
-        kb = sA + (s & SAVAD_DBG_SLOTMASK) * 2 * KV_TILE_FLOATS;
-        if (false) {
-#else
-        if (helper) {
-#endif
-            if (s >= HS) continue;
-            jt = a + s % HT;
-            kb = sB + (s & 1) * 2 * KV_TILE_FLOATS;
-            if (s > 0 && s % HT == 0) {  // next block of the group: hand the finished partial over, start afresh
-                if (qvalid) store_attention_partial(Opart, ml, row, O, m_run, l_run, h);
-                qb = qb0 + s / HT;
-                row = kbase + 32 * (size_t)qb + m;
-                qvalid = (32 * qb + m) < T;
-#pragma unroll
-                for (int G8 = 0; G8 < 16; ++G8) xg[G8] = ld4(q + row * D + 8 * G8 + 4 * h);
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) O[nb] = zero16();
-                m_run = NEG_BIG;
-                l_run = 0.0f;
-            }
-        } else {
-            if (!active) continue;
-            jt = s;
-            kb = sA + (s & SAVAD_DBG_SLOTMASK) * 2 * KV_TILE_FLOATS;
-        }
-        const float* vb = kb + KV_TILE_FLOATS;
-        f32x16 sc = zero16();
-        const float* krow = kb + n * D;
-#pragma unroll
-        for (int G8 = 0; G8 < 16; ++G8) {
-            const f32x4 k4 = ld4(krow + 4 * ((2 * G8 + h) ^ (n & 15)));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sc = SAVAD_MFMA(k4[e], xg[G8][e], sc);
-        }
-        if (32 * jt + 32 > T) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
-                sc[r] = (32 * jt + jk < T) ? sc[r] : NEG_BIG;
-            }
-        }
-        online_softmax(sc, m_run, l_run, O, c);
-        const float* vp = vb + 4 * h * D + n;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
-        }
-    }
-#ifdef SAVAD_TIMING
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        g_savad_dbg[50] = nq; g_savad_dbg[51] = a; g_savad_dbg[52] = HT; g_savad_dbg[53] = HS; g_savad_dbg[54] = NT; g_savad_dbg[55] = NG;
-        g_savad_dbg[56] = (long long)(l_run * 1000.0f); g_savad_dbg[57] = T; g_savad_dbg[58] = B;
-    }
-#endif
-    if (helper && HS > 0 && qvalid) store_attention_partial(Opart, ml, row, O, m_run, l_run, h);
-    // ---- hand-over: the helper's partials become visible to its workgroup; the staging area becomes ring + biases
-    float* ring = lds;
-    float* lbo = lds + 2 * WBLK;
-    float* lb1 = lbo + D;
-    float* lb2 = lb1 + DFF;
-    float* lbn = lb2 + D;
-    if (helper) {  // the helper owns no rows: it rides along the row chain on the group's first block, storing nothing
-        qb = qb0;
-        row = kbase + 32 * (size_t)qb + m;
-        qvalid = false;
-    } else {
-        qvalid = active && (32 * qb + m) < T;
-    }
-    f32x16 h1[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        h1[nb] = zero16();
-        add_block(h1[nb], hbuf + row * D + 32 * nb, h);
-    }
-    if (!LAST && b == B - 1 && g == NG - 1) store_block(vn + ((size_t)B * T + m) * D + 32 * w, zero16(), h);
-    wait_vmem_all();          // this wave's partial stores have left
-    __threadfence_block();
-    __syncthreads();
-    const DmaLanes LA = dma_lanes_rows32(D, true, w, lane), LB = dma_lanes_rows128(DFF, w, lane);
-    dma_block(Wo, LA, ring, w);
-    stage_bias(lbo, bo, D);
-    stage_bias(lb1, b1, DFF);
-    stage_bias(lb2, b2, D);
-    if (!LAST) stage_bias(lbn, bn, 3 * D);
-    {
-        float w0 = 1.0f, w1 = 0.0f, lh = 0.0f;
-        const float* op = Opart + row * D + 4 * h;
-        if (HS > 0 && qvalid) {
-            const f32x2 th = *reinterpret_cast<const f32x2*>(ml + row * 2);
-            const float M = fmaxf(m_run, th[0]);
-            w0 = __builtin_amdgcn_exp2f((m_run - M) * c);
-            w1 = __builtin_amdgcn_exp2f((th[0] - M) * c);
-            lh = th[1];
-        }
-        const float inv = qvalid ? 1.0f / (l_run * w0 + lh * w1) : 0.0f;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                f32x4 oh = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (HS > 0 && qvalid) oh = ld4(op + 8 * (4 * nb + gg));
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    xg[4 * nb + gg][e] = qvalid ? (O[nb][4 * gg + e] * w0 + oh[e] * w1) * inv : 0.0f;
-            }
-    }
-    row_chain_m<LAST>(xg, h1, row, qvalid, qvalid, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, qn, kn, vn, out, w, n, h);
+    row_chain_m<LAST>(xg, h1, row, qvalid, qvalid, active, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, qn, kn, vn, out, w, n, h);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -86,17 +86,32 @@ __device__ __forceinline__ void load_hblock(f32x16 (&x)[4], const hres_t* hb, in
             for (int s = 0; s < 8; ++s) x[nb][8 * gp + s] += f[s];
         }
 }
-__device__ __forceinline__ void store_hblock(hres_t* hb, const f32x16 (&x)[4], int lane) {
+// Saturation is not silent: a wave that clamps anything adds the number of clamped elements to *satcnt (one atomic
+// per wave and stored block, only when it happens; savad_residual_saturations reads and clears the counter).  The reference's
+// fp32 residual cannot saturate; a model whose residual stream leaves +-65504 needs the fp32 path (precision "fp32").
+__device__ __forceinline__ void store_hblock(hres_t* hb, const f32x16 (&x)[4], int lane, unsigned* __restrict__ satcnt) {
+    float amax = 0.0f;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
             f32x8 f;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) f[s] = fminf(fmaxf(x[nb][8 * gp + s], -65504.0f), 65504.0f);
+            for (int s = 0; s < 8; ++s) {
+                amax = fmaxf(amax, fabsf(x[nb][8 * gp + s]));
+                f[s] = fminf(fmaxf(x[nb][8 * gp + s], -65504.0f), 65504.0f);
+            }
             const f16x8 t = __builtin_convertvector(f, f16x8);
             *reinterpret_cast<u32x4*>(hb + ((nb * 2 + gp) * 64 + lane) * 8) = __builtin_bit_cast(u32x4, t);
         }
+    if (__any(!(amax <= 65504.0f))) {  // rare: count exactly (NaN counts too)
+        unsigned c = 0;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c += !(fabsf(x[nb][r]) <= 65504.0f);
+        if (c) atomicAdd(satcnt, c);
+    }
 }
 
 // ---- LDS ring of 32 KiB blocks fed by asynchronous global->LDS DMA, shared by the NW waves of a
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf1
     const XT* __restrict__ x, int B, int T, int F, int nblk, const char* __restrict__ win_frag,
     const float* __restrict__ bin, const float* __restrict__ pe, const char* __restrict__ wqkv_frag,
     const float* __restrict__ bqkv, hres_t* __restrict__ hbuf, char* __restrict__ qf, char* __restrict__ kf,
-    char* __restrict__ vtf, float qscale) {
+    char* __restrict__ vtf, float qscale, unsigned* __restrict__ satcnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using R = Ring<NW>;
     float* lbq = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf1
         for (int nb = 0; nb < 4; ++nb)
             h0[nb] = SAVAD_MFMA_BF16(ldfrag(win_frag + ((size_t)(nb * KS + ks) * 64 + lane) * 16), xf, h0[nb]);
     }
-    store_hblock(hbuf + (size_t)blk * HBLK_FLOATS, h0, lane);
+    store_hblock(hbuf + (size_t)blk * HBLK_FLOATS, h0, lane, satcnt);
     f32x4 xg[16];
     layernorm_regs(h0, xg);
     bf16x8 xp[8];
@@ -508,6 +523,7 @@ struct RowArgsBf16 {
     char *qf, *kf, *vtf;  // !LAST: written (the NEXT layer's buffers)
     float* out;           // LAST
     float qscale;
+    unsigned* satcnt;     // residual-stream saturation counter (store_hblock)
 };
 
 // The whole row chain of block `blk` for one wave.  In: xp = the block's attention context as B-operand fragments.
@@ -582,7 +598,7 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
         advance(2 + 2 * ch);  // W2 chunk
         gemm_ring(o, ring.slot(2 + 2 * ch), ap, lane);
     }
-    if (!LAST && live) store_hblock(hb, o, lane);
+    if (!LAST && live) store_hblock(hb, o, lane, A.satcnt);
     layernorm_regs(o, xg);
     if (!LAST) {
         pack_row(xg, xp);

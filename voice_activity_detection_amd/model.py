@@ -215,6 +215,17 @@ class SelfAttentiveVAD(nn.Module):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(_lib.load().savad_reserve(self._handle, int(max_frames), ctypes.c_void_p(stream)))
 
+    def residual_saturations(self) -> int:
+        """precision "bf16" stores the residual stream as fp16 between kernels (+-65504): number of elements that had to
+        be clamped since the last call (0 on every workload the parity tests know; > 0 means: use precision "fp32").
+        Synchronises the current stream."""
+        if self._handle is None:
+            return 0
+        n = ctypes.c_ulonglong()
+        stream = torch.cuda.current_stream(self._handle_device).cuda_stream
+        _lib.check(_lib.load().savad_residual_saturations(self._handle, ctypes.byref(n), ctypes.c_void_p(stream)))
+        return int(n.value)
+
     # ---- profiling hooks used by bench.py -------------------------------------------------------
     def set_profiling(self, capacity: int):
         _lib.check(_lib.load().savad_set_profiling(self._handle, int(capacity)))
