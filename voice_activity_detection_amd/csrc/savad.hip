@@ -3,6 +3,9 @@
 //   input_qkv -> [attention(l) -> row(l)] x L      (row(L-1) ends in classifier + log-softmax)
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
+#ifdef SAVAD_ATTN2  // experiment builds only (scripts/ubench/attention2): -DSAVAD_ATTN2='"<header>"' adds bf16 row_mode 6
+#include SAVAD_ATTN2
+#endif
 #include <type_traits>
 #include "savad_logmel.h"
 #include "savad_post.h"
@@ -500,6 +503,12 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
+#ifdef SAVAD_ATTN2
+    if (m && mode == 6) {
+        m->row_mode = 6;
+        return SAVAD_OK;
+    }
+#endif
     if (!m || mode < 0 || mode > 4) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
@@ -653,6 +662,20 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
             if (T <= 32) {
                 hipLaunchKernelGGL(bf::attention_packed_kernel_bf16, dim3((bp.nblk + 3) / 4), dim3(256), 0, st, qf, kf, vtf, ctxf,
                                    B, T, bp.nblk);
+#ifdef SAVAD_ATTN2
+            } else if (m->row_mode == 6) {
+                const int QB = (T + 31) / 32, NP = (QB + 1) / 2;
+                int NG = B >= 256 ? 1 : (256 + B - 1) / B;
+                if (NG > (NP + 3) / 4) NG = (NP + 3) / 4;
+                if (NG < 1) NG = 1;
+                static bool attr_done = false;
+                if (!attr_done) {
+                    if ((rc = allow_lds(bf::attention2_kernel_bf16, bf::A2_NRING * bf::A2_STAGE_BYTES))) return;
+                    attr_done = true;
+                }
+                hipLaunchKernelGGL(bf::attention2_kernel_bf16, dim3(8 * (((long)B * NG + 7) / 8)), dim3(256), bf::A2_NRING * bf::A2_STAGE_BYTES, st,
+                                   qf, kf, vtf, ctxf, B, T, NG);
+#endif
             } else {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
                 hipLaunchKernelGGL((bf::attention_kernel_bf16<NW>), dim3(8 * (((long)B * NG + 7) / 8)), wg, ring, st, qf, kf, vtf, ctxf, B,
