@@ -242,6 +242,44 @@ def test_packed_attention_inside_row_kernel(torch_cuda, model, golden, state1234
         model.row_mode = 0
 
 
+def test_single_launch_packed_forward(torch_cuda, model, golden, state1234):
+    """T <= 32: the whole forward in ONE launch (packed_forward_kernel, row_mode 5; what automatic picks up to 256
+    packed tiles).  Against the goldens / the oracle for every T <= 32 tile shape (1 .. 32 sequences per tile, ragged
+    last tile, a batch larger than one round of the CUs, odd feature sizes, other depths), and its per-sequence
+    results must not depend on what else shares the tile or the batch."""
+    from oracle import oracle
+    from voice_activity_detection_amd import seeded_state_dict
+
+    torch = torch_cuda
+    assert np.abs(run(torch, model, feats(101, (4, 7, 80)), row_mode=5) - golden["g1_out"]).max() < TIGHT
+    assert np.abs(run(torch, model, feats(77, (1, 7, 80)), row_mode=5) - golden["g4_B1T7"]).max() < TIGHT
+    y = run(torch, model, feats(78, (1000, 7, 80)), row_mode=0)  # 250 tiles: automatic = the single launch
+    assert np.abs(y[:8] - golden["g4_B1000T7_head"]).max() < TIGHT and np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < TIGHT
+    assert np.array_equal(y, run(torch, model, feats(78, (1000, 7, 80)), row_mode=5))
+    for T in (1, 2, 5, 10, 11, 16, 17, 31, 32):
+        y = run(torch, model, feats(400 + T, (3, T, 80)), row_mode=5)
+        assert np.abs(y - golden[f"g4_T{T}"]).max() < TIGHT, T
+    for shape in [(5, 7, 80), (37, 3, 80), (1, 1, 80), (33, 1, 80), (9, 32, 80), (7, 13, 80), (1500, 7, 80), (300, 16, 80)]:
+        x = feats(7 + shape[0], shape)
+        y = run(torch, model, x, row_mode=5)
+        assert np.abs(y - oracle.forward(state1234, x)).max() < TIGHT, shape
+        assert np.array_equal(y, run(torch, model, x, row_mode=5)), shape  # deterministic
+        assert np.abs(y - run(torch, model, x, row_mode=1)).max() < 2e-5, shape  # the per-layer launches
+    x = feats(91, (41, 7, 80))
+    whole = run(torch, model, x, row_mode=5)
+    for i in (0, 3, 17, 40):  # alone in the batch: same bits at the same tile slot (4 sequences per tile), else fp32 summation order
+        alone = run(torch, model, x[i:i + 1], row_mode=5)[0]
+        assert np.array_equal(alone, whole[i]) if i % 4 == 0 else np.abs(alone - whole[i]).max() < 2e-6, i
+    assert np.array_equal(run(torch, model, x[4:12], row_mode=5), whole[4:12])  # whole tiles move together
+    for F in (257, 13):  # zero-padded K of the input Linear, K > 128 in chunks
+        st = seeded_state_dict(900 + F, feature_size=F)
+        xf = feats(901 + F, (5, 7, F))
+        assert np.abs(run(torch, make_model(torch, st, F=F), xf, row_mode=5) - oracle.forward(st, xf)).max() < TIGHT, F
+    st = seeded_state_dict(55, num_layers=5)
+    x = feats(56, (6, 7, 80))
+    assert np.abs(run(torch, make_model(torch, st, L=5), x, row_mode=5) - oracle.forward(st, x)).max() < TIGHT
+
+
 def test_properties_full_size(torch_cuda, model):
     # size-independent properties at config-2 size: normalisation, batch-permutation equivariance
     # (sequences are independent: bit-exact), determinism

@@ -156,7 +156,8 @@ Workspace plan(const savad_model* m, int B, int T) {
     // N-split works through ceil(tiles / 256) rounds of ~45 us, M-split through one round of ~118 us per 256 workgroups
     // of 128 rows: M wins from the third N-split round on (more than 512 tiles of 32 rows).  Measured at T=800: B=20
     // (500 tiles) N 0.504 / M 0.648 ms; B=24 (600 tiles) N 0.611 / M 0.589 ms.
-    w.msplit = m->row_mode == 2 || m->row_mode == 3 || (m->row_mode == 0 && w.rows_pad / 32 > 512);
+    const int row_mode = m->row_mode == 5 ? 0 : m->row_mode;  // 5 only differs from automatic for T <= 32 (savad_forward)
+    w.msplit = row_mode == 2 || row_mode == 3 || (row_mode == 0 && w.rows_pad / 32 > 512);
     // In the M-split regime without key splits the attention stage and the row chain of a query-block group
     // run back to back in one workgroup (attention_row_kernel).  row_mode 2 keeps them as separate launches.
     // Automatic: only when a query-block group keeps at least 80 % of its 4 wave slots busy -- waves without a
@@ -165,7 +166,7 @@ Workspace plan(const savad_model* m, int B, int T) {
     // 7) 0.640 / 0.668).
     const int QBp = (T + 31) / 32, NGp = (QBp + 3) / 4;
     const bool ragged = QBp * 5 < NGp * 4 * 4;  // QB / (4 NG) < 0.8
-    w.fused = w.msplit && T > 32 && w.S == 1 && (m->row_mode == 3 || (m->row_mode != 2 && !ragged));
+    w.fused = w.msplit && T > 32 && w.S == 1 && (row_mode == 3 || (row_mode != 2 && !ragged));
     size_t off = 0;
     w.h = off;
     off += w.rows_pad * D;
@@ -326,7 +327,8 @@ BlockPlan plan_blocks(const savad_model* m, int B, int T) {
     const bool ragged = QBp * 5 < NGp * 4 * 4;  // fewer than 80 % of a group's wave slots hold a query block
     // (below one workgroup per CU the forward is launch / latency bound and fusing wins even with idle slots:
     // B=64, T=50: 0.070 / 0.074 ms; B=32, T=160: 0.072 / 0.080 ms)
-    p.fused = T > 32 && (m->row_mode == 3 || (m->row_mode == 0 && groups <= 1024 && (!ragged || groups <= 256)));
+    const bool automatic = m->row_mode == 0 || m->row_mode == 5;
+    p.fused = T > 32 && (m->row_mode == 3 || (automatic && groups <= 1024 && (!ragged || groups <= 256)));
     p.q2 = p.k2 = p.vt2 = off;
     if (p.fused) {
         p.q2 = off;
@@ -509,7 +511,7 @@ SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
         return SAVAD_OK;
     }
 #endif
-    if (!m || mode < 0 || mode > 4) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 5) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -753,6 +755,31 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
 
     const int tiles_m = (int)(ws.rows_pad / 128);
     const bool msplit = ws.msplit;
+    // T <= 32 in the small-batch regime (the reference pipeline's 7-frame windows): the whole forward is ONE launch,
+    // a workgroup per packed tile of floor(32/T) sequences keeps every activation on its CU (packed_forward_kernel).
+    // Automatic while the tiles fit one round of the 256 CUs; row_mode 5 forces it for any T <= 32 batch.
+    if (T <= 32 && L <= PACKED_MAX_LAYERS &&
+        (m->row_mode == 5 || (m->row_mode == 0 && !msplit && (B + 32 / T - 1) / (32 / T) <= 256))) {
+        const int G = 32 / T, nblk = (B + G - 1) / G;
+        PackedModel pm;
+        for (int l = 0; l < L; ++l) {
+            const auto& r = m->lr[l];
+            const auto& p = m->lp[l];
+            pm.layer[l] = PackedLayer{P + p.wqkv, P + p.bqkv, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2};
+        }
+        for (int l = L; l < PACKED_MAX_LAYERS; ++l) pm.layer[l] = pm.layer[0];
+        pm.win = win_fp32(m);
+        pm.bin = R + m->r_bin;
+        pm.pe = m->d_pe;
+        pm.wc = P + m->p_wc;
+        pm.bc = P + m->p_bc;
+        pm.L = L;
+        hipLaunchKernelGGL(packed_forward_kernel, dim3(nblk), dim3(256), 0, st, x, (int)ws.rows, T, F, pm, c, out, G * T);
+        prof.mark("packed_forward");
+        prof.done();
+        HIP_TRY(hipGetLastError());
+        return SAVAD_OK;
+    }
     if (msplit)
         hipLaunchKernelGGL(input_qkv_kernel_m, dim3(tiles_m), dim3(256), 0, st, x, (int)ws.rows, T, F, win_fp32(m),
                            R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);

@@ -782,6 +782,224 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     SAVAD_STAMP(38);
 }
 
+// ---------------------------------------------------------------------------------------------
+// T <= 32, whole forward in ONE launch (the reference pipeline's own shape: 7-frame windows,
+// vad/predictors/vad_predictor.py:77-112).  A workgroup owns one packed tile (floor(32/T) whole sequences) for
+// ALL layers; nothing but x, the weights and the log-probabilities crosses the CU boundary: the residual
+// stream lives in registers (wave w: features [32w, 32w+32) in row layout), LayerNorm rows are exchanged
+// through LDS as in row_kernel, and the attention never leaves the registers either:
+//   * wave w projects ITS 32 features of Q and K in row layout and ITS 32 features of V TRANSPOSED (MFMA
+//     operands swapped: A = activation rows, B = weight rows -> lane = feature, registers = rows);
+//   * S^T = K Q^T is a sum over features: every wave contracts its own 32 (16 MFMAs, operands straight from
+//     the Q / K accumulators), the four partial score tiles are summed through LDS in a fixed order (all waves
+//     hold identical scores), the softmax is lane-local and redundant per wave (16 exps);
+//   * O^T = V^T P^T for the wave's own features: A = the transposed V accumulator, B = the probabilities, again
+//     16 MFMAs; the context block joins the other three through the LDS exchange buffer for the out-projection.
+// 32 attention MFMAs per wave and layer instead of the 128 redundant ones of row_kernel's packed mode, no
+// q / k / v / h round trip through L2 and one launch instead of four.
+// ---------------------------------------------------------------------------------------------
+constexpr int PACKED_MAX_LAYERS = 8;
+struct PackedLayer {
+    const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2;  // wqkv / bqkv / w1 / b1: LayerNorm affine folded in
+};
+struct PackedModel {
+    PackedLayer layer[PACKED_MAX_LAYERS];
+    const float *win, *bin, *pe, *wc, *bc;
+    int L;
+};
+constexpr int LBIAS = DFF + D + 3 * D + D;  // b1 | b2 | bqkv | bo, per parity
+
+__global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __restrict__ x, int rows, int T, int F, PackedModel M,
+                                                                float c, float* __restrict__ out, int tile_rows) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE * XLD + 12 * TILE * PLD + 2 * LBIAS];
+    float* xb0 = lds;
+    float* xb1 = lds + TILE * XLD;
+    float* pbuf = lds + 2 * TILE * XLD;  // reduce-scatter blocks [dest 4][slot 3][32][PLD]; also the 4 partial score tiles
+    float* lbias = pbuf + 12 * TILE * PLD;
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t row = (size_t)blockIdx.x * tile_rows + m;
+    const bool in_batch = row < (size_t)rows;
+    const bool lane_ok = m < tile_rows && in_batch;  // lanes past the tile alias the next tile's rows: computed, never stored
+    const int tq = m / T;
+
+    auto stage_layer_bias = [&](int l) {
+        float* lb = lbias + (l & 1) * LBIAS;
+        const PackedLayer& W = M.layer[l];
+        stage_bias(lb, W.b1, DFF);
+        stage_bias(lb + DFF, W.b2, D);
+        stage_bias(lb + DFF + D, W.bqkv, 3 * D);
+        stage_bias(lb + DFF + 4 * D, W.bo, D);
+    };
+    WBlock wa, wb;
+    stage_layer_bias(0);
+    wload_k128(wa, M.layer[0].wqkv + (size_t)(32 * w + n) * D + 4 * h);  // layer 0's query block: in flight under the input GEMM
+
+    // ---- input Linear + positional encoding (self_attention.py:12-16,24): K = F in chunks of 128, all loads of a
+    // chunk requested before its first MFMA
+    f32x16 own = zero16();
+    {
+        const float* xp = x + (in_batch ? row : 0) * (size_t)F + 4 * h;
+        const float* wp = M.win + (size_t)(32 * w + n) * F + 4 * h;
+        const int nG = F / 8;
+        for (int G0 = 0; G0 < nG; G0 += 16) {
+            f32x4 xin[16];
+#pragma unroll
+            for (int G = 0; G < 16; ++G) {
+                if (G0 + G < nG) {
+                    xin[G] = ld4(xp + 8 * (G0 + G));
+                    wb.v[G] = ld4(wp + 8 * (G0 + G));
+                }
+            }
+#pragma unroll
+            for (int G = 0; G < 16; ++G) {
+                if (G0 + G < nG) {
+                    const f32x4 x4 = in_batch ? xin[G] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) own = SAVAD_MFMA(wb.v[G][e], x4[e], own);
+                }
+            }
+        }
+        add_bias(own, M.bin + 32 * w, h);
+        const int t = (int)((in_batch ? row : 0) % (size_t)T);
+        add_block(own, M.pe + (size_t)t * D + 32 * w, h);
+    }
+
+    f32x4 xg[16];
+#pragma unroll 1
+    for (int l = 0; l < M.L; ++l) {
+        const PackedLayer& W = M.layer[l];
+        const float* lb = lbias + (l & 1) * LBIAS;
+        const float *lb1 = lb, *lb2 = lb + DFF, *lbn = lb + DFF + D, *lbo = lb + DFF + 4 * D;
+        // ---- LN1 + Q, K (row layout) and V^T blocks of this wave's 32 features; wa = query block (requested a block ago)
+        store_block(xb0 + m * XLD + 32 * w, own, h);
+        __syncthreads();
+        if (l + 1 < M.L) stage_layer_bias(l + 1);  // other parity; every wave is past the previous layer's last bias read
+        read_rows_layernorm(xb0, m, h, xg);
+        wload_k128(wb, W.wqkv + (size_t)(D + 32 * w + n) * D + 4 * h);
+        f32x16 qb = bias_block(lbn + 32 * w, h);
+        wmma_k128(qb, wa, xg);
+        wload_k128(wa, W.wqkv + (size_t)(2 * D + 32 * w + n) * D + 4 * h);
+        f32x16 kb = bias_block(lbn + D + 32 * w, h);
+        wmma_k128(kb, wb, xg);
+        wload_k128(wb, W.wo + (size_t)(32 * w + n) * D + 4 * h);
+        f32x16 vT;  // vT[4g+s] = v[row 8g+4h+s][feature 32w + n]
+        {
+            const float bv = lbn[2 * D + 32 * w + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vT[r] = bv;
+#pragma unroll
+            for (int G = 0; G < 16; ++G)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vT = SAVAD_MFMA(xg[G][e], wa.v[G][e], vT);
+        }
+        wload_k128(wa, W.w1 + (size_t)(128 * w + n) * D + 4 * h);  // first FFN block
+        // ---- scores: this wave's 32-feature share, summed over the waves through LDS
+        f32x16 sc = zero16();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc = SAVAD_MFMA(kb[r], qb[r], sc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st4(pbuf + ((w * 4 + g) * 64 + lane) * 4, f32x4{sc[4 * g], sc[4 * g + 1], sc[4 * g + 2], sc[4 * g + 3]});
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 s4 = ld4(pbuf + ((0 * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) s4 += ld4(pbuf + ((ww * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc[4 * g + e] = s4[e];
+        }
+        // block-diagonal mask (a key belongs to the query's own sequence), softmax over the single key tile
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
+            const bool ok = (jk < tile_rows) && (jk / T == tq) && ((size_t)blockIdx.x * tile_rows + jk < (size_t)rows);
+            sc[r] = ok ? sc[r] : NEG_BIG;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = half_max(mx);
+        const float mc = mx * c;
+        float rs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -mc));
+            rs += sc[r];
+        }
+        const float inv = lane_ok ? 1.0f / half_sum(rs) : 0.0f;
+        f32x16 ctx = zero16();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctx = SAVAD_MFMA(vT[r], sc[r], ctx);
+        ctx *= inv;
+        store_block(xb1 + m * XLD + 32 * w, ctx, h);
+        __syncthreads();
+#pragma unroll
+        for (int G = 0; G < 16; ++G) xg[G] = ld4(xb1 + m * XLD + 8 * G + 4 * h);
+        // ---- out-projection + residual (accumulator starts at the residual stream), LN2
+        f32x16 h1 = own + bias_block(lbo + 32 * w, h);
+        wmma_k128(h1, wb, xg);
+        store_block(xb0 + m * XLD + 32 * w, h1, h);  // xb0's LN1 readers passed two barriers since
+        __syncthreads();
+        read_rows_layernorm(xb0, m, h, xg);
+        // ---- FFN: hidden units [128w, 128w+128) in 4 chunks of 32 (wa = W1 chunk, wb = W2 slice), as in row_kernel
+        f32x16 o[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) o[nb] = zero16();
+#pragma unroll 1
+        for (int ch = 0; ch < 4; ++ch) {
+            const int hid0 = 128 * w + 32 * ch;
+            wload_w2(wb, W.w2 + (size_t)n * DFF + hid0 + 4 * h, DFF);
+            f32x16 a = bias_block(lb1 + hid0, h);
+            wmma_k128(a, wa, xg);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
+            if (ch + 1 < 4)
+                wload_k128(wa, W.w1 + (size_t)(hid0 + 32 + n) * D + 4 * h);
+            else if (l + 1 < M.L)
+                wload_k128(wa, M.layer[l + 1].wqkv + (size_t)(32 * w + n) * D + 4 * h);  // next layer's query block
+            wmma_w2(o, wb, a);
+        }
+        // reduce-scatter the 4 K-split partials: wave w ends up with feature block w (the score tiles' readers
+        // passed two barriers since)
+        own = o[0];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb == w) {
+                own = o[nb];
+            } else {
+                const int slot = (w - nb - 1) & 3;
+                store_block(pbuf + ((nb * 3 + slot) * TILE + m) * PLD, o[nb], h);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int slot = 0; slot < 3; ++slot) add_block(own, pbuf + ((w * 3 + slot) * TILE + m) * PLD, h);
+        own += bias_block(lb2 + 32 * w, h);
+        own += h1;  // residual onto the un-normalised stream (transformer.py:235-237)
+    }
+    // ---- final LayerNorm (folded into the classifier) + Linear(D, 2) + log-softmax (self_attention.py:26-28)
+    store_block(xb0 + m * XLD + 32 * w, own, h);
+    __syncthreads();
+    if (w == 0) {
+        read_rows_layernorm(xb0, m, h, xg);
+        float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const f32x4 c0 = ld4(M.wc + 8 * G + 4 * h), c1 = ld4(M.wc + D + 8 * G + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z0 = __builtin_fmaf(xg[G][e], c0[e], z0);
+                z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
+            }
+        }
+        z0 = half_sum(z0) + M.bc[0];
+        z1 = half_sum(z1) + M.bc[1];
+        const float mx = fmaxf(z0, z1);
+        const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+        if (h == 0 && lane_ok) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+    }
+}
+
 // =============================================================================================
 // M-split row kernels (used when the batch is large enough to fill the chip with 128-row tiles).
 // A workgroup = 128 data rows = 4 waves x 32 rows; every wave runs the WHOLE row-wise chain for
