@@ -93,9 +93,11 @@ struct savad_model {
     // packed offsets
     struct LayerPacked {
         size_t wqkv, bqkv, w1, b1;
+        size_t frag;  // the layer's matrices in fragment order (packed_forward_kernel)
     };
     std::vector<LayerPacked> lp;
     size_t p_wc, p_bc;
+    size_t p_bias = 0;  // [L][LBIAS] b1' | b2 | bqkv' | bo (packed_forward_kernel stages them in one sweep)
     int FP = 0;           // feature size rounded up to a multiple of 16 (kernels' K granularity)
     size_t p_win_pad = 0;  // [D][FP] zero-padded copy of input_layer.0.weight (only when FP != feature_size)
 };
@@ -250,6 +252,18 @@ int prepare_weights(savad_model* m, hipStream_t st) {
         if ((rc = fold(m, st, r.wk, r.bk, r.ln1w, r.ln1b, p.wqkv + (size_t)D * D, p.bqkv + D, D, D))) return rc;
         if ((rc = fold(m, st, r.wv, r.bv, r.ln1w, r.ln1b, p.wqkv + (size_t)2 * D * D, p.bqkv + 2 * D, D, D))) return rc;
         if ((rc = fold(m, st, r.w1, r.b1, r.ln2w, r.ln2b, p.w1, p.b1, DFF, D))) return rc;
+        float* frag = m->d_packed + p.frag;
+        hipLaunchKernelGGL(pack_frag32_kernel, dim3(192), dim3(256), 0, st, m->d_packed + p.wqkv, 0, 12, frag);
+        hipLaunchKernelGGL(pack_frag32_kernel, dim3(64), dim3(256), 0, st, m->d_raw + r.wo, 0, 4, frag + 12 * FRAG_BLOCK);
+        hipLaunchKernelGGL(pack_frag32_kernel, dim3(256), dim3(256), 0, st, m->d_packed + p.w1, 0, 16, frag + 16 * FRAG_BLOCK);
+        hipLaunchKernelGGL(pack_frag32_kernel, dim3(256), dim3(256), 0, st, m->d_raw + r.w2, 1, 16, frag + 32 * FRAG_BLOCK);
+        HIP_TRY(hipGetLastError());
+        float* lb = m->d_packed + m->p_bias + (size_t)l * LBIAS;
+        const size_t f = sizeof(float);
+        HIP_TRY(hipMemcpyAsync(lb, m->d_packed + p.b1, DFF * f, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(lb + DFF, m->d_raw + r.b2, D * f, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(lb + DFF + D, m->d_packed + p.bqkv, 3 * D * f, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(lb + DFF + 4 * D, m->d_raw + r.bo, D * f, hipMemcpyDeviceToDevice, st));
     }
     int rc = fold(m, st, m->r_wc, m->r_bc, m->r_lnf_w, m->r_lnf_b, m->p_wc, m->p_bc, 2, D);
     if (rc) return rc;
@@ -424,11 +438,15 @@ SAVAD_EXPORT int savad_create(const savad_config* cfg, savad_handle* out) {
         m->packed_floats += (size_t)DFF * D;
         q.b1 = m->packed_floats;
         m->packed_floats += DFF;
+        q.frag = m->packed_floats;
+        m->packed_floats += FRAG_LAYER;
     }
     m->r_lnf_w = add_param(m, "encoder.layer_norm.weight", D);
     m->r_lnf_b = add_param(m, "encoder.layer_norm.bias", D);
     m->r_wc = add_param(m, "classifier.weight", 2 * D);
     m->r_bc = add_param(m, "classifier.bias", 2);
+    m->p_bias = m->packed_floats;
+    m->packed_floats += (size_t)L * LBIAS;
     m->p_wc = m->packed_floats;
     m->packed_floats += 2 * D;
     m->p_bc = m->packed_floats;
@@ -762,11 +780,8 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
         (m->row_mode == 5 || (m->row_mode == 0 && !msplit && (B + 32 / T - 1) / (32 / T) <= 256))) {
         const int G = 32 / T, nblk = (B + G - 1) / G;
         PackedModel pm;
-        for (int l = 0; l < L; ++l) {
-            const auto& r = m->lr[l];
-            const auto& p = m->lp[l];
-            pm.layer[l] = PackedLayer{P + p.wqkv, P + p.bqkv, R + r.wo, R + r.bo, P + p.w1, P + p.b1, R + r.w2, R + r.b2};
-        }
+        for (int l = 0; l < L; ++l) pm.layer[l] = PackedLayer{P + m->lp[l].frag};
+        pm.bias = P + m->p_bias;
         for (int l = L; l < PACKED_MAX_LAYERS; ++l) pm.layer[l] = pm.layer[0];
         pm.win = win_fp32(m);
         pm.bin = R + m->r_bin;

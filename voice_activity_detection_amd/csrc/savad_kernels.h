@@ -799,41 +799,68 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
 // q / k / v / h round trip through L2 and one launch instead of four.
 // ---------------------------------------------------------------------------------------------
 constexpr int PACKED_MAX_LAYERS = 8;
+// Weights in FRAGMENT ORDER (pack_frag32_kernel): the 16 KB a wave consumes as one A-operand block are contiguous and
+// register i of lane l sits at (i * 64 + l) * 16 bytes, so one load instruction reads 1 KB = 8 whole cache lines.
+// (Row-major blocks make every load touch 32 lines for 32 bytes each, four instructions per line, all in flight
+// together: the L2 sees the stream four times over.)  48 blocks per layer:
+//   0..11 Wqkv' rows 32b..32b+31 | 12..15 Wo rows | 16..31 W1' rows | 32..47 W2 columns 32(b-32).. (all 128 rows)
+constexpr int FRAG_BLOCK = 4096, FRAG_LAYER = 48 * FRAG_BLOCK;  // floats
 struct PackedLayer {
-    const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2;  // wqkv / bqkv / w1 / b1: LayerNorm affine folded in
+    const float* frag;  // Wqkv / W1: LayerNorm affine folded in
 };
+// The request and the wait are written out by hand: left to itself hipcc sinks the 16 loads of a block down to
+// their first use once the Q / K / V accumulators join the two weight buffers and the activation rows in the
+// register file ("global_load; s_waitcnt vmcnt(0); 4 MFMAs", 16 times per block -- the prefetch is gone).  The
+// waits name the buffer as an in/out operand so that no MFMA reading it can be scheduled above them; the layer
+// loop issues no other vector-memory instruction, so the counts are exact.
+__device__ __forceinline__ void wload_frag(WBlock& wb, const float* __restrict__ frag, int block, int voff /* lane * 16 bytes */) {
+    const float* p = frag + (size_t)block * FRAG_BLOCK;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(wb.v[i]) : "v"(voff), "s"(p + (i >> 2) * 1024), "n"((i & 3) * 1024));
+}
+template <int PENDING>  // younger requests allowed to stay in flight (16 per block)
+__device__ __forceinline__ void wwait(WBlock& wb) {
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(wb.v[0]), "+v"(wb.v[1]), "+v"(wb.v[2]), "+v"(wb.v[3]), "+v"(wb.v[4]), "+v"(wb.v[5]), "+v"(wb.v[6]), "+v"(wb.v[7]),
+                   "+v"(wb.v[8]), "+v"(wb.v[9]), "+v"(wb.v[10]), "+v"(wb.v[11]), "+v"(wb.v[12]), "+v"(wb.v[13]), "+v"(wb.v[14]),
+                   "+v"(wb.v[15])
+                 : "n"(PENDING));
+}
 struct PackedModel {
     PackedLayer layer[PACKED_MAX_LAYERS];
     const float *win, *bin, *pe, *wc, *bc;
+    const float* bias;  // [L][LBIAS]: b1' | b2 | bqkv' | bo of every layer, contiguous
     int L;
 };
-constexpr int LBIAS = DFF + D + 3 * D + D;  // b1 | b2 | bqkv | bo, per parity
+constexpr int LBIAS = DFF + D + 3 * D + D;  // b1 | b2 | bqkv | bo
 
 __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __restrict__ x, int rows, int T, int F, PackedModel M,
                                                                 float c, float* __restrict__ out, int tile_rows) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * TILE * XLD + 12 * TILE * PLD + 2 * LBIAS];
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE * XLD + 12 * TILE * PLD + PACKED_MAX_LAYERS * LBIAS];
     float* xb0 = lds;
     float* xb1 = lds + TILE * XLD;
     float* pbuf = lds + 2 * TILE * XLD;  // reduce-scatter blocks [dest 4][slot 3][32][PLD]; also the 4 partial score tiles
-    float* lbias = pbuf + 12 * TILE * PLD;
+    float* lbias = pbuf + 12 * TILE * PLD;  // every layer's biases, staged once
     const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t row = (size_t)blockIdx.x * tile_rows + m;
     const bool in_batch = row < (size_t)rows;
     const bool lane_ok = m < tile_rows && in_batch;  // lanes past the tile alias the next tile's rows: computed, never stored
     const int tq = m / T;
+    const int voff = lane * 16;
 
-    auto stage_layer_bias = [&](int l) {
-        float* lb = lbias + (l & 1) * LBIAS;
-        const PackedLayer& W = M.layer[l];
-        stage_bias(lb, W.b1, DFF);
-        stage_bias(lb + DFF, W.b2, D);
-        stage_bias(lb + DFF + D, W.bqkv, 3 * D);
-        stage_bias(lb + DFF + 4 * D, W.bo, D);
-    };
+    SAVAD_STAMP(48);
+    // Weight stream: 12 blocks of 16 KB per wave and layer (Q K V Wo, then W1 / W2 slices alternating), two register
+    // buffers, every block requested one block (64 MFMAs = 4096 cycles) before its first use.
     WBlock wa, wb;
-    stage_layer_bias(0);
-    wload_k128(wa, M.layer[0].wqkv + (size_t)(32 * w + n) * D + 4 * h);  // layer 0's query block: in flight under the input GEMM
+    // all biases -> LDS (requested now, stored after the input GEMM, published by the first barrier)
+    constexpr int NBT = (PACKED_MAX_LAYERS * LBIAS / 4 + 255) / 256;
+    const int nb4 = M.L * (LBIAS / 4);
+    f32x4 bt[NBT];
+#pragma unroll
+    for (int j = 0; j < NBT; ++j)
+        if ((int)threadIdx.x + 256 * j < nb4) bt[j] = ld4(M.bias + 4 * (threadIdx.x + 256 * j));
 
     // ---- input Linear + positional encoding (self_attention.py:12-16,24): K = F in chunks of 128, all loads of a
     // chunk requested before its first MFMA
@@ -846,17 +873,19 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
             f32x4 xin[16];
 #pragma unroll
             for (int G = 0; G < 16; ++G) {
-                if (G0 + G < nG) {
-                    xin[G] = ld4(xp + 8 * (G0 + G));
-                    wb.v[G] = ld4(wp + 8 * (G0 + G));
-                }
+                const int Gc = G0 + G < nG ? G0 + G : nG - 1;  // past the end: a valid address, the product is dropped below
+                xin[G] = ld4(xp + 8 * Gc);
+                wb.v[G] = ld4(wp + 8 * Gc);
             }
 #pragma unroll
-            for (int G = 0; G < 16; ++G) {
+            for (int G = 0; G < 16; G += 2) {  // F is a multiple of 16: chunks come in pairs
                 if (G0 + G < nG) {
-                    const f32x4 x4 = in_batch ? xin[G] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) own = SAVAD_MFMA(wb.v[G][e], x4[e], own);
+                    for (int g = G; g < G + 2; ++g) {
+                        const f32x4 x4 = in_batch ? xin[g] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) own = SAVAD_MFMA(wb.v[g][e], x4[e], own);
+                    }
                 }
             }
         }
@@ -864,36 +893,46 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
         const int t = (int)((in_batch ? row : 0) % (size_t)T);
         add_block(own, M.pe + (size_t)t * D + 32 * w, h);
     }
+#pragma unroll
+    for (int j = 0; j < NBT; ++j)
+        if ((int)threadIdx.x + 256 * j < nb4) st4(lbias + 4 * (threadIdx.x + 256 * j), bt[j]);
 
+    wload_frag(wa, M.layer[0].frag, w, voff);  // layer 0's query block (after the prologue's compiler-managed loads:
+                                               // their waits would otherwise cover this request too)
+    SAVAD_STAMP(49);
     f32x4 xg[16];
 #pragma unroll 1
     for (int l = 0; l < M.L; ++l) {
-        const PackedLayer& W = M.layer[l];
-        const float* lb = lbias + (l & 1) * LBIAS;
+        const float* frag = M.layer[l].frag;
+        const float* lb = lbias + l * LBIAS;
         const float *lb1 = lb, *lb2 = lb + DFF, *lbn = lb + DFF + D, *lbo = lb + DFF + 4 * D;
         // ---- LN1 + Q, K (row layout) and V^T blocks of this wave's 32 features; wa = query block (requested a block ago)
         store_block(xb0 + m * XLD + 32 * w, own, h);
         __syncthreads();
-        if (l + 1 < M.L) stage_layer_bias(l + 1);  // other parity; every wave is past the previous layer's last bias read
         read_rows_layernorm(xb0, m, h, xg);
-        wload_k128(wb, W.wqkv + (size_t)(D + 32 * w + n) * D + 4 * h);
+        SAVAD_STAMP(50);
+        wload_frag(wb, frag, 4 + w, voff);
         f32x16 qb = bias_block(lbn + 32 * w, h);
+        wwait<16>(wa);
         wmma_k128(qb, wa, xg);
-        wload_k128(wa, W.wqkv + (size_t)(2 * D + 32 * w + n) * D + 4 * h);
+        wload_frag(wa, frag, 8 + w, voff);
         f32x16 kb = bias_block(lbn + D + 32 * w, h);
+        wwait<16>(wb);
         wmma_k128(kb, wb, xg);
-        wload_k128(wb, W.wo + (size_t)(32 * w + n) * D + 4 * h);
+        wload_frag(wb, frag, 12 + w, voff);
         f32x16 vT;  // vT[4g+s] = v[row 8g+4h+s][feature 32w + n]
         {
             const float bv = lbn[2 * D + 32 * w + n];
 #pragma unroll
             for (int r = 0; r < 16; ++r) vT[r] = bv;
+            wwait<16>(wa);
 #pragma unroll
             for (int G = 0; G < 16; ++G)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vT = SAVAD_MFMA(xg[G][e], wa.v[G][e], vT);
         }
-        wload_k128(wa, W.w1 + (size_t)(128 * w + n) * D + 4 * h);  // first FFN block
+        wload_frag(wa, frag, 16 + 4 * w, voff);  // first FFN block
+        SAVAD_STAMP(51);
         // ---- scores: this wave's 32-feature share, summed over the waves through LDS
         f32x16 sc = zero16();
 #pragma unroll
@@ -909,6 +948,7 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
 #pragma unroll
             for (int e = 0; e < 4; ++e) sc[4 * g + e] = s4[e];
         }
+        SAVAD_STAMP(52);
         // block-diagonal mask (a key belongs to the query's own sequence), softmax over the single key tile
         float mx = NEG_BIG;
 #pragma unroll
@@ -931,34 +971,40 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) ctx = SAVAD_MFMA(vT[r], sc[r], ctx);
         ctx *= inv;
+        SAVAD_STAMP(53);
         store_block(xb1 + m * XLD + 32 * w, ctx, h);
         __syncthreads();
 #pragma unroll
         for (int G = 0; G < 16; ++G) xg[G] = ld4(xb1 + m * XLD + 8 * G + 4 * h);
+        SAVAD_STAMP(54);
         // ---- out-projection + residual (accumulator starts at the residual stream), LN2
         f32x16 h1 = own + bias_block(lbo + 32 * w, h);
+        wwait<16>(wb);
         wmma_k128(h1, wb, xg);
         store_block(xb0 + m * XLD + 32 * w, h1, h);  // xb0's LN1 readers passed two barriers since
         __syncthreads();
         read_rows_layernorm(xb0, m, h, xg);
-        // ---- FFN: hidden units [128w, 128w+128) in 4 chunks of 32 (wa = W1 chunk, wb = W2 slice), as in row_kernel
+        SAVAD_STAMP(55);
+        // ---- FFN: hidden units [128w, 128w+128) in 4 chunks of 32 (wa = W1 slice, wb = W2 slice), as in row_kernel
         f32x16 o[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) o[nb] = zero16();
+        const float* nfrag = M.layer[l + 1 < M.L ? l + 1 : l].frag;
 #pragma unroll 1
         for (int ch = 0; ch < 4; ++ch) {
-            const int hid0 = 128 * w + 32 * ch;
-            wload_w2(wb, W.w2 + (size_t)n * DFF + hid0 + 4 * h, DFF);
-            f32x16 a = bias_block(lb1 + hid0, h);
+            wload_frag(wb, frag, 32 + 4 * w + ch, voff);
+            f32x16 a = bias_block(lb1 + 128 * w + 32 * ch, h);
+            wwait<16>(wa);
             wmma_k128(a, wa, xg);
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
-            if (ch + 1 < 4)
-                wload_k128(wa, W.w1 + (size_t)(hid0 + 32 + n) * D + 4 * h);
-            else if (l + 1 < M.L)
-                wload_k128(wa, M.layer[l + 1].wqkv + (size_t)(32 * w + n) * D + 4 * h);  // next layer's query block
+            // the next W1 slice, or the next layer's query block; behind the last layer the stream simply re-reads a
+            // block it will not use (keeps the wait count uniform)
+            wload_frag(wa, ch + 1 < 4 ? frag : nfrag, ch + 1 < 4 ? 16 + 4 * w + ch + 1 : w, voff);
+            wwait<16>(wb);
             wmma_w2(o, wb, a);
         }
+        SAVAD_STAMP(56);
         // reduce-scatter the 4 K-split partials: wave w ends up with feature block w (the score tiles' readers
         // passed two barriers since)
         own = o[0];
@@ -976,6 +1022,7 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
         for (int slot = 0; slot < 3; ++slot) add_block(own, pbuf + ((w * 3 + slot) * TILE + m) * PLD, h);
         own += bias_block(lb2 + 32 * w, h);
         own += h1;  // residual onto the un-normalised stream (transformer.py:235-237)
+        SAVAD_STAMP(57);
     }
     // ---- final LayerNorm (folded into the classifier) + Linear(D, 2) + log-softmax (self_attention.py:26-28)
     store_block(xb0 + m * XLD + 32 * w, own, h);
@@ -998,6 +1045,7 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
         const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
         if (h == 0 && lane_ok) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
     }
+    SAVAD_STAMP(58);
 }
 
 // =============================================================================================
@@ -1387,6 +1435,19 @@ __global__ __launch_bounds__(256, 2) void attention_row_kernel(
 //   LN(x) W^T + b = xhat (W diag(gamma))^T + (b + W beta)
 // One block per output row; beta term accumulated in fp64.
 // ---------------------------------------------------------------------------------------------
+// fp32 weights in fragment order (PackedLayer::frag).  mode 0: `count` row blocks of W [32 count][128] (register i =
+// k-chunk G: W[32 b + n][8 G + 4 h + e]); mode 1: `count` column blocks of W2 [128][512] (register i = 4 nb + g:
+// W2[32 nb + n][32 b + 8 g + 4 h + e]).
+__global__ void pack_frag32_kernel(const float* __restrict__ W, int mode, int count, float* __restrict__ out) {
+    const size_t total = (size_t)count * FRAG_BLOCK;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / FRAG_BLOCK), r = (int)(idx % FRAG_BLOCK);
+        const int i = r >> 8, lane = (r >> 2) & 63, e = r & 3, n = lane & 31, h = lane >> 5;
+        out[idx] = mode == 0 ? W[(size_t)(32 * b + n) * D + 8 * i + 4 * h + e]
+                             : W[(size_t)(32 * (i >> 2) + n) * DFF + 32 * b + 8 * (i & 3) + 4 * h + e];
+    }
+}
+
 __global__ void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
                                const float* __restrict__ beta, float* __restrict__ Wout, float* __restrict__ bout,
                                int K) {
