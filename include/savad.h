@@ -103,11 +103,10 @@ int savad_forward_ex(savad_handle h, const void* x, int x_dtype, int B, int T, f
 int savad_set_attention_splits(savad_handle h, int splits);
 /* Tuning knob: the launch schedule (results differ only in fp32 summation order; default 0 = automatic).
  *   fp32 operands
- *     1  row-wise stages on 32-row tiles, output features split over the workgroup's 4 waves; for T <= 32 the
- *        row kernel computes its tile's attention itself while the tiles fit one round of the CUs
- *     4  as 1, but the T <= 32 attention always stays its own launch
- *     5  T <= 32: the whole forward in ONE launch, a workgroup per packed tile of floor(32/T) sequences (what
- *        automatic picks while the tiles fit one round of the CUs); T > 32: as 0
+ *     1  row-wise stages on 32-row tiles, output features split over the workgroup's 4 waves; attention is its own
+ *        launch (what automatic picks for small T > 32 batches)
+ *     4  T <= 32: the whole forward in ONE launch, a workgroup per packed tile of floor(32/T) sequences (what
+ *        automatic picks up to 1024 tiles); T > 32: as 0
  *     2  row-wise stages on 128-row tiles, weight stream shared through LDS; attention and row stages are
  *        separate launches
  *     3  as 2, with attention and row chain of a query-block group fused into one launch per layer whenever

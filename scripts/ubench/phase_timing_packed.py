@@ -8,7 +8,7 @@ from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, _l
 B, T = int(sys.argv[1]), int(sys.argv[2])
 m = SelfAttentiveVAD(80, 3, 128, 0.5)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()})
-m = m.cuda().eval(); m.row_mode = 5
+m = m.cuda().eval(); m.row_mode = 4
 x = torch.randn(B, T, 80, device="cuda")
 for _ in range(3): m(x)
 torch.cuda.synchronize()
@@ -25,3 +25,5 @@ print(f"  {'layers 0..L-2 + LN1 of the last':36s} {t[2]-t[1]:8d}")
 for i in range(2, 9): print(f"  {names[i]:36s} {t[i+1]-t[i]:8d}")
 print(f"  {names[9]:36s} {t[10]-t[9]:8d}")
 print("  total", t[10] - t[0])
+u = list(buf[40:46])
+print("  last FFN chunk: wait W1", u[1]-u[0], " W1 MFMAs", u[2]-u[1], " relu+issue", u[3]-u[2], " wait W2", u[4]-u[3], " W2 MFMAs", u[5]-u[4])

@@ -213,37 +213,8 @@ def test_fused_attention_row_launches(torch_cuda, model, golden, state1234):
         model.row_mode, model.attention_splits = 0, 0
 
 
-def test_packed_attention_inside_row_kernel(torch_cuda, model, golden, state1234):
-    """T <= 32, small batches: the N-split row kernel computes its tile's attention itself (row_mode 0 / 1) instead
-    of reading what a separate launch wrote (row_mode 4).  Same arithmetic -> bit-identical; goldens for the
-    reference's own window shape; tiles that are not a multiple of 32 rows (T=7: 28), a last tile with missing
-    sequences, and a NaN-poisoned workspace."""
-    from oracle import oracle
-
-    torch = torch_cuda
-    y = run(torch, model, feats(101, (4, 7, 80)), row_mode=1)
-    assert np.abs(y - golden["g1_out"]).max() < TIGHT
-    y = run(torch, model, feats(78, (1000, 7, 80)), row_mode=0)
-    assert np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < TIGHT
-    for shape in ((1, 1, 80), (3, 7, 80), (5, 16, 80), (37, 3, 80), (9, 32, 80), (1001, 7, 80), (250, 11, 80), (2, 31, 80)):
-        x = feats(sum(shape) + 3, shape)
-        fused = run(torch, model, x, row_mode=1)
-        assert np.array_equal(fused, run(torch, model, x, row_mode=4)), shape
-        assert np.abs(fused - oracle.forward(state1234, x)).max() < TIGHT, shape
-    model.row_mode = 1
-    try:
-        xt = torch.from_numpy(feats(5, (13, 7, 80))).cuda()
-        with torch.no_grad():
-            y0 = model(features=xt).clone()
-            model._workspace.fill_(255)
-            y1 = model(features=xt)
-        assert torch.isfinite(y1).all() and torch.equal(y0, y1)
-    finally:
-        model.row_mode = 0
-
-
 def test_single_launch_packed_forward(torch_cuda, model, golden, state1234):
-    """T <= 32: the whole forward in ONE launch (packed_forward_kernel, row_mode 5; what automatic picks up to 256
+    """T <= 32: the whole forward in ONE launch (packed_forward_kernel, row_mode 4; what automatic picks up to 1024
     packed tiles).  Against the goldens / the oracle for every T <= 32 tile shape (1 .. 32 sequences per tile, ragged
     last tile, a batch larger than one round of the CUs, odd feature sizes, other depths), and its per-sequence
     results must not depend on what else shares the tile or the batch."""
@@ -251,33 +222,39 @@ def test_single_launch_packed_forward(torch_cuda, model, golden, state1234):
     from voice_activity_detection_amd import seeded_state_dict
 
     torch = torch_cuda
-    assert np.abs(run(torch, model, feats(101, (4, 7, 80)), row_mode=5) - golden["g1_out"]).max() < TIGHT
-    assert np.abs(run(torch, model, feats(77, (1, 7, 80)), row_mode=5) - golden["g4_B1T7"]).max() < TIGHT
+    assert np.abs(run(torch, model, feats(101, (4, 7, 80)), row_mode=4) - golden["g1_out"]).max() < TIGHT
+    assert np.abs(run(torch, model, feats(77, (1, 7, 80)), row_mode=4) - golden["g4_B1T7"]).max() < TIGHT
     y = run(torch, model, feats(78, (1000, 7, 80)), row_mode=0)  # 250 tiles: automatic = the single launch
     assert np.abs(y[:8] - golden["g4_B1000T7_head"]).max() < TIGHT and np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < TIGHT
-    assert np.array_equal(y, run(torch, model, feats(78, (1000, 7, 80)), row_mode=5))
+    assert np.array_equal(y, run(torch, model, feats(78, (1000, 7, 80)), row_mode=4))
     for T in (1, 2, 5, 10, 11, 16, 17, 31, 32):
-        y = run(torch, model, feats(400 + T, (3, T, 80)), row_mode=5)
+        y = run(torch, model, feats(400 + T, (3, T, 80)), row_mode=4)
         assert np.abs(y - golden[f"g4_T{T}"]).max() < TIGHT, T
     for shape in [(5, 7, 80), (37, 3, 80), (1, 1, 80), (33, 1, 80), (9, 32, 80), (7, 13, 80), (1500, 7, 80), (300, 16, 80)]:
         x = feats(7 + shape[0], shape)
-        y = run(torch, model, x, row_mode=5)
+        y = run(torch, model, x, row_mode=4)
         assert np.abs(y - oracle.forward(state1234, x)).max() < TIGHT, shape
-        assert np.array_equal(y, run(torch, model, x, row_mode=5)), shape  # deterministic
+        assert np.array_equal(y, run(torch, model, x, row_mode=4)), shape  # deterministic
         assert np.abs(y - run(torch, model, x, row_mode=1)).max() < 2e-5, shape  # the per-layer launches
     x = feats(91, (41, 7, 80))
-    whole = run(torch, model, x, row_mode=5)
+    whole = run(torch, model, x, row_mode=4)
     for i in (0, 3, 17, 40):  # alone in the batch: same bits at the same tile slot (4 sequences per tile), else fp32 summation order
-        alone = run(torch, model, x[i:i + 1], row_mode=5)[0]
+        alone = run(torch, model, x[i:i + 1], row_mode=4)[0]
         assert np.array_equal(alone, whole[i]) if i % 4 == 0 else np.abs(alone - whole[i]).max() < 2e-6, i
-    assert np.array_equal(run(torch, model, x[4:12], row_mode=5), whole[4:12])  # whole tiles move together
+    assert np.array_equal(run(torch, model, x[4:12], row_mode=4), whole[4:12])  # whole tiles move together
     for F in (257, 13):  # zero-padded K of the input Linear, K > 128 in chunks
         st = seeded_state_dict(900 + F, feature_size=F)
         xf = feats(901 + F, (5, 7, F))
-        assert np.abs(run(torch, make_model(torch, st, F=F), xf, row_mode=5) - oracle.forward(st, xf)).max() < TIGHT, F
+        assert np.abs(run(torch, make_model(torch, st, F=F), xf, row_mode=4) - oracle.forward(st, xf)).max() < TIGHT, F
+    xt = torch.from_numpy(feats(5, (13, 7, 80))).cuda()  # nothing but x, the weights and `out` is touched
+    with torch.no_grad():
+        y0 = model(features=xt).clone()
+        model._workspace.fill_(255)
+        y1 = model(features=xt)
+    assert torch.isfinite(y1).all() and torch.equal(y0, y1)
     st = seeded_state_dict(55, num_layers=5)
     x = feats(56, (6, 7, 80))
-    assert np.abs(run(torch, make_model(torch, st, L=5), x, row_mode=5) - oracle.forward(st, x)).max() < TIGHT
+    assert np.abs(run(torch, make_model(torch, st, L=5), x, row_mode=4) - oracle.forward(st, x)).max() < TIGHT
 
 
 def test_properties_full_size(torch_cuda, model):

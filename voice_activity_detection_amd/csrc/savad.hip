@@ -158,7 +158,7 @@ Workspace plan(const savad_model* m, int B, int T) {
     // N-split works through ceil(tiles / 256) rounds of ~45 us, M-split through one round of ~118 us per 256 workgroups
     // of 128 rows: M wins from the third N-split round on (more than 512 tiles of 32 rows).  Measured at T=800: B=20
     // (500 tiles) N 0.504 / M 0.648 ms; B=24 (600 tiles) N 0.611 / M 0.589 ms.
-    const int row_mode = m->row_mode == 5 ? 0 : m->row_mode;  // 5 only differs from automatic for T <= 32 (savad_forward)
+    const int row_mode = m->row_mode == 4 ? 0 : m->row_mode;  // 4 only differs from automatic for T <= 32 (savad_forward)
     w.msplit = row_mode == 2 || row_mode == 3 || (row_mode == 0 && w.rows_pad / 32 > 512);
     // In the M-split regime without key splits the attention stage and the row chain of a query-block group
     // run back to back in one workgroup (attention_row_kernel).  row_mode 2 keeps them as separate launches.
@@ -341,7 +341,7 @@ BlockPlan plan_blocks(const savad_model* m, int B, int T) {
     const bool ragged = QBp * 5 < NGp * 4 * 4;  // fewer than 80 % of a group's wave slots hold a query block
     // (below one workgroup per CU the forward is launch / latency bound and fusing wins even with idle slots:
     // B=64, T=50: 0.070 / 0.074 ms; B=32, T=160: 0.072 / 0.080 ms)
-    const bool automatic = m->row_mode == 0 || m->row_mode == 5;
+    const bool automatic = m->row_mode == 0 || m->row_mode == 4;
     p.fused = T > 32 && (m->row_mode == 3 || (automatic && groups <= 1024 && (!ragged || groups <= 256)));
     p.q2 = p.k2 = p.vt2 = off;
     if (p.fused) {
@@ -529,7 +529,7 @@ SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
         return SAVAD_OK;
     }
 #endif
-    if (!m || mode < 0 || mode > 5) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 4) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -775,9 +775,13 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     const bool msplit = ws.msplit;
     // T <= 32 in the small-batch regime (the reference pipeline's 7-frame windows): the whole forward is ONE launch,
     // a workgroup per packed tile of floor(32/T) sequences keeps every activation on its CU (packed_forward_kernel).
-    // Automatic while the tiles fit one round of the 256 CUs; row_mode 5 forces it for any T <= 32 batch.
+    // Automatic up to 1024 tiles (four rounds of the 256 CUs); beyond that the 128-row M-split tiles, which fetch the
+    // weight stream once per 128 rows instead of once per tile, are ahead.  Measured at T=7, ms per forward, single
+    // launch / per-layer N-split launches / M-split: 250 tiles 0.100 / 0.156 / 0.356; 512 tiles 0.186 / 0.272 / 0.364;
+    // 1024 tiles 0.366 / 0.506 / 0.383; 2048 tiles 0.728 / 0.878 / 0.699; 4096 tiles (the predictor's 16384-window
+    // batches) 1.454 / 1.736 / 1.346.  row_mode 4 forces the single launch for any T <= 32 batch.
     if (T <= 32 && L <= PACKED_MAX_LAYERS &&
-        (m->row_mode == 5 || (m->row_mode == 0 && !msplit && (B + 32 / T - 1) / (32 / T) <= 256))) {
+        (m->row_mode == 4 || (m->row_mode == 0 && (B + 32 / T - 1) / (32 / T) <= 1024))) {
         const int G = 32 / T, nblk = (B + G - 1) / G;
         PackedModel pm;
         for (int l = 0; l < L; ++l) pm.layer[l] = PackedLayer{P + m->lp[l].frag};
@@ -827,15 +831,8 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
         HIP_TRY(hipGetLastError());
         return SAVAD_OK;
     }
-    // T <= 32 in the N-split regime: the row kernel computes its tile's attention itself (tile = floor(32/T) whole
-    // sequences; each of the 4 waves needs the whole context tile and computes it), so a layer is ONE launch.  Only
-    // while the tiles fit one round of the 256 CUs: there the 4x redundant 128 MFMAs and the 28-row tiles of T=7 cost
-    // nothing ([1000,7,80]: 0.171 -> 0.162 ms); with several rounds per CU they do ([600,16,80]: 0.266 -> 0.276 ms).
-    const int Gp = T <= 32 ? 32 / T : 0, rowsPB = Gp * T, nblk_packed = T <= 32 ? (B + Gp - 1) / Gp : 0;
-    const bool packed_fused = T <= 32 && !msplit && nblk_packed <= 256 && m->row_mode != 4;
     for (int l = 0; l < L; ++l) {
-        if (packed_fused) {
-        } else if (T <= 32) {
+        if (T <= 32) {
             const int G = 32 / T, nblk = (B + G - 1) / G;
             hipLaunchKernelGGL(attention_packed_kernel, dim3(nblk), dim3(64), 0, st, q, k, v, op, ml, B, T, (int)ws.rows, c);
         } else {
@@ -844,7 +841,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
             hipLaunchKernelGGL(attention_kernel, dim3(grid), dim3(256), 0, st, q, k, v, op, ml, B, T, (int)ws.rows_pad,
                                ws.S, NG, c);
         }
-        if (!packed_fused) prof.mark("attention");
+        prof.mark("attention");
         const auto& r = m->lr[l];
         const auto& p = m->lp[l];
 #define SAVAD_ROW_ARGS(WN, BN) op, ml, ws.S, (int)ws.rows, (int)ws.rows_pad, c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, \
@@ -854,18 +851,16 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
                 hipLaunchKernelGGL(row_kernel_m<false>, dim3(tiles_m), dim3(256), 0, st,
                                    SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv));
             else
-                hipLaunchKernelGGL(row_kernel<false>, dim3(packed_fused ? nblk_packed : tiles), dim3(256), 0, st,
-                                   SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv), packed_fused ? rowsPB : TILE,
-                                   packed_fused ? T : 0);
-            prof.mark(packed_fused ? "attention_row" : "row");
+                hipLaunchKernelGGL(row_kernel<false>, dim3(tiles), dim3(256), 0, st,
+                                   SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv));
+            prof.mark("row");
         } else {
             if (msplit)
                 hipLaunchKernelGGL(row_kernel_m<true>, dim3(tiles_m), dim3(256), 0, st,
                                    SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc));
             else
-                hipLaunchKernelGGL(row_kernel<true>, dim3(packed_fused ? nblk_packed : tiles), dim3(256), 0, st,
-                                   SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc), packed_fused ? rowsPB : TILE, packed_fused ? T : 0);
-            prof.mark(packed_fused ? "attention_row_last" : "row_last");
+                hipLaunchKernelGGL(row_kernel<true>, dim3(tiles), dim3(256), 0, st, SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc));
+            prof.mark("row_last");
         }
 #undef SAVAD_ROW_ARGS
     }

@@ -657,8 +657,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
     const float* __restrict__ b2, const float* __restrict__ Wn /* LAST ? Wc'[2][D] : Wqkv'[3D][D] */,
     const float* __restrict__ bn, float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
-    float* __restrict__ out /* [rows][2] */, int tile_rows /* 32, or floor(32/T)*T with Tpack */,
-    int Tpack /* > 0: T <= 32 and the tile's attention is computed HERE from q, k, v instead of read from Opart */) {
+    float* __restrict__ out /* [rows][2] */) {
     __shared__ __attribute__((aligned(16))) float lds[TILE * XLD + 12 * TILE * PLD + 8 * D];
     float* xbuf = lds;
     float* pbuf = lds + TILE * XLD;  // [dest block 4][src slot 3][32 rows][PLD]
@@ -667,10 +666,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     float* lbn = lb2 + D;
     const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t row = (size_t)blockIdx.x * tile_rows + m;
-    // Packed mode: the tile is floor(32/T) whole sequences (tile_rows <= 32 rows); the remaining lanes alias the next
-    // tile's rows and rows past the batch may lie outside the buffers: neither is ever stored.
-    const bool lane_ok = Tpack > 0 ? (m < tile_rows && row < (size_t)rows) : true;
+    const size_t row = (size_t)blockIdx.x * TILE + m;
 
     SAVAD_STAMP(32);
     WBlock wa, wb;
@@ -682,20 +678,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     add_block(h1, hbuf + row * D + 32 * w, h);
     // ---- phase 0: ctx = combination of the key-split partials (rows are lane-local: all scalars per lane)
     f32x4 xg[16];
-    if (Tpack > 0) {
-        // every wave needs the whole context tile as B operand: each computes it (128 MFMAs) instead of all four
-        // reading back what a separate 1-wave launch wrote -- no launch, no partial round trip
-        f32x16 O[4];
-        float m_run, l_run;
-        packed_attention_tile(O, m_run, l_run, q, k, v, (size_t)blockIdx.x * tile_rows, tile_rows, Tpack, rows, c, n, h);
-        const float inv = lane_ok ? 1.0f / l_run : 0.0f;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xg[4 * nb + (r >> 2)][r & 3] = lane_ok ? O[nb][r] * inv : 0.0f;
-    } else {
-        combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
-    }
+    combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
     SAVAD_STAMP(33);
     // ---- phase 1: h1 = ctx Wo^T + bo + h   (wave's 32 features)
     wload_k128(wb, W1 + (size_t)(128 * w + n) * D + 4 * h);  // first FFN block
@@ -741,7 +724,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     for (int slot = 0; slot < 3; ++slot) add_block(own, pbuf + ((w * 3 + slot) * TILE + m) * PLD, h);
     own += bias_block(lb2 + 32 * w, h);
     own += h1;  // residual onto the un-normalised stream (transformer.py:235-237)
-    if (!LAST && lane_ok) store_block(hbuf + row * D + 32 * w, own, h);
+    if (!LAST) store_block(hbuf + row * D + 32 * w, own, h);
     SAVAD_STAMP(36);
     // ---- phase 3
     store_block(xbuf + m * XLD + 32 * w, own, h);  // xbuf's last readers all passed the barrier above
@@ -758,7 +741,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
             if (j + 1 < 3) wload_k128(nxt, Wn + (size_t)(D * (j + 1) + 32 * w + n) * D + 4 * h);
             f32x16 acc = bias_block(lbn + D * j + 32 * w, h);
             wmma_k128(acc, cur, xg);
-            if (lane_ok) store_block(dst[j] + row * D + 32 * w, acc, h);
+            store_block(dst[j] + row * D + 32 * w, acc, h);
         }
     } else if (w == 0) {
         float z0 = 0.0f, z1 = 0.0f;
@@ -777,7 +760,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
         z1 += bn[1];
         const float mx = fmaxf(z0, z1);
         const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
-        if (h == 0 && lane_ok && row < (size_t)rows) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+        if (h == 0 && row < (size_t)rows) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
     }
     SAVAD_STAMP(38);
 }
@@ -994,15 +977,21 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
         for (int ch = 0; ch < 4; ++ch) {
             wload_frag(wb, frag, 32 + 4 * w + ch, voff);
             f32x16 a = bias_block(lb1 + 128 * w + 32 * ch, h);
+            SAVAD_STAMP(40);
             wwait<16>(wa);
+            SAVAD_STAMP(41);
             wmma_k128(a, wa, xg);
+            SAVAD_STAMP(42);
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
             // the next W1 slice, or the next layer's query block; behind the last layer the stream simply re-reads a
             // block it will not use (keeps the wait count uniform)
             wload_frag(wa, ch + 1 < 4 ? frag : nfrag, ch + 1 < 4 ? 16 + 4 * w + ch + 1 : w, voff);
+            SAVAD_STAMP(43);
             wwait<16>(wb);
+            SAVAD_STAMP(44);
             wmma_w2(o, wb, a);
+            SAVAD_STAMP(45);
         }
         SAVAD_STAMP(56);
         // reduce-scatter the 4 K-split partials: wave w ends up with feature block w (the score tiles' readers

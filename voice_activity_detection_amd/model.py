@@ -80,7 +80,7 @@ class SelfAttentiveVAD(nn.Module):
         self._synced_versions = None
         self._workspace: Optional[Tensor] = None
         self.attention_splits = 0  # 0 = automatic
-        self.row_mode = 0  # 0 = automatic, 1 / 4 = N-split 32-row tiles, 2 / 3 = M-split 128-row tiles (include/savad.h)
+        self.row_mode = 0  # 0 = automatic, 1 = N-split 32-row tiles, 2 / 3 = M-split 128-row tiles, 4 = T <= 32 in one launch (include/savad.h)
         # "fp32": exact-fp32 MFMA (default, log-probs within 1e-4 of the reference).
         # "bf16": bf16 MFMA operands, fp32 accumulation / statistics, fp16-stored residual stream (BASELINE configs[2..3]).
         self.precision = "fp32"
