@@ -265,10 +265,13 @@ class Runner:
             walls = [float(v) for v in t.tolist()]
         return walls, evs, y
 
-    def kernel_profile(self, steps):
+    def kernel_profile(self, steps, ms_hint=None):
         """the same K steps with every kernel bracketed by HIP events on the launch stream -> [(label, ms)]"""
-        self.model.set_profiling(steps)
-        for _ in range(steps):
+        # creating the events idles the GPU; the first ~15 ms of kernels afterwards run at lower clocks (230 -> 207 us per
+        # fused launch, seen in the rocprofv3 trace): ~0.15 s of un-recorded forwards first
+        settle = max(steps, int(0.15 / (ms_hint * 1e-3))) if ms_hint else 200
+        self.model.set_profiling(steps, skip=settle)
+        for _ in range(settle + steps):
             self.step()
         self.drain()
         torch.cuda.synchronize()
@@ -401,7 +404,7 @@ def main():
                         "note": "step = one RCCL all_gather of [B,T,2] log-probs per forward (forward_sharded, the product path); "
                                 "final = each forward writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block"}
         main_run.set_gather(args.gather, K)
-    ktimes = [] if args.no_events else main_run.kernel_profile(min(K, 20))
+    ktimes = [] if args.no_events else main_run.kernel_profile(min(K, 20), head["ms_per_step"])
 
     # ---- secondary legs, measured in the same run so that they are driver-witnessed
     secondary = {}
@@ -421,7 +424,7 @@ def main():
                 k2 = 20 if t2 > 32 else 50
                 w, e, y2 = r.timed_blocks(k2, 5, args.min_seconds / 2)
                 s = summarize(w, e, k2, world * b2 * t2)
-                kt = [] if args.no_events else r.kernel_profile(10)
+                kt = [] if args.no_events else r.kernel_profile(10, s["ms_per_step"])
                 s.update({"workload": workload_label(prec, b2, t2), "global_batch": world * b2, "unit": "frames/s",
                           "finite": bool(torch.isfinite(y2).all().item()),
                           "roofline": roofline_block(kt, prec, b2, t2, s["ms_per_step"])})

@@ -115,11 +115,14 @@ int savad_set_attention_splits(savad_handle h, int splits);
  *     1  separate attention / row launches, 4-wave workgroups      2  the same with 8-wave workgroups
  *     3  fused launches (T > 32)                                    0  fused up to ~4 workgroups per CU */
 int savad_set_row_mode(savad_handle h, int mode);
-/* Fills the names/durations of the kernels of the most recent savad_forward when profiling is
- * enabled with savad_set_profiling(h, 1): the forward then brackets every launch with hipEvents on
- * `stream` and synchronises at the end (bench.py uses this for the roofline block).
- * Returns the number of kernels written (<= max). */
-int savad_set_profiling(savad_handle h, int enable);
+/* Per-kernel timing (bench.py's roofline block).  savad_set_profiling(h, capacity): the next `capacity` calls of
+ * savad_forward bracket every launch with hipEvents on `stream` (capacity 0 switches profiling off and frees the
+ * events); savad_profiling_skip(h, n): the next n forwards run un-recorded first (event creation idles the GPU for
+ * a moment and the first ~15 ms of kernels afterwards run at lower clocks: 230 -> 207 us measured);
+ * savad_last_kernel_times: after the caller has synchronised the stream, the launch names and their average duration
+ * (ms) over the recorded forwards; returns the number of kernels written (<= max) and starts a new recording. */
+int savad_set_profiling(savad_handle h, int capacity);
+int savad_profiling_skip(savad_handle h, int forwards);
 int savad_last_kernel_times(savad_handle h, const char** names, float* ms, int max);
 
 /* Window geometry of the predictor: W = 2*(half-1)/jump + 3 (vad/predictor.py:57-59); offsets =

@@ -7,9 +7,10 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline $*"
-# the kernel-trace pass runs the SAME command as the default bench line (K = 50, W = 10): its per-kernel averages are
-# the ones bench.py's HIP-event durations are checked against; the PMC passes serialise kernels and stay short
+BENCH="python $REPO/bench.py --steps 10 --warmup 3 --min-seconds 0.02 --no-secondary --no-cpu-baseline $*"
+# the kernel-trace pass runs the SAME command as the default bench line (K = 50, W = 10, secondary legs included): its
+# per-kernel averages are the ones bench.py's HIP-event durations are checked against; the PMC passes serialise kernels,
+# so they run the primary workload only and stay short
 TRACE_BENCH="python $REPO/bench.py --no-cpu-baseline $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- $TRACE_BENCH > $OUT/trace.log 2>&1

@@ -33,7 +33,7 @@ for f in find("trace/**/*kernel_stats.csv"):
     print(f"\n## kernel stats ({os.path.relpath(f, out)})")
     with open(f) as fh:
         for i, row in enumerate(csv.DictReader(fh)):
-            if i >= 12:
+            if i >= 18:
                 break
             print(f"{short(row['Name']):28s} calls={row['Calls']:>5s} total_ns={row['TotalDurationNs']:>12s} "
                   f"avg_ns={float(row['AverageNs']):>12.0f} min={row['MinNs']:>9s} max={row['MaxNs']:>9s} pct={row['Percentage']}")

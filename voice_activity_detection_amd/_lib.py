@@ -37,6 +37,7 @@ SYMBOLS = {
     "savad_set_attention_splits": (c_int, [c_void_p, c_int]),
     "savad_set_row_mode": (c_int, [c_void_p, c_int]),
     "savad_set_profiling": (c_int, [c_void_p, c_int]),
+    "savad_profiling_skip": (c_int, [c_void_p, c_int]),
     "savad_last_kernel_times": (c_int, [c_void_p, POINTER(c_char_p), POINTER(c_float), c_int]),
     "savad_window_offsets": (c_int, [c_int, c_int, POINTER(c_int32)]),
     "savad_gather_windows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

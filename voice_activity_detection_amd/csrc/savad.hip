@@ -80,7 +80,7 @@ struct savad_model {
     };
     std::vector<LayerFrag> lf;
     // profiling
-    int prof_capacity = 0, prof_used = 0, prof_nk = 0;
+    int prof_capacity = 0, prof_used = 0, prof_nk = 0, prof_skip = 0;
     std::vector<hipEvent_t> events;  // prof_capacity * MAX_EVENTS
     std::vector<const char*> knames;
 
@@ -370,7 +370,9 @@ struct Prof {
     hipEvent_t* ev;
     int n;
     Prof(savad_model* mm, hipStream_t s) : m(mm), st(s), ev(nullptr), n(0) {
-        if (m->prof_capacity > 0 && m->prof_used < m->prof_capacity) {
+        if (m->prof_capacity > 0 && m->prof_skip > 0) {
+            --m->prof_skip;  // settle-in forwards after savad_set_profiling: launched as usual, not recorded
+        } else if (m->prof_capacity > 0 && m->prof_used < m->prof_capacity) {
             ev = m->events.data() + (size_t)m->prof_used * MAX_EVENTS;
             m->knames.clear();
             hipEventRecord(ev[0], st);
@@ -876,8 +878,15 @@ SAVAD_EXPORT int savad_set_profiling(savad_handle m, int capacity) {
     m->prof_capacity = capacity;
     m->prof_used = 0;
     m->prof_nk = 0;
+    m->prof_skip = 0;
     m->events.resize((size_t)capacity * MAX_EVENTS);
     for (auto& e : m->events) HIP_TRY(hipEventCreate(&e));
+    return SAVAD_OK;
+}
+
+SAVAD_EXPORT int savad_profiling_skip(savad_handle m, int forwards) {
+    if (!m || forwards < 0) return fail(SAVAD_E_INVALID, "bad argument");
+    m->prof_skip = forwards;
     return SAVAD_OK;
 }
 

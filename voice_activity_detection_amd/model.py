@@ -227,8 +227,11 @@ class SelfAttentiveVAD(nn.Module):
         return int(n.value)
 
     # ---- profiling hooks used by bench.py -------------------------------------------------------
-    def set_profiling(self, capacity: int):
+    def set_profiling(self, capacity: int, skip: int = 0):
+        """record the kernels of the next `capacity` forwards, after `skip` un-recorded ones (clocks settle)"""
         _lib.check(_lib.load().savad_set_profiling(self._handle, int(capacity)))
+        if skip:
+            _lib.check(_lib.load().savad_profiling_skip(self._handle, int(skip)))
 
     def kernel_times(self):
         """[(kernel name, average ms)] per launch position since set_profiling; sync the stream first."""
