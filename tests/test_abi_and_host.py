@@ -130,6 +130,8 @@ def test_module_copies_and_pickles_drop_runtime_state(state1234):
     m.eval()                          # ... so mode switches force a re-push
     assert m._synced_versions is None
     m._synced_versions = m._param_versions()
+    m.eval()                          # ... but a call that changes nothing (the predictor's, before every batch) must not
+    assert m._synced_versions is not None
     with torch.no_grad():
         m.classifier.bias.add_(1.0)   # ordinary in-place edits are seen
     assert m._param_versions() != m._synced_versions

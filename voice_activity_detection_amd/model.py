@@ -126,8 +126,12 @@ class SelfAttentiveVAD(nn.Module):
             self.__dict__.setdefault(name, None)
 
     def train(self, mode: bool = True):
-        # switching modes is where parameters were most likely edited behind autograd's back (p.data.copy_ in EMA /
-        # init code leaves data_ptr and _version unchanged): re-push the weights at the next forward
+        # SWITCHING modes is where parameters were most likely edited behind autograd's back (p.data.copy_ in EMA /
+        # init code leaves data_ptr and _version unchanged): re-push the weights at the next forward.  A call that
+        # changes nothing (the predictor's model.eval() before every batch) must cost nothing: the re-push is 54 copies
+        # plus the fold / pack kernels, ~0.4 ms against a 0.09 ms forward.
+        if bool(mode) == self.training:
+            return self
         self._synced_versions = None
         return super().train(mode)
 
@@ -138,7 +142,7 @@ class SelfAttentiveVAD(nn.Module):
         """Push the module's parameters into the library's packed weight store when they changed.  Changes are detected
         through (data_ptr, _version): load_state_dict, .to(), optimizer steps and in-place tensor ops are all caught.
         NOT caught: writes through `.data` / `.detach()` views (p.data.mul_(...), p.data.copy_(...)), which bump neither --
-        call `model.sync_weights(force=True)` after such edits (`.train()` / `.eval()` also force a re-push).
+        call `model.sync_weights(force=True)` after such edits (a `.train()` / `.eval()` that switches the mode also forces a re-push).
         One module instance = one library handle + one cached workspace: use it from one stream at a time."""
         versions = self._param_versions()
         if not force and versions == self._synced_versions:
