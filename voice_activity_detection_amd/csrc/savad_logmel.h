@@ -11,7 +11,7 @@
 // in adjacent rows, so that |X|^2 is lane-local), B operand = the frame's samples straight from the
 // reflect-padded signal (16-byte aligned because 160, 56 and 8G+4h are multiples of 4).  The power
 // values feed the mel GEMM from the accumulator registers; log and the [N,80] store finish the
-// wave.  One wave = 32 frames, 4 passes of 4 DFT row blocks (64 bins) each.
+// tile.  One workgroup = 32 frames, its 4 waves take one pass of 4 DFT row blocks (64 bins) each.
 #pragma once
 #include "savad_kernels.h"
 
@@ -35,13 +35,16 @@ __global__ void reflect_pad_kernel(const float* __restrict__ y, int n, float* __
     }
 }
 
+// One WORKGROUP = 32 frames; wave w runs pass w (64 of the 256 bins: 800 DFT MFMAs + its 96 mel MFMAs) and the four
+// partial mel accumulators are summed through LDS in a fixed order.  (First version: one wave ran all four passes of
+// its tile -- 3584 dependent-issue MFMAs = 100 us of latency for a 10 s clip, whose 32 tiles occupied 8 CUs.)
 __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict__ ypad, int n_frames,
                                                         const float* __restrict__ dft_frag,
                                                         const float* __restrict__ mel_frag, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float part[4 * 3 * 16 * 64];  // [wave][mel block][register][lane]
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x * 4 + w;
-    if (tile * 32 >= n_frames) return;
+    const int pass = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x;
     int f = tile * 32 + m;
     const bool valid = f < n_frames;
     if (!valid) f = n_frames - 1;
@@ -49,8 +52,7 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
     f32x16 macc[3];
 #pragma unroll
     for (int mb = 0; mb < 3; ++mb) macc[mb] = zero16();
-#pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
+    {
         f32x16 acc[4];
 #pragma unroll
         for (int rbl = 0; rbl < 4; ++rbl) acc[rbl] = zero16();
@@ -82,20 +84,27 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
                 }
         }
     }
-    if (!valid) return;
-    float* op = out + (size_t)f * N_MELS;
 #pragma unroll
     for (int mb = 0; mb < 3; ++mb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int mel0 = 32 * mb + 8 * g + 4 * h;
-            if (mel0 < N_MELS) {
-                f32x4 t;
+        for (int g = 0; g < 4; ++g)
+            st4(part + (((pass * 3 + mb) * 4 + g) * 64 + lane) * 4, f32x4{macc[mb][4 * g], macc[mb][4 * g + 1], macc[mb][4 * g + 2], macc[mb][4 * g + 3]});
+    __syncthreads();
+    const int mb = pass;  // wave mb finishes mel block mb
+    if (mb >= 3 || !valid) return;
+    float* op = out + (size_t)f * N_MELS;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) t[s] = logf(macc[mb][4 * g + s] + 1e-6f);
-                st4(op + mel0, t);
-            }
+    for (int g = 0; g < 4; ++g) {
+        const int mel0 = 32 * mb + 8 * g + 4 * h;
+        if (mel0 < N_MELS) {
+            f32x4 t = ld4(part + (((0 * 3 + mb) * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) t += ld4(part + (((w2 * 3 + mb) * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) t[s2] = logf(t[s2] + 1e-6f);
+            st4(op + mel0, t);
         }
+    }
 }
 
 }  // namespace mel
