@@ -318,6 +318,43 @@ def roofline_block(ktimes, precision, B, T, ms_forward):
     }
 
 
+def clip_pipeline(state, dev, seconds, min_seconds):
+    """The reference pipeline's own case (BASELINE configs[0]): `seconds` of 16 kHz audio resident on the device ->
+    log-mel [N,80] -> N-6 windows of 7 frames -> SelfAttentiveVAD -> boosted probabilities [N,7] (vad/predictor.py:
+    159-262), everything on the current stream.  Median over blocks of 50 calls, HIP events."""
+    from voice_activity_detection_amd import SelfAttentiveVAD
+    from voice_activity_detection_amd.features import log_mel
+    from voice_activity_detection_amd.predictor import VADFromScratchPredictor
+
+    model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    pred = VADFromScratchPredictor(model.to(dev).eval(), dev)
+    audio = torch.from_numpy(np.random.default_rng(7).normal(0.0, 0.1, int(16000 * seconds)).astype(np.float32)).to(dev)
+
+    def chain():
+        return pred.predict_probabilities_device(log_mel(audio, dev))
+
+    for _ in range(30):
+        probs, _ = chain()
+    torch.cuda.synchronize()
+    per_call, spent = [], 0.0
+    while len(per_call) < 5 or spent < min_seconds:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            chain()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        per_call.append(ms / 50)
+        spent += ms * 1e-3
+    med = statistics.median(per_call)
+    return {"workload": f"BASELINE configs[0]: {seconds:g} s of 16 kHz audio on the device -> log-mel -> {probs.shape[0] - 6} windows [7,80] -> forward -> boost -> probabilities {list(probs.shape)}",
+            "ms_per_clip": round(med, 4), "ms_per_clip_min": round(min(per_call), 4), "frames": int(probs.shape[0]),
+            "frames_per_s": round(probs.shape[0] / (med * 1e-3), 1), "real_time_factor": round(med * 1e-3 / seconds, 9),
+            "finite": bool(torch.isfinite(probs).all().item()), "blocks": len(per_call)}
+
+
 def workload_label(precision, B, T):
     if (precision, B, T) == ("fp32", 32, 800):
         tag = "BASELINE configs[1]"
@@ -435,6 +472,12 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:  # a secondary leg must never take the headline line down with it
                 secondary[key] = {"error": f"{type(exc).__name__}: {exc}"}
+
+        if world == 1 and not use_dist:
+            try:  # configs[0] end to end on the device: 10 s of resident audio -> log-mel -> 7-frame windows -> forward -> boost
+                secondary["configs0_clip10s_audio_to_probabilities"] = clip_pipeline(state, dev, 10.0, args.min_seconds / 2)
+            except Exception as exc:
+                secondary["configs0_clip10s_audio_to_probabilities"] = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         line = {

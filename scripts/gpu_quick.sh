@@ -14,5 +14,5 @@ python - <<PY
 import json
 d=json.loads(open("$OUT/bench.json").read())
 print("fp32 [32,800]: ms", d["ms_per_step"], "min", d["ms_per_step_min"], d["roofline"]["kernels_ms"])
-for k,v in d.get("secondary",{}).items(): print(k, v.get("ms_per_step"), v.get("error"), (v.get("roofline") or {}).get("kernels_ms"))
+for k,v in d.get("secondary",{}).items(): print(k, v.get("ms_per_step", v.get("ms_per_clip")), v.get("error"), (v.get("roofline") or {}).get("kernels_ms"))
 PY
