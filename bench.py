@@ -69,7 +69,7 @@ def launch_work(name: str, B: int, T: int, e: int):
         return 295424.0 * frames, frames * (D * e + 8 + D * hres + 8)
     if base == "input_qkv":
         return 118784.0 * frames, frames * (F * e + D * hres + 3 * D * e)
-    if base == "forward_t7":  # whole forward in one launch (T <= 32): features in, log-probs out
+    if base == "packed_forward":  # whole forward in one launch (T <= 32): features in, log-probs out
         return flops_per_frame(T) * frames, frames * (F * e + 8)
     return 0.0, 0
 
@@ -93,9 +93,11 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     bench line) or bf16 [256,800] -- and (b) the profile was taken on exactly the kernel sources that are
     running now (`csrc_hash` stored in the file); otherwise null."""
     if (precision, B, T) == ("fp32", 32, 800):
-        files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if "bf16" not in f.name]
+        files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if "bf16" not in f.name and "t7" not in f.name]
     elif (precision, B, T) == ("bf16", 256, 800):
         files = sorted((REPO / "profiles").glob("*bf16_b256_traffic.json"))
+    elif (precision, B, T) == ("fp32", 1000, 7):
+        files = sorted((REPO / "profiles").glob("*t7_traffic.json"))
     else:
         return None
     want = kernel_source_hash()
@@ -107,7 +109,7 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     stem = name.replace("_last", "")
     prefix = {"attention": "attention_kernel", "attention_row": "attention_row_kernel", "row": "row_kernel", "input_qkv": "input_qkv_kernel",
               "attention_bf16": "attention", "row_bf16": "row_kernel_bf16", "input_qkv_bf16": "input_qkv_kernel_bf16",
-              "attention_row_bf16": "attention_row_kernel_bf16"}.get(stem)
+              "attention_row_bf16": "attention_row_kernel_bf16", "packed_forward": "packed_forward_kernel"}.get(stem)
     if prefix is None:
         return None
     for key, entry in data.items():
