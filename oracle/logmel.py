@@ -1,6 +1,8 @@
 """CPU oracle of the reference's log-mel front-end -- TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: the algorithm lives in a third-party dependency that is absent from
+PARITY WITH LIBROSA UNPINNED (its STFT is pinned against scipy.signal.stft and its filterbank against Slaney's
+closed form: tests/golden/make_golden_logmel.py, tests/test_oracle_golden.py): the algorithm lives in a third-party
+dependency that is absent from
 /root/reference and from this image -- librosa (pinned ``librosa==0.8.0`` in the reference's
 ``requirements.txt:3``) -- and no reference test holds feature values.  This
 file restates librosa 0.8.0's published defaults for the reference's only call site,

@@ -15,7 +15,7 @@ def find(pattern):
 
 
 def short(name):
-    m = re.search(r"savad::(?:bf::)?(\w+)(<[^>]*>)?", name)
+    m = re.search(r"savad::(?:bf::|mel::)?(\w+)(<[^>]*>)?", name)
     if m:
         return m.group(1) + (m.group(2) or "")
     # rocprofv3 leaves some template instantiations mangled: _ZN5savad2bf15row_kernel_bf16ILb0ELi4EEEv...
