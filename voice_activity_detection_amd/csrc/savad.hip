@@ -806,7 +806,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
                            R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
     else
         hipLaunchKernelGGL(input_qkv_kernel, dim3(tiles), dim3(256), 0, st, x, (int)ws.rows, T, F, win_fp32(m),
-                           R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
+                           R + m->r_bin, m->d_pe, P + m->lp[0].frag, P + m->lp[0].bqkv, hb, q, k, v);
     prof.mark("input_qkv");
     if (ws.fused) {
         float* qkv[2][3] = {{q, k, v}, {W + ws.q2, W + ws.k2, W + ws.v2}};
@@ -848,23 +848,25 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
         const auto& p = m->lp[l];
 #define SAVAD_ROW_ARGS(WN, BN) op, ml, ws.S, (int)ws.rows, (int)ws.rows_pad, c, hb, R + r.wo, R + r.bo, P + p.w1, P + p.b1, \
                                R + r.w2, R + r.b2, WN, BN, q, k, v, out
+#define SAVAD_ROWN_ARGS(NFRAG, WN, BN) op, ml, ws.S, (int)ws.rows, (int)ws.rows_pad, c, hb, P + p.frag, R + r.bo, P + p.b1, R + r.b2, \
+                                       NFRAG, WN, BN, q, k, v, out
         if (l + 1 < L) {
             if (msplit)
                 hipLaunchKernelGGL(row_kernel_m<false>, dim3(tiles_m), dim3(256), 0, st,
                                    SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv));
             else
-                hipLaunchKernelGGL(row_kernel<false>, dim3(tiles), dim3(256), 0, st,
-                                   SAVAD_ROW_ARGS(P + m->lp[l + 1].wqkv, P + m->lp[l + 1].bqkv));
+                hipLaunchKernelGGL(row_kernel<false>, dim3(tiles), dim3(256), 0, st, SAVAD_ROWN_ARGS(P + m->lp[l + 1].frag, P, P + m->lp[l + 1].bqkv));
             prof.mark("row");
         } else {
             if (msplit)
                 hipLaunchKernelGGL(row_kernel_m<true>, dim3(tiles_m), dim3(256), 0, st,
                                    SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc));
             else
-                hipLaunchKernelGGL(row_kernel<true>, dim3(tiles), dim3(256), 0, st, SAVAD_ROW_ARGS(P + m->p_wc, P + m->p_bc));
+                hipLaunchKernelGGL(row_kernel<true>, dim3(tiles), dim3(256), 0, st, SAVAD_ROWN_ARGS(P + p.frag, P + m->p_wc, P + m->p_bc));
             prof.mark("row_last");
         }
 #undef SAVAD_ROW_ARGS
+#undef SAVAD_ROWN_ARGS
     }
     prof.done();
     HIP_TRY(hipGetLastError());

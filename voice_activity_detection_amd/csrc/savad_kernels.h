@@ -71,17 +71,6 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-// acc(32 features n0.. x 32 rows) += W[n0 + (lane&31)][0..127] . x[row][0..127]
-// wp = W + (n0 + (lane & 31)) * ldw + 4 * h
-__device__ __forceinline__ void gemm_k128(f32x16& acc, const float* __restrict__ wp, const f32x4 (&xg)[16]) {
-#pragma unroll
-    for (int G = 0; G < 16; ++G) {
-        const f32x4 w4 = ld4(wp + 8 * G);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = SAVAD_MFMA(w4[s], xg[G][s], acc);
-    }
-}
-
 // bias for the wave's feature block in row layout: b[n0 + 8g + 4h + s]
 __device__ __forceinline__ void add_bias(f32x16& acc, const float* __restrict__ b, int h) {
 #pragma unroll
@@ -137,61 +126,6 @@ __device__ __forceinline__ void read_rows_layernorm(const float* xbuf, int m, in
     const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + LN_EPS);
 #pragma unroll
     for (int G = 0; G < 16; ++G) xg[G] *= rstd;
-}
-
-// LN1(next layer) + packed QKV projection for the wave's 32-feature block of each of q, k, v.
-// Wqkv: [3*D][D] (rows: query, key, value projection; LN affine folded), bqkv: [3*D].
-__device__ __forceinline__ void qkv_block(const f32x4 (&xg)[16], const float* __restrict__ Wqkv,
-                                          const float* __restrict__ bqkv, float* __restrict__ q,
-                                          float* __restrict__ k, float* __restrict__ v, size_t row, int w, int n, int h) {
-    float* dst[3] = {q, k, v};
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        f32x16 acc = zero16();
-        gemm_k128(acc, Wqkv + (size_t)(D * j + 32 * w + n) * D + 4 * h, xg);
-        add_bias(acc, bqkv + D * j + 32 * w, h);
-        store_block(dst[j] + row * D + 32 * w, acc, h);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Kernel 1: input Linear(F, D) + sinusoidal PE / sqrt(D)  (vad/models/self_attention.py:12-16,24;
-// vad/modeling/transformer.py:392-401), then layer-0 LN + QKV (transformer.py:234-237,281-284).
-// One workgroup (4 waves) per 32 data rows; wave w owns output features [32w, 32w+32).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void input_qkv_kernel(
-    const float* __restrict__ x, int rows, int T, int F, const float* __restrict__ Win, const float* __restrict__ bin,
-    const float* __restrict__ pe /* [T][D], already / sqrt(D) */, const float* __restrict__ Wqkv,
-    const float* __restrict__ bqkv, float* __restrict__ hbuf, float* __restrict__ q, float* __restrict__ k,
-    float* __restrict__ v) {
-    __shared__ __attribute__((aligned(16))) float xbuf[TILE * XLD];
-    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t row = (size_t)blockIdx.x * TILE + m;
-    const bool valid = row < (size_t)rows;
-    const float* xp = x + (valid ? row : 0) * (size_t)F + 4 * h;
-    const float* wp = Win + (size_t)(32 * w + n) * F + 4 * h;
-
-    f32x16 acc = zero16();
-    for (int G = 0; G < F / 8; ++G) {
-        f32x4 x4 = ld4(xp + 8 * G);
-        if (!valid) x4 = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the batch stay finite (they are never stored to `out`)
-        const f32x4 w4 = ld4(wp + 8 * G);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = SAVAD_MFMA(w4[s], x4[s], acc);
-    }
-    add_bias(acc, bin + 32 * w, h);
-    const int t = (int)((valid ? row : 0) % (size_t)T);
-    add_block(acc, pe + (size_t)t * D + 32 * w, h);
-    store_block(hbuf + row * D + 32 * w, acc, h);  // residual stream h0
-    // V's 32 slack rows behind the last tile feed the PV product with probability exactly 0:
-    // they must be finite, so the last workgroup zeroes them once per forward.
-    if (blockIdx.x == gridDim.x - 1) store_block(v + (row + TILE) * D + 32 * w, zero16(), h);
-    store_block(xbuf + m * XLD + 32 * w, acc, h);
-    __syncthreads();
-    f32x4 xg[16];
-    read_rows_layernorm(xbuf, m, h, xg);
-    qkv_block(xg, Wqkv, bqkv, q, k, v, row, w, n, h);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -580,18 +514,6 @@ __device__ __forceinline__ f32x16 bias_block(const float* lds_bias /* &bias[n0] 
 struct WBlock {
     f32x4 v[16];
 };
-// 32 rows (lane & 31) x 128 k: chunk G at wp + 8G   (wp = W + (n0 + n) * ld + 4h)
-__device__ __forceinline__ void wload_k128(WBlock& wb, const float* __restrict__ wp) {
-#pragma unroll
-    for (int G = 0; G < 16; ++G) wb.v[G] = ld4(wp + 8 * G);
-}
-// 4 output blocks x 32 k (a column slice of W2 [128][512]): chunk (nb, g) at wp + 32*nb*ld + 8g
-__device__ __forceinline__ void wload_w2(WBlock& wb, const float* __restrict__ wp, int ld) {
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) wb.v[4 * nb + g] = ld4(wp + (size_t)(32 * nb) * ld + 8 * g);
-}
 __device__ __forceinline__ void wmma_k128(f32x16& acc, const WBlock& wb, const f32x4 (&xg)[16]) {
 #pragma unroll
     for (int G = 0; G < 16; ++G)
@@ -605,6 +527,32 @@ __device__ __forceinline__ void wmma_w2(f32x16 (&o)[4], const WBlock& wb, const 
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[nb] = SAVAD_MFMA(wb.v[4 * nb + g][e], a[4 * g + e], o[nb]);
+}
+
+// Weights in FRAGMENT ORDER (pack_frag32_kernel): the 16 KB a wave consumes as one A-operand block are contiguous and
+// register i of lane l sits at (i * 64 + l) * 16 bytes, so one load instruction reads 1 KB = 8 whole cache lines.
+// (Row-major blocks make every load touch 32 lines for 32 bytes each, four instructions per line, all in flight
+// together: the L2 sees the stream four times over.)  48 blocks per layer:
+//   0..11 Wqkv' rows 32b..32b+31 | 12..15 Wo rows | 16..31 W1' rows | 32..47 W2 columns 32(b-32).. (all 128 rows)
+constexpr int FRAG_BLOCK = 4096, FRAG_LAYER = 48 * FRAG_BLOCK;  // floats
+// The request and the wait are written out by hand: left to itself hipcc sinks the 16 loads of a block down to
+// their first use once the Q / K / V accumulators join the two weight buffers and the activation rows in the
+// register file ("global_load; s_waitcnt vmcnt(0); 4 MFMAs", 16 times per block -- the prefetch is gone).  The
+// waits name the buffer as an in/out operand so that no MFMA reading it can be scheduled above them; the layer
+// loop issues no other vector-memory instruction, so the counts are exact.
+__device__ __forceinline__ void wload_frag(WBlock& wb, const float* __restrict__ frag, int block, int voff /* lane * 16 bytes */) {
+    const float* p = frag + (size_t)block * FRAG_BLOCK;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(wb.v[i]) : "v"(voff), "s"(p + (i >> 2) * 1024), "n"((i & 3) * 1024));
+}
+template <int PENDING>  // younger requests allowed to stay in flight (16 per block)
+__device__ __forceinline__ void wwait(WBlock& wb) {
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(wb.v[0]), "+v"(wb.v[1]), "+v"(wb.v[2]), "+v"(wb.v[3]), "+v"(wb.v[4]), "+v"(wb.v[5]), "+v"(wb.v[6]), "+v"(wb.v[7]),
+                   "+v"(wb.v[8]), "+v"(wb.v[9]), "+v"(wb.v[10]), "+v"(wb.v[11]), "+v"(wb.v[12]), "+v"(wb.v[13]), "+v"(wb.v[14]),
+                   "+v"(wb.v[15])
+                 : "n"(PENDING));
 }
 
 // ctx = sum_s w_s O_s / sum_s w_s l_s over the S key-split partials of the lane's row (lane-local scalars).
@@ -624,6 +572,14 @@ __device__ __forceinline__ void combine_splits(f32x4 (&xg)[16], const float* __r
         for (int G = 0; G < 16; ++G) xg[G] = valid ? xg[G] * inv : f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
+    // every split's partial is requested one split ahead of its use, the first one before the maxima are known: the
+    // loads of a split are one L2 / MALL round trip (the attention launch wrote them from another XCD)
+    f32x4 nxt[16];
+    {
+        const float* op0 = Opart + row * D + 4 * h;
+#pragma unroll
+        for (int G = 0; G < 16; ++G) nxt[G] = ld4(op0 + 8 * G);
+    }
     float M = NEG_BIG;
     for (int s = 0; s < S; ++s) {
         const float ms = ml[((size_t)s * rows_pad + row) * 2];
@@ -633,31 +589,110 @@ __device__ __forceinline__ void combine_splits(f32x4 (&xg)[16], const float* __r
 #pragma unroll
     for (int G = 0; G < 16; ++G) xg[G] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < S; ++s) {
+        f32x4 cur[16];
+#pragma unroll
+        for (int G = 0; G < 16; ++G) cur[G] = nxt[G];
+        if (s + 1 < S) {
+            const float* op = Opart + ((size_t)(s + 1) * rows_pad + row) * D + 4 * h;
+#pragma unroll
+            for (int G = 0; G < 16; ++G) nxt[G] = ld4(op + 8 * G);
+        }
         f32x2 t = *reinterpret_cast<const f32x2*>(ml + ((size_t)s * rows_pad + row) * 2);
         if (!valid) t = f32x2{0.0f, 1.0f};
         const float ws = __builtin_amdgcn_exp2f((t[0] - M) * c);
         den += ws * t[1];
-        const float* op = Opart + ((size_t)s * rows_pad + row) * D + 4 * h;
 #pragma unroll
-        for (int G = 0; G < 16; ++G) {
-            f32x4 o4 = ld4(op + 8 * G);
-            if (!valid) o4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            xg[G] += ws * o4;
-        }
+        for (int G = 0; G < 16; ++G) xg[G] += ws * (valid ? cur[G] : f32x4{0.f, 0.f, 0.f, 0.f});
     }
     const float inv = 1.0f / den;
 #pragma unroll
     for (int G = 0; G < 16; ++G) xg[G] *= inv;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel 1: input Linear(F, D) + sinusoidal PE / sqrt(D)  (vad/models/self_attention.py:12-16,24;
+// vad/modeling/transformer.py:392-401), then layer-0 LN + QKV (transformer.py:234-237,281-284).
+// One workgroup (4 waves) per 32 data rows; wave w owns output features [32w, 32w+32).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void input_qkv_kernel(
+    const float* __restrict__ x, int rows, int T, int F, const float* __restrict__ Win, const float* __restrict__ bin,
+    const float* __restrict__ pe /* [T][D], already / sqrt(D) */, const float* __restrict__ frag0 /* layer 0, fragment order */,
+    const float* __restrict__ bqkv, float* __restrict__ hbuf, float* __restrict__ q, float* __restrict__ k,
+    float* __restrict__ v) {
+    __shared__ __attribute__((aligned(16))) float lds[TILE * XLD + 3 * D];
+    float* xbuf = lds;
+    float* lbn = lds + TILE * XLD;
+    const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int voff = lane * 16;
+    const size_t row = (size_t)blockIdx.x * TILE + m;
+    const bool valid = row < (size_t)rows;
+    const float* xp = x + (valid ? row : 0) * (size_t)F + 4 * h;
+    const float* wp = Win + (size_t)(32 * w + n) * F + 4 * h;
+    WBlock wa, wb;
+    stage_bias(lbn, bqkv, 3 * D);
+
+    // K = F in chunks of 128: all loads of a chunk requested before its first MFMA (F is a multiple of 16)
+    f32x16 acc = zero16();
+    const int nG = F / 8;
+    for (int G0 = 0; G0 < nG; G0 += 16) {
+        f32x4 xin[16];
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const int Gc = G0 + G < nG ? G0 + G : nG - 1;  // past the end: a valid address, the product is dropped below
+            xin[G] = ld4(xp + 8 * Gc);
+            wb.v[G] = ld4(wp + 8 * Gc);
+        }
+#pragma unroll
+        for (int G = 0; G < 16; G += 2) {
+            if (G0 + G < nG) {
+#pragma unroll
+                for (int g = G; g < G + 2; ++g) {
+                    const f32x4 x4 = valid ? xin[g] : f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the batch stay finite (never stored to `out`)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = SAVAD_MFMA(wb.v[g][e], x4[e], acc);
+                }
+            }
+        }
+    }
+    add_bias(acc, bin + 32 * w, h);
+    const int t = (int)((valid ? row : 0) % (size_t)T);
+    add_block(acc, pe + (size_t)t * D + 32 * w, h);
+    // layer 0's query / key blocks (fragment order, hand-placed waits: see wload_frag); requested behind the
+    // compiler-managed loads above, whose waits would otherwise cover these too
+    wload_frag(wa, frag0, w, voff);
+    wload_frag(wb, frag0, 4 + w, voff);
+    store_block(hbuf + row * D + 32 * w, acc, h);  // residual stream h0
+    // V's 32 slack rows behind the last tile feed the PV product with probability exactly 0:
+    // they must be finite, so the last workgroup zeroes them once per forward.
+    if (blockIdx.x == gridDim.x - 1) store_block(v + (row + TILE) * D + 32 * w, zero16(), h);
+    store_block(xbuf + m * XLD + 32 * w, acc, h);
+    __syncthreads();
+    f32x4 xg[16];
+    read_rows_layernorm(xbuf, m, h, xg);
+    f32x16 qa = bias_block(lbn + 32 * w, h);
+    wwait<16>(wa);
+    wmma_k128(qa, wa, xg);
+    wload_frag(wa, frag0, 8 + w, voff);
+    f32x16 ka = bias_block(lbn + D + 32 * w, h);
+    wwait<16>(wb);
+    wmma_k128(ka, wb, xg);
+    f32x16 va = bias_block(lbn + 2 * D + 32 * w, h);
+    wwait<0>(wa);
+    wmma_k128(va, wa, xg);
+    store_block(q + row * D + 32 * w, qa, h);
+    store_block(k + row * D + 32 * w, ka, h);
+    store_block(v + row * D + 32 * w, va, h);
+}
+
 template <bool LAST>
 __global__ __launch_bounds__(256, 1) void row_kernel(
     const float* __restrict__ Opart, const float* __restrict__ ml, int S, int rows, int rows_pad, float c,
-    float* __restrict__ hbuf, const float* __restrict__ Wo, const float* __restrict__ bo,
-    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
-    const float* __restrict__ b2, const float* __restrict__ Wn /* LAST ? Wc'[2][D] : Wqkv'[3D][D] */,
-    const float* __restrict__ bn, float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
-    float* __restrict__ out /* [rows][2] */) {
+    float* __restrict__ hbuf, const float* __restrict__ frag /* this layer's weights in fragment order */,
+    const float* __restrict__ bo, const float* __restrict__ b1, const float* __restrict__ b2,
+    const float* __restrict__ nfrag /* LAST ? unused : the next layer's fragments (Wqkv' blocks 0..11) */,
+    const float* __restrict__ Wn /* LAST: Wc'[2][D] */, const float* __restrict__ bn /* LAST ? bc'[2] : bqkv'[3D] */,
+    float* __restrict__ q, float* __restrict__ k, float* __restrict__ v, float* __restrict__ out /* [rows][2] */) {
     __shared__ __attribute__((aligned(16))) float lds[TILE * XLD + 12 * TILE * PLD + 8 * D];
     float* xbuf = lds;
     float* pbuf = lds + TILE * XLD;  // [dest block 4][src slot 3][32 rows][PLD]
@@ -666,24 +701,34 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     float* lbn = lb2 + D;
     const int lane = threadIdx.x & 63, n = lane & 31, m = n, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int voff = lane * 16;
     const size_t row = (size_t)blockIdx.x * TILE + m;
 
     SAVAD_STAMP(32);
+    // Weight stream of this wave (16 KB blocks in fragment order, wload_frag / wwait): Wo, then W1 / W2 slices
+    // alternating, then the next layer's Q, K, V blocks; two register buffers, every block requested one block ahead.
+    // The waits count LOADS only: result stores issued in between may retire out of order with respect to loads, so they
+    // are never part of the allowance (a wait can only come out longer than needed, never shorter).
     WBlock wa, wb;
-    stage_bias(lb1, b1, DFF);
-    stage_bias(lb2, b2, D);
-    if (!LAST) stage_bias(lbn, bn, 3 * D);
-    wload_k128(wa, Wo + (size_t)(32 * w + n) * D + 4 * h);  // requested before the partials: consumed after phase 0
-    f32x16 h1 = zero16();  // the out-projection accumulator starts at the residual stream (requested now, consumed after phase 0)
+    wload_frag(wb, frag, 12 + w, voff);      // Wo rows 32w..
+    wload_frag(wa, frag, 16 + 4 * w, voff);  // first FFN block
+    // b1 | b2 | bqkv' are 256 float4 (160 without the QKV bias): ONE load per thread, requested with everything else of
+    // this phase and stored to LDS after it (a load -> wait -> store sequence per array costs a round trip each)
+    const int t4 = threadIdx.x;
+    const bool bias_lane = LAST ? t4 < 160 : true;
+    const float* bsrc = t4 < 128 ? b1 + 4 * t4 : (t4 < 160 ? b2 + 4 * (t4 - 128) : bn + 4 * (t4 - 160));
+    const f32x4 bval = bias_lane ? ld4(bsrc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x16 h1 = zero16();  // the out-projection accumulator starts at the residual stream + bias
+    add_bias(h1, bo + 32 * w, h);
     add_block(h1, hbuf + row * D + 32 * w, h);
     // ---- phase 0: ctx = combination of the key-split partials (rows are lane-local: all scalars per lane)
     f32x4 xg[16];
     combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
+    if (bias_lane) st4(lb1 + 4 * t4, bval);  // published by the first barrier below
     SAVAD_STAMP(33);
     // ---- phase 1: h1 = ctx Wo^T + bo + h   (wave's 32 features)
-    wload_k128(wb, W1 + (size_t)(128 * w + n) * D + 4 * h);  // first FFN block
-    wmma_k128(h1, wa, xg);
-    add_bias(h1, bo + 32 * w, h);
+    wwait<16>(wb);
+    wmma_k128(h1, wb, xg);
     store_block(xbuf + m * XLD + 32 * w, h1, h);
     __syncthreads();
     read_rows_layernorm(xbuf, m, h, xg);
@@ -695,17 +740,17 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     for (int nb = 0; nb < 4; ++nb) o[nb] = zero16();
 #pragma unroll 1
     for (int ch = 0; ch < 4; ++ch) {
-        const int hid0 = 128 * w + 32 * ch;
-        wload_w2(wa, W2 + (size_t)n * DFF + hid0 + 4 * h, DFF);
-        f32x16 a = bias_block(lb1 + hid0, h);
-        wmma_k128(a, wb, xg);
+        wload_frag(wb, frag, 32 + 4 * w + ch, voff);
+        f32x16 a = bias_block(lb1 + 128 * w + 32 * ch, h);
+        wwait<16>(wa);
+        wmma_k128(a, wa, xg);
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
-        if (ch + 1 < 4)
-            wload_k128(wb, W1 + (size_t)(hid0 + 32 + n) * D + 4 * h);
-        else if (!LAST)
-            wload_k128(wb, Wn + (size_t)(32 * w + n) * D + 4 * h);  // query block of the next layer
-        wmma_w2(o, wa, a);
+        // the next W1 slice, or the next layer's query block; the LAST launch re-reads a block it will not use (keeps
+        // the wait count uniform)
+        wload_frag(wa, (ch + 1 < 4 || LAST) ? frag : nfrag, ch + 1 < 4 ? 16 + 4 * w + ch + 1 : w, voff);
+        wwait<16>(wb);
+        wmma_w2(o, wb, a);
     }
     SAVAD_STAMP(35);
     // reduce-scatter the 4 K-split partials: wave w ends up with feature block w
@@ -732,17 +777,21 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
     read_rows_layernorm(xbuf, m, h, xg);
     SAVAD_STAMP(37);
     if (!LAST) {
-        // Q (already in wb), K, V blocks of this wave's 32 features, each prefetched one block ahead
-        float* dst[3] = {q, k, v};
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            WBlock& cur = (j & 1) ? wa : wb;
-            WBlock& nxt = (j & 1) ? wb : wa;
-            if (j + 1 < 3) wload_k128(nxt, Wn + (size_t)(D * (j + 1) + 32 * w + n) * D + 4 * h);
-            f32x16 acc = bias_block(lbn + D * j + 32 * w, h);
-            wmma_k128(acc, cur, xg);
-            store_block(dst[j] + row * D + 32 * w, acc, h);
-        }
+        // Q (in flight in wa), K, V blocks of this wave's 32 features; results are stored after the last wait
+        wload_frag(wb, nfrag, 4 + w, voff);
+        f32x16 qa = bias_block(lbn + 32 * w, h);
+        wwait<16>(wa);
+        wmma_k128(qa, wa, xg);
+        wload_frag(wa, nfrag, 8 + w, voff);
+        f32x16 ka = bias_block(lbn + D + 32 * w, h);
+        wwait<16>(wb);
+        wmma_k128(ka, wb, xg);
+        f32x16 va = bias_block(lbn + 2 * D + 32 * w, h);
+        wwait<0>(wa);
+        wmma_k128(va, wa, xg);
+        store_block(q + row * D + 32 * w, qa, h);
+        store_block(k + row * D + 32 * w, ka, h);
+        store_block(v + row * D + 32 * w, va, h);
     } else if (w == 0) {
         float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
@@ -782,34 +831,9 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
 // q / k / v / h round trip through L2 and one launch instead of four.
 // ---------------------------------------------------------------------------------------------
 constexpr int PACKED_MAX_LAYERS = 8;
-// Weights in FRAGMENT ORDER (pack_frag32_kernel): the 16 KB a wave consumes as one A-operand block are contiguous and
-// register i of lane l sits at (i * 64 + l) * 16 bytes, so one load instruction reads 1 KB = 8 whole cache lines.
-// (Row-major blocks make every load touch 32 lines for 32 bytes each, four instructions per line, all in flight
-// together: the L2 sees the stream four times over.)  48 blocks per layer:
-//   0..11 Wqkv' rows 32b..32b+31 | 12..15 Wo rows | 16..31 W1' rows | 32..47 W2 columns 32(b-32).. (all 128 rows)
-constexpr int FRAG_BLOCK = 4096, FRAG_LAYER = 48 * FRAG_BLOCK;  // floats
 struct PackedLayer {
     const float* frag;  // Wqkv / W1: LayerNorm affine folded in
 };
-// The request and the wait are written out by hand: left to itself hipcc sinks the 16 loads of a block down to
-// their first use once the Q / K / V accumulators join the two weight buffers and the activation rows in the
-// register file ("global_load; s_waitcnt vmcnt(0); 4 MFMAs", 16 times per block -- the prefetch is gone).  The
-// waits name the buffer as an in/out operand so that no MFMA reading it can be scheduled above them; the layer
-// loop issues no other vector-memory instruction, so the counts are exact.
-__device__ __forceinline__ void wload_frag(WBlock& wb, const float* __restrict__ frag, int block, int voff /* lane * 16 bytes */) {
-    const float* p = frag + (size_t)block * FRAG_BLOCK;  // wave-uniform
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(wb.v[i]) : "v"(voff), "s"(p + (i >> 2) * 1024), "n"((i & 3) * 1024));
-}
-template <int PENDING>  // younger requests allowed to stay in flight (16 per block)
-__device__ __forceinline__ void wwait(WBlock& wb) {
-    asm volatile("s_waitcnt vmcnt(%16)"
-                 : "+v"(wb.v[0]), "+v"(wb.v[1]), "+v"(wb.v[2]), "+v"(wb.v[3]), "+v"(wb.v[4]), "+v"(wb.v[5]), "+v"(wb.v[6]), "+v"(wb.v[7]),
-                   "+v"(wb.v[8]), "+v"(wb.v[9]), "+v"(wb.v[10]), "+v"(wb.v[11]), "+v"(wb.v[12]), "+v"(wb.v[13]), "+v"(wb.v[14]),
-                   "+v"(wb.v[15])
-                 : "n"(PENDING));
-}
 struct PackedModel {
     PackedLayer layer[PACKED_MAX_LAYERS];
     const float *win, *bin, *pe, *wc, *bc;
