@@ -255,6 +255,10 @@ def test_single_launch_packed_forward(torch_cuda, model, golden, state1234):
     st = seeded_state_dict(55, num_layers=5)
     x = feats(56, (6, 7, 80))
     assert np.abs(run(torch, make_model(torch, st, L=5), x, row_mode=4) - oracle.forward(st, x)).max() < TIGHT
+    st = seeded_state_dict(57, num_layers=9)  # deeper than the kernel's layer table (8): the per-layer launches take over
+    m9 = make_model(torch, st, L=9)
+    for mode in (0, 4):
+        assert np.abs(run(torch, m9, x, row_mode=mode) - oracle.forward(st, x)).max() < TIGHT, mode
 
 
 def test_properties_full_size(torch_cuda, model):
