@@ -136,6 +136,18 @@ int savad_window_offsets(int half, int jump, int32_t* offsets);
 int savad_gather_windows(const float* feature, int N, int F, int half, int jump, int first, int count, float* windows,
                          int64_t* positions, void* stream);
 
+/* The whole of VADFromScratchPredictor.predict_probabilities (vad/predictor.py:159-262) in one call: feature [N,F] fp32
+ * (device) -> probs [N,W] (the boosted positive-class probabilities, unfilled slots exactly 0.5) and mean [N] (may be
+ * NULL) = probs.mean(axis=1) (vad/predictor.py:95).  Windows are cut as savad_gather_windows does, `chunk` windows per
+ * forward (the reference's chunk_size, :180); results are those of savad_gather_windows + savad_forward + savad_boost
+ * (bit for bit when the forwards run the same launch schedule).  With fp32 arithmetic, W <= 32 and at most 1024 packed
+ * tiles (4096 windows of 7 frames) the forward reads its windows straight out of the feature matrix (no window copies,
+ * no positions, no scatter): two launches for the whole clip.  Asynchronous on `stream`, no allocation;
+ * workspace from savad_predict_workspace_bytes (same N, half, jump, chunk and the handle's current precision). */
+int savad_predict_workspace_bytes(savad_handle h, int N, int half, int jump, int chunk, size_t* bytes);
+int savad_predict_probabilities(savad_handle h, const float* feature, int N, int half, int jump, int chunk, float* probs,
+                                float* mean, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Replaces the boosted prediction (vad/predictor.py:238-258 and :95):
  *   boosted[N][W][2] = 0; boosted[positions[b][w]][w] = logp[b][w]  (scatter)
  *   probs[n][w] = softmax(boosted[n][w])[1]  (unfilled slots = exactly 0.5, and averaged in)

@@ -405,6 +405,39 @@ def test_predictor_level_golden(torch_cuda, model, golden, tag, n, seed):
     assert np.abs(big.predict_probabilities(feat) - probs).max() < 1e-6
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_one_call_predictor_matches_the_three_entry_points(torch_cuda, model, precision):
+    """savad_predict_probabilities (windows read straight out of the feature matrix by the single-launch forward, boosted
+    prediction as a gather) against savad_gather_windows + savad_forward + savad_boost: the same bits -- whole clips, a clip
+    longer than one launch's 4096 windows, clips too short for a single window, the bf16 path (window copies + forward
+    inside the call) and a reference-style chunk_size."""
+    from voice_activity_detection_amd import VADFromScratchPredictor
+
+    torch = torch_cuda
+    model.precision = precision
+    try:
+        for n, chunk in ((1022, 16384), (5000, 16384), (39, 16384), (38, 16384), (5, 16384), (1, 16384), (2100, 1000)):
+            pred = VADFromScratchPredictor(model, "cuda", chunk_size=chunk)
+            feat = torch.from_numpy(feats(900 + n, (n, 80))).cuda()
+            p1, m1 = pred.predict_probabilities_device(feat)
+            p0, m0 = pred.predict_probabilities_device_stepwise(feat)
+            torch.cuda.synchronize()
+            assert p1.shape == p0.shape == (n, 7) and torch.equal(p1, p0) and torch.equal(m1, m0), (n, chunk)
+        big = VADFromScratchPredictor(model, "cuda")
+        model.row_mode = 4  # force the windowed single launch beyond its automatic range: 4096-window launches
+        try:
+            feat = torch.from_numpy(feats(77, (9000, 80))).cuda()
+            p1, _ = big.predict_probabilities_device(feat)
+            model.row_mode = 0
+            p0, _ = big.predict_probabilities_device_stepwise(feat)
+            assert float((p1 - p0).abs().max()) < (2e-6 if precision == "fp32" else 1e-2)
+        finally:
+            model.row_mode = 0
+        assert pred.predict_probabilities(np.zeros((0, 80), np.float32)).shape == (0, 7)
+    finally:
+        model.precision = "fp32"
+
+
 def test_gather_and_boost_bit_exact(torch_cuda):
     """Index/byte work is bit-exact against the oracle."""
     from oracle import oracle

@@ -42,6 +42,8 @@ SYMBOLS = {
     "savad_window_offsets": (c_int, [c_int, c_int, POINTER(c_int32)]),
     "savad_gather_windows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "savad_boost": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "savad_predict_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "savad_predict_probabilities": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "savad_stream_window_count": (c_int, [c_int, c_int, c_int]),
     "savad_gather_strided": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "savad_overlap_merge": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -830,6 +830,11 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
 // 32 attention MFMAs per wave and layer instead of the 128 redundant ones of row_kernel's packed mode, no
 // q / k / v / h round trip through L2 and one launch instead of four.
 // ---------------------------------------------------------------------------------------------
+// window geometry of the predictor (vad/predictor.py:186-212): W relative frame offsets
+struct WindowOffsets {
+    int w;
+    int off[64];
+};
 constexpr int PACKED_MAX_LAYERS = 8;
 struct PackedLayer {
     const float* frag;  // Wqkv / W1: LayerNorm affine folded in
@@ -842,8 +847,12 @@ struct PackedModel {
 };
 constexpr int LBIAS = DFF + D + 3 * D + D;  // b1 | b2 | bqkv | bo
 
+// Windowed mode (wo.w == T > 0): x is the predictor's feature MATRIX [N][F] and sequence s is its window
+// feature[win_base + s + wo.off[0..T-1]] (a13, vad/predictor.py:180-220) -- the gather is an address computation here
+// instead of a launch that writes 7 copies of every frame and a forward that reads them back.
 __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __restrict__ x, int rows, int T, int F, PackedModel M,
-                                                                float c, float* __restrict__ out, int tile_rows) {
+                                                                float c, float* __restrict__ out, int tile_rows, WindowOffsets wo,
+                                                                int win_base) {
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE * XLD + 12 * TILE * PLD + PACKED_MAX_LAYERS * LBIAS];
     float* xb0 = lds;
     float* xb1 = lds + TILE * XLD;
@@ -873,7 +882,9 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
     // chunk requested before its first MFMA
     f32x16 own = zero16();
     {
-        const float* xp = x + (in_batch ? row : 0) * (size_t)F + 4 * h;
+        const size_t rr = in_batch ? row : 0;
+        const size_t src_row = wo.w > 0 ? (size_t)win_base + rr / (size_t)T + wo.off[rr % (size_t)T] : rr;
+        const float* xp = x + src_row * (size_t)F + 4 * h;
         const float* wp = M.win + (size_t)(32 * w + n) * F + 4 * h;
         const int nG = F / 8;
         for (int G0 = 0; G0 < nG; G0 += 16) {
@@ -1484,10 +1495,6 @@ __global__ void fold_ln_kernel(const float* __restrict__ W, const float* __restr
 // ---------------------------------------------------------------------------------------------
 // a13: window gather (vad/predictor.py:180-220).  One thread per output float4.
 // ---------------------------------------------------------------------------------------------
-struct WindowOffsets {
-    int w;
-    int off[64];
-};
 __global__ void gather_windows_kernel(const float* __restrict__ feature, int F, int half, int first, int count,
                                       WindowOffsets wo, float* __restrict__ windows, int64_t* __restrict__ positions) {
     const int f4 = F / 4;
@@ -1520,6 +1527,28 @@ __global__ void boost_softmax_kernel(const float* __restrict__ boosted, int N, i
         float acc = 0.0f;
         for (int wi = 0; wi < W; ++wi) {
             const f32x2 z = *reinterpret_cast<const f32x2*>(boosted + ((size_t)nrow * W + wi) * 2);
+            const float mx = fmaxf(z[0], z[1]);
+            const float e0 = expf(z[0] - mx), e1 = expf(z[1] - mx);
+            const float p = e1 / (e0 + e1);
+            probs[(size_t)nrow * W + wi] = p;
+            acc += p;
+        }
+        if (mean) mean[nrow] = acc / (float)W;
+    }
+}
+
+// The same result as scatter + softmax, read the other way round: slot (n, w) of the boosted array was written by
+// window b = n - half - off[w] if that window exists, else it still holds (0, 0) -> 0.5.  Same arithmetic on the same
+// values, no memset, no scatter launch, no positions array.
+__global__ void boost_gather_kernel(const float* __restrict__ logp, int n_items, int N, int half, WindowOffsets wo,
+                                    float* __restrict__ probs, float* __restrict__ mean) {
+    const int W = wo.w;
+    for (int nrow = blockIdx.x * blockDim.x + threadIdx.x; nrow < N; nrow += gridDim.x * blockDim.x) {
+        float acc = 0.0f;
+        for (int wi = 0; wi < W; ++wi) {
+            const int b = nrow - half - wo.off[wi];
+            f32x2 z = f32x2{0.0f, 0.0f};
+            if (b >= 0 && b < n_items) z = *reinterpret_cast<const f32x2*>(logp + ((size_t)b * W + wi) * 2);
             const float mx = fmaxf(z[0], z[1]);
             const float e0 = expf(z[0] - mx), e1 = expf(z[1] - mx);
             const float p = e1 / (e0 + e1);

@@ -210,6 +210,45 @@ class SelfAttentiveVAD(nn.Module):
                                             ws.numel(), ctypes.c_void_p(stream)))
         return out
 
+    @torch.no_grad()
+    def predict_windows(self, feature: Tensor, half: int, jump: int, chunk: int):
+        """The whole of VADFromScratchPredictor.predict_probabilities (vad/predictor.py:159-262) in ONE library call
+        (savad_predict_probabilities): feature [N, F] fp32 on the device -> (probs [N, W], mean [N]); the windows are
+        read straight out of the feature matrix when the single-launch forward applies."""
+        if feature.device.type != "cuda":
+            raise _lib.SavadError("the MI355X predictor needs a HIP device (no CPU fallback)")
+        if self.training and self.dropout_p > 0:
+            raise _lib.SavadError("training-mode dropout is outside this build's scope: call model.eval()")
+        device = feature.device
+        feat = feature.detach().float().contiguous()
+        if feat.dim() != 2 or feat.shape[1] != self.feature_size:
+            raise ValueError(f"feature must be [N, {self.feature_size}], got {tuple(feat.shape)}")
+        N = feat.shape[0]
+        lib = _lib.load()
+        W = lib.savad_window_offsets(int(half), int(jump), None)
+        probs = torch.empty((N, W), dtype=torch.float32, device=device)
+        mean = torch.empty((N,), dtype=torch.float32, device=device)
+        if N == 0:
+            return probs, mean
+        with torch.cuda.device(device):
+            self._ensure_handle(device)
+            self.sync_weights()
+            _lib.check(lib.savad_set_attention_splits(self._handle, int(self.attention_splits)))
+            _lib.check(lib.savad_set_row_mode(self._handle, int(self.row_mode)))
+            _lib.check(lib.savad_set_precision(self._handle, 1 if self.precision == "bf16" else 0))
+            nbytes = ctypes.c_size_t()
+            _lib.check(lib.savad_predict_workspace_bytes(self._handle, N, int(half), int(jump), int(chunk), ctypes.byref(nbytes)))
+            ws = self._workspace
+            if ws is None or ws.device != device or ws.numel() < nbytes.value:
+                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+                self._workspace = ws
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.savad_predict_probabilities(self._handle, ctypes.c_void_p(feat.data_ptr()), N, int(half), int(jump),
+                                                       int(chunk), ctypes.c_void_p(probs.data_ptr()),
+                                                       ctypes.c_void_p(mean.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                                       ws.numel(), ctypes.c_void_p(stream)))
+        return probs, mean
+
     def reserve(self, max_frames: int, device=None):
         """Pre-size the library's positional-encoding table for sequences of up to `max_frames` frames (savad_reserve):
         forwards with T <= max_frames then run without any allocation or synchronisation inside the library."""

@@ -185,12 +185,22 @@ class VADFromScratchPredictor:
 
     @torch.no_grad()
     def predict_probabilities_device(self, feature):
-        lib = _lib.load()
+        """feature [N, F] -> (probs [N, W], mean [N]) on the device: window gather (a13), forward, boosted prediction (a14)
+        in one library call (savad_predict_probabilities)."""
         if self.device.type != "cuda":
             raise _lib.SavadError("the MI355X predictor needs a HIP device (no CPU fallback)")
-        feat = torch.as_tensor(feature, dtype=torch.float32).to(self.device).contiguous()
+        feat = torch.as_tensor(feature, dtype=torch.float32).to(self.device)
         if feat.dim() != 2:
             raise ValueError("feature must be [N, F]")
+        self.model.eval()
+        return self.model.predict_windows(feat, self.context_window_half_frames, self.context_window_jump_frames, self.chunk_size)
+
+    @torch.no_grad()
+    def predict_probabilities_device_stepwise(self, feature):
+        """The same through the three separate entry points (savad_gather_windows, savad_forward, savad_boost): what
+        savad_predict_probabilities must reproduce bit for bit (tests)."""
+        lib = _lib.load()
+        feat = torch.as_tensor(feature, dtype=torch.float32).to(self.device).contiguous()
         N, F = feat.shape
         half, jump, W = self.context_window_half_frames, self.context_window_jump_frames, self.context_window_frames
         data_length = N - 2 * half  # vad/predictor.py:169
