@@ -106,7 +106,8 @@ int savad_set_attention_splits(savad_handle h, int splits);
  *     1  row-wise stages on 32-row tiles, output features split over the workgroup's 4 waves; attention is its own
  *        launch (what automatic picks for small T > 32 batches)
  *     4  T <= 32: the whole forward in ONE launch, a workgroup per packed tile of floor(32/T) sequences (what
- *        automatic picks up to 1024 tiles); T > 32: as 0
+ *        automatic picks up to 1024 tiles unless the dense 32-row tiles of mode 1 fit fewer rounds of the CUs);
+ *        T > 32: as 0
  *     2  row-wise stages on 128-row tiles, weight stream shared through LDS; attention and row stages are
  *        separate launches
  *     3  as 2, with attention and row chain of a query-block group fused into one launch per layer whenever

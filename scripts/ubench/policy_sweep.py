@@ -25,11 +25,11 @@ for B, T in shapes:
     if prec == "bf16": x = x.to(torch.bfloat16)
     res = {}
     bench(x)  # first-touch effects (allocation, clocks) land here, not on the first mode timed
-    for mode in (3, 2, 1, 0):
+    for mode in (4, 3, 2, 1, 0):
         m.row_mode = mode
         res[mode] = bench(x)
     best = min(res.values())
     ratio = res[0] / best
     worst = max(worst, ratio)
-    print(f"B={B:6d} T={T:5d}  auto {res[0]:.4f}  N {res[1]:.4f}  M {res[2]:.4f}  fused {res[3]:.4f}   auto/best = {ratio:.3f}" + ("  <<<" if ratio > 1.05 else ""), flush=True)
+    print(f"B={B:6d} T={T:5d}  auto {res[0]:.4f}  N {res[1]:.4f}  M {res[2]:.4f}  fused {res[3]:.4f}  one {res[4]:.4f}   auto/best = {ratio:.3f}" + ("  <<<" if ratio > 1.05 else ""), flush=True)
 print("worst auto/best", round(worst, 3))

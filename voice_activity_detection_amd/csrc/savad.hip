@@ -805,8 +805,14 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     // launch / per-layer N-split launches / M-split: 250 tiles 0.100 / 0.156 / 0.356; 512 tiles 0.186 / 0.272 / 0.364;
     // 1024 tiles 0.366 / 0.506 / 0.383; 2048 tiles 0.728 / 0.878 / 0.699; 4096 tiles (the predictor's 16384-window
     // batches) 1.454 / 1.736 / 1.346.  row_mode 4 forces the single launch for any T <= 32 batch.
-    if (T <= 32 && L <= PACKED_MAX_LAYERS &&
-        (m->row_mode == 4 || (m->row_mode == 0 && (B + 32 / T - 1) / (32 / T) <= 1024))) {
+    // A packed tile holds floor(32/T)*T of 32 rows (28 at T=7, 20 at T=20, 17 at T=17): while the DENSE 32-row tiles of the
+    // per-layer N-split launches still fit fewer rounds of the CUs, those win (T=20, B=400: 400 packed / 250 dense tiles,
+    // 0.184 against 0.160 ms).  Round model fitted to scripts/ubench/policy_sweep.py: 92 us per round of packed tiles, 45 +
+    // 110 us per round of dense tiles.
+    const long tiles_packed = T <= 32 ? ((long)B + 32 / T - 1) / (32 / T) : 0, tiles_dense = ((long)B * T + 31) / 32;
+    const bool one_launch = tiles_packed <= 1024 &&
+                            (tiles_dense > 512 || 92 * ((tiles_packed + 255) / 256) <= 45 + 110 * ((tiles_dense + 255) / 256));
+    if (T <= 32 && L <= PACKED_MAX_LAYERS && (m->row_mode == 4 || (m->row_mode == 0 && one_launch))) {
         WindowOffsets none;
         none.w = 0;
         launch_packed_forward(m, st, x, B, T, F, out, none, 0);
