@@ -56,16 +56,34 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
         f32x16 acc[4];
 #pragma unroll
         for (int rbl = 0; rbl < 4; ++rbl) acc[rbl] = zero16();
-        const float* ap = dft_frag + (size_t)(pass * 4) * KG * 256 + lane * 4;
-#pragma unroll 2
+        // DFT rows and samples of k-group G are requested TWO groups (32 MFMAs) ahead, by hand: hipcc sinks such loads down
+        // to their first use (compiler finding (vi)) and each of the 50 groups then pays an L2 round trip.
+        const float* apu = dft_frag + (size_t)(pass * 4) * KG * 256;  // wave-uniform
+        const int voff = lane * 16;
+        f32x4 ab[3][4], xb[3];
+        auto issue = [&](int G, int slot) {
+#pragma unroll
+            for (int rbl = 0; rbl < 4; ++rbl)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ab[slot][rbl]) : "v"(voff), "s"(apu + (size_t)(rbl * KG + G) * 256));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xb[slot]) : "v"(xp + 8 * G));
+        };
+        issue(0, 0);
+        issue(1, 1);
+#pragma unroll
         for (int G = 0; G < KG; ++G) {
-            const f32x4 x4 = ld4(xp + 8 * G);
+            const int slot = G % 3;
+            if (G + 2 < KG) issue(G + 2, (G + 2) % 3);
+            // loads retire in order: at most the 5 x (groups issued after G) may still be in flight
+            if (G + 2 < KG)
+                asm volatile("s_waitcnt vmcnt(10)" : "+v"(ab[slot][0]), "+v"(ab[slot][1]), "+v"(ab[slot][2]), "+v"(ab[slot][3]), "+v"(xb[slot]));
+            else if (G + 1 < KG)
+                asm volatile("s_waitcnt vmcnt(5)" : "+v"(ab[slot][0]), "+v"(ab[slot][1]), "+v"(ab[slot][2]), "+v"(ab[slot][3]), "+v"(xb[slot]));
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ab[slot][0]), "+v"(ab[slot][1]), "+v"(ab[slot][2]), "+v"(ab[slot][3]), "+v"(xb[slot]));
 #pragma unroll
-            for (int rbl = 0; rbl < 4; ++rbl) {
-                const f32x4 a4 = ld4(ap + (size_t)(rbl * KG + G) * 256);
+            for (int rbl = 0; rbl < 4; ++rbl)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[rbl] = SAVAD_MFMA(a4[e], x4[e], acc[rbl]);
-            }
+                for (int e = 0; e < 4; ++e) acc[rbl] = SAVAD_MFMA(ab[slot][rbl][e], xb[slot][e], acc[rbl]);
         }
         // power spectrum, lane-local: rows 2b (re) and 2b+1 (im) are registers 2i and 2i+1
         const float* mp = mel_frag + (size_t)(pass * 3) * 4 * 2 * 256 + lane * 4;
