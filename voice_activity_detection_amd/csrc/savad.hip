@@ -1208,7 +1208,7 @@ SAVAD_EXPORT int savad_logmel(const float* audio, int n_samples, float* workspac
     const int g1 = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(mel::reflect_pad_kernel, dim3(g1), dim3(256), 0, st, audio, n_samples, workspace);
     const int tiles = (n_frames + 31) / 32;
-    hipLaunchKernelGGL(mel::logmel_kernel, dim3(tiles), dim3(256), 0, st, workspace, n_frames, g_mel.d_dft, g_mel.d_mel,
+    hipLaunchKernelGGL(mel::logmel_kernel<4>, dim3(tiles), dim3(256), 0, st, workspace, n_frames, g_mel.d_dft, g_mel.d_mel,
                        features);
     HIP_TRY(hipGetLastError());
     return SAVAD_OK;

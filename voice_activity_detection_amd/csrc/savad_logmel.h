@@ -14,9 +14,19 @@
 // tile.  One workgroup = 32 frames, its 4 waves take one pass of 4 DFT row blocks (64 bins) each.
 #pragma once
 #include "savad_kernels.h"
+#include <type_traits>
 
 namespace savad {
 namespace mel {
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 constexpr int N_FFT = 512, HOP = 160, WIN = 400, N_MELS = 80, LPAD = (N_FFT - WIN) / 2;  // LPAD = 56
 constexpr int KG = WIN / 8;                    // 50 k-groups of 8 samples
@@ -38,12 +48,17 @@ __global__ void reflect_pad_kernel(const float* __restrict__ y, int n, float* __
 // One WORKGROUP = 32 frames; wave w runs pass w (64 of the 256 bins: 800 DFT MFMAs + its 96 mel MFMAs) and the four
 // partial mel accumulators are summed through LDS in a fixed order.  (First version: one wave ran all four passes of
 // its tile -- 3584 dependent-issue MFMAs = 100 us of latency for a 10 s clip, whose 32 tiles occupied 8 CUs.)
-__global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict__ ypad, int n_frames,
-                                                        const float* __restrict__ dft_frag,
-                                                        const float* __restrict__ mel_frag, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float part[4 * 3 * 16 * 64];  // [wave][mel block][register][lane]
+// (NWV = 8, two waves per pass with two row blocks each, is no faster for short inputs -- the same 896 MFMAs land on each
+// SIMD of the tile's CU -- and measured slower: 37.6 against 31.1 us for a 10 s clip.)
+template <int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void logmel_kernel(const float* __restrict__ ypad, int n_frames,
+                                                                          const float* __restrict__ dft_frag,
+                                                                          const float* __restrict__ mel_frag, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float part[NWV * 3 * 16 * 64];  // [wave][mel block][register][lane]
+    constexpr int RB = 16 / NWV;  // DFT row blocks per wave
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-    const int pass = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pass = wv / (NWV / 4), rb0 = (wv % (NWV / 4)) * RB;
     const int tile = blockIdx.x;
     int f = tile * 32 + m;
     const bool valid = f < n_frames;
@@ -53,62 +68,87 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
 #pragma unroll
     for (int mb = 0; mb < 3; ++mb) macc[mb] = zero16();
     {
-        f32x16 acc[4];
+        f32x16 acc[RB];
 #pragma unroll
-        for (int rbl = 0; rbl < 4; ++rbl) acc[rbl] = zero16();
-        // DFT rows and samples of k-group G are requested TWO groups (32 MFMAs) ahead, by hand: hipcc sinks such loads down
+        for (int rbl = 0; rbl < RB; ++rbl) acc[rbl] = zero16();
+        // DFT rows and samples of k-group G are requested DEPTH groups ahead, by hand: hipcc sinks such loads down
         // to their first use (compiler finding (vi)) and each of the 50 groups then pays an L2 round trip.
-        const float* apu = dft_frag + (size_t)(pass * 4) * KG * 256;  // wave-uniform
+        const float* apu = dft_frag + (size_t)(pass * 4 + rb0) * KG * 256;  // wave-uniform
         const int voff = lane * 16;
-        f32x4 ab[3][4], xb[3];
+        // request depth in k-groups (6 instead of 2 for the two-waves-per-pass variant measured slower: 38 vs 32 us)
+        constexpr int DEPTH = 2, NSLOT = DEPTH + 1;
+        f32x4 ab[NSLOT][RB], xb[NSLOT];
         auto issue = [&](int G, int slot) {
 #pragma unroll
-            for (int rbl = 0; rbl < 4; ++rbl)
+            for (int rbl = 0; rbl < RB; ++rbl)
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ab[slot][rbl]) : "v"(voff), "s"(apu + (size_t)(rbl * KG + G) * 256));
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xb[slot]) : "v"(xp + 8 * G));
         };
-        issue(0, 0);
-        issue(1, 1);
+        // mel filter fragments of this wave's row blocks: ALL requested at once (hipcc would again pair every load with its 4
+        // MFMAs: 12-24 dependent round trips to the Infinity Cache), and for the two-waves-per-pass variant BEFORE the DFT
+        // loop -- older than its loads, so the loop's counted waits are unaffected
+        const float* mpu = mel_frag + (size_t)(pass * 3) * 4 * 2 * 256;  // wave-uniform
+        f32x4 mf[RB][3][2];
+        auto issue_mel = [&]() {
 #pragma unroll
-        for (int G = 0; G < KG; ++G) {
-            const int slot = G % 3;
-            if (G + 2 < KG) issue(G + 2, (G + 2) % 3);
-            // loads retire in order: at most the 5 x (groups issued after G) may still be in flight
-            if (G + 2 < KG)
-                asm volatile("s_waitcnt vmcnt(10)" : "+v"(ab[slot][0]), "+v"(ab[slot][1]), "+v"(ab[slot][2]), "+v"(ab[slot][3]), "+v"(xb[slot]));
-            else if (G + 1 < KG)
-                asm volatile("s_waitcnt vmcnt(5)" : "+v"(ab[slot][0]), "+v"(ab[slot][1]), "+v"(ab[slot][2]), "+v"(ab[slot][3]), "+v"(xb[slot]));
+            for (int rbl = 0; rbl < RB; ++rbl)
+#pragma unroll
+                for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp)
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(mf[rbl][mb][gp]) : "v"(voff), "s"(mpu + (size_t)((mb * 4 + rb0 + rbl) * 2 + gp) * 256));
+        };
+        if (RB != 4) issue_mel();
+#pragma unroll
+        for (int G = 0; G < DEPTH; ++G) issue(G, G);
+        static_for<0, KG>([&](auto Gc) {
+            constexpr int G = decltype(Gc)::value, slot = G % NSLOT;
+            if (G + DEPTH < KG) issue(G + DEPTH, (G + DEPTH) % NSLOT);
+            // loads retire in order: at most the (RB + 1) loads of each group requested after G may still be in flight
+            constexpr int newer = (KG - 1 - G < DEPTH ? KG - 1 - G : DEPTH) * (RB + 1);
+            if (RB == 4)
+                asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ab[slot][0]), "+v"(ab[slot][1]), "+v"(ab[slot][RB - 2]), "+v"(ab[slot][RB - 1]), "+v"(xb[slot]) : "n"(newer));
             else
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ab[slot][0]), "+v"(ab[slot][1]), "+v"(ab[slot][2]), "+v"(ab[slot][3]), "+v"(xb[slot]));
+                asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ab[slot][0]), "+v"(ab[slot][1]), "+v"(xb[slot]) : "n"(newer));
 #pragma unroll
-            for (int rbl = 0; rbl < 4; ++rbl)
+            for (int rbl = 0; rbl < RB; ++rbl)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[rbl] = SAVAD_MFMA(ab[slot][rbl][e], xb[slot][e], acc[rbl]);
-        }
+        });
+        if (RB == 4) issue_mel();  // (a wave per pass has no registers to spare across the DFT loop)
         // power spectrum, lane-local: rows 2b (re) and 2b+1 (im) are registers 2i and 2i+1
-        const float* mp = mel_frag + (size_t)(pass * 3) * 4 * 2 * 256 + lane * 4;
+        float pw[RB][8];
 #pragma unroll
-        for (int rbl = 0; rbl < 4; ++rbl) {
-            float pw[8];
+        for (int rbl = 0; rbl < RB; ++rbl)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) pw[i] = acc[rbl][2 * i] * acc[rbl][2 * i] + acc[rbl][2 * i + 1] * acc[rbl][2 * i + 1];
+            for (int i = 0; i < 8; ++i) pw[rbl][i] = acc[rbl][2 * i] * acc[rbl][2 * i] + acc[rbl][2 * i + 1] * acc[rbl][2 * i + 1];
 #pragma unroll
-            for (int mb = 0; mb < 3; ++mb)
+        for (int rbl = 0; rbl < RB; ++rbl)
 #pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    const f32x4 m4 = ld4(mp + (size_t)((mb * 4 + rbl) * 2 + gp) * 256);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) macc[mb] = SAVAD_MFMA(m4[e], pw[4 * gp + e], macc[mb]);
+            for (int mb = 0; mb < 3; ++mb) {
+                if (rbl == 0 && mb == 0) {
+                    if (RB == 4)
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mf[0][0][0]), "+v"(mf[0][0][1]), "+v"(mf[0][1][0]), "+v"(mf[0][1][1]), "+v"(mf[0][2][0]), "+v"(mf[0][2][1]),
+                                     "+v"(mf[1][0][0]), "+v"(mf[1][0][1]), "+v"(mf[1][1][0]), "+v"(mf[1][1][1]), "+v"(mf[1][2][0]), "+v"(mf[1][2][1]),
+                                     "+v"(mf[RB - 2][0][0]), "+v"(mf[RB - 2][0][1]), "+v"(mf[RB - 2][1][0]), "+v"(mf[RB - 2][1][1]), "+v"(mf[RB - 2][2][0]), "+v"(mf[RB - 2][2][1]),
+                                     "+v"(mf[RB - 1][0][0]), "+v"(mf[RB - 1][0][1]), "+v"(mf[RB - 1][1][0]), "+v"(mf[RB - 1][1][1]), "+v"(mf[RB - 1][2][0]), "+v"(mf[RB - 1][2][1]));
+                    else
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(mf[0][0][0]), "+v"(mf[0][0][1]), "+v"(mf[0][1][0]), "+v"(mf[0][1][1]), "+v"(mf[0][2][0]), "+v"(mf[0][2][1]),
+                                     "+v"(mf[1][0][0]), "+v"(mf[1][0][1]), "+v"(mf[1][1][0]), "+v"(mf[1][1][1]), "+v"(mf[1][2][0]), "+v"(mf[1][2][1]));
                 }
-        }
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) macc[mb] = SAVAD_MFMA(mf[rbl][mb][gp][e], pw[rbl][4 * gp + e], macc[mb]);
+            }
     }
 #pragma unroll
     for (int mb = 0; mb < 3; ++mb)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            st4(part + (((pass * 3 + mb) * 4 + g) * 64 + lane) * 4, f32x4{macc[mb][4 * g], macc[mb][4 * g + 1], macc[mb][4 * g + 2], macc[mb][4 * g + 3]});
+            st4(part + (((wv * 3 + mb) * 4 + g) * 64 + lane) * 4, f32x4{macc[mb][4 * g], macc[mb][4 * g + 1], macc[mb][4 * g + 2], macc[mb][4 * g + 3]});
     __syncthreads();
-    const int mb = pass;  // wave mb finishes mel block mb
+    const int mb = wv;  // wave mb finishes mel block mb
     if (mb >= 3 || !valid) return;
     float* op = out + (size_t)f * N_MELS;
 #pragma unroll
@@ -117,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void logmel_kernel(const float* __restrict_
         if (mel0 < N_MELS) {
             f32x4 t = ld4(part + (((0 * 3 + mb) * 4 + g) * 64 + lane) * 4);
 #pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) t += ld4(part + (((w2 * 3 + mb) * 4 + g) * 64 + lane) * 4);
+            for (int w2 = 1; w2 < NWV; ++w2) t += ld4(part + (((w2 * 3 + mb) * 4 + g) * 64 + lane) * 4);
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) t[s2] = logf(t[s2] + 1e-6f);
             st4(op + mel0, t);

@@ -60,20 +60,31 @@ def load_wav_mono16k(path) -> np.ndarray:
     return resample_to_16k(pcm, rate)
 
 
-@torch.no_grad()
+_HOP, _N_FFT = 160, 512  # savad_logmel.h: HOP, N_FFT (frames = 1 + n // hop; workspace = padded signal + slack)
+
+
 def log_mel(audio, device="cuda") -> torch.Tensor:
-    """audio: 1-D float32 samples @16 kHz (numpy or tensor) -> device tensor [N, 80] float32, N = 1 + len // 160."""
+    """audio: 1-D float32 samples @16 kHz (numpy or tensor) -> device tensor [N, 80] float32, N = 1 + len // 160.
+    (Host side kept thin on purpose: for a 10 s clip the two kernels take ~25 us, the Python around them used to
+    take longer.)"""
     lib = _lib.load()
-    dev = torch.device(device)
-    y = torch.as_tensor(audio, dtype=torch.float32).to(dev).contiguous()
+    dev = device if isinstance(device, torch.device) else torch.device(device)
+    y = audio if (isinstance(audio, torch.Tensor) and audio.dtype == torch.float32 and audio.device == dev and audio.is_contiguous()) \
+        else torch.as_tensor(audio, dtype=torch.float32).to(dev).contiguous()
     if y.dim() != 1 or y.numel() < 1:
         raise ValueError("audio must be a non-empty 1-D array")
+    if y.device.type != "cuda":
+        raise _lib.SavadError("the log-mel front-end runs only on a HIP device (no CPU fallback)")
     n = y.numel()
-    with torch.cuda.device(dev):
-        frames = lib.savad_logmel_frames(n)
-        ws = torch.empty(lib.savad_logmel_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        out = torch.empty((frames, 80), dtype=torch.float32, device=dev)
-        _lib.check(lib.savad_logmel(ctypes.c_void_p(y.data_ptr()), n, ctypes.c_void_p(ws.data_ptr()),
-                                    ctypes.c_void_p(out.data_ptr()),
-                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    frames = 1 + n // _HOP
+    ws_floats = n + _N_FFT + 64  # savad_logmel_workspace_bytes(n) / 4
+    idx = y.device.index if y.device.index is not None else torch.cuda.current_device()
+    if idx != torch.cuda.current_device():
+        with torch.cuda.device(idx):
+            return log_mel(y, y.device)
+    buf = torch.empty(ws_floats, dtype=torch.float32, device=y.device)
+    out = torch.empty((frames, 80), dtype=torch.float32, device=y.device)
+    _lib.check(lib.savad_logmel(ctypes.c_void_p(y.data_ptr()), n, ctypes.c_void_p(buf.data_ptr()),
+                                ctypes.c_void_p(out.data_ptr()),
+                                ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)))
     return out
