@@ -1,6 +1,6 @@
 import ctypes, os, sys
 sys.path.insert(0, os.getcwd())
-os.environ["SAVAD_LIB"] = os.path.abspath("scripts/ubench/libsavad_timing.so")
+os.environ.setdefault("SAVAD_LIB", os.path.abspath("scripts/ubench/libsavad_timing.so"))
 import numpy as np, torch
 from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
