@@ -71,7 +71,9 @@ size_t savad_param_numel(savad_handle h, int i);
 
 /* Pre-sizes the positional-encoding table (vad/modeling/transformer.py:392-397: the reference grows its cache
  * when T exceeds it) for sequences of up to T_max frames, so that savad_forward with T <= T_max neither
- * allocates nor synchronises.  May allocate and synchronise `stream` itself. */
+ * allocates nor synchronises.  May allocate and synchronise `stream` itself.  Once every parameter has been set
+ * (savad_set_param) it also folds / packs the weights for the precision selected by savad_set_precision, so that the
+ * FIRST forward after it enqueues nothing but its own kernels (HIP-graph capturable). */
 int savad_reserve(savad_handle h, int T_max, void* stream);
 
 /* Bytes of scratch savad_forward needs for a [B,T,F] batch (activations + attention partials). */

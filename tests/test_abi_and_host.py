@@ -120,7 +120,7 @@ def test_module_copies_and_pickles_drop_runtime_state(state1234):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in state1234.items()})
     m._handle = ctypes.c_void_p(1234)  # what a forward leaves behind (never dereferenced here)
     m._workspace, m._synced_versions = torch.zeros(4), m._param_versions()
-    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m)), copy.copy(m)):
         assert clone._handle is None and clone._workspace is None and clone._synced_versions is None
         assert all(torch.equal(a, b) for a, b in zip(clone.state_dict().values(), m.state_dict().values()))
         assert clone.precision == "fp32" and clone.feature_size == 80
@@ -135,7 +135,59 @@ def test_module_copies_and_pickles_drop_runtime_state(state1234):
     with torch.no_grad():
         m.classifier.bias.add_(1.0)   # ordinary in-place edits are seen
     assert m._param_versions() != m._synced_versions
+    # children follow the parent's mode even when the parent's own flag did not change
+    m.encoder.training = True
+    m.eval()
+    assert not m.encoder.training and m._synced_versions is not None
+    # nn.DataParallel replicas would SHARE the native handle (shallow __dict__ copy, no parameters): refused, clearly
+    from voice_activity_detection_amd._lib import SavadError
+    with pytest.raises(SavadError, match="DataParallel"):
+        m._replicate_for_data_parallel()
+    assert m._handle.value == 1234  # untouched
     m._handle = None  # nothing real to destroy
+
+
+def test_checkpoints_load_without_arbitrary_unpickling(tmp_path, state1234, monkeypatch):
+    """A reference-format checkpoint (tensors, containers, numpy-scalar metrics) loads with weights_only=True; a file
+    that needs arbitrary unpickling is refused unless the caller opts in (trust_checkpoint / SAVAD_TRUST_CHECKPOINT)."""
+    import numpy as np
+    import torch
+
+    from tests.conftest import write_reference_checkpoint
+    from voice_activity_detection_amd.predictor import VADFromScratchPredictor as P
+
+    monkeypatch.delenv("SAVAD_TRUST_CHECKPOINT", raising=False)
+    write_reference_checkpoint(tmp_path / "ok.checkpoint", state1234)
+    ck = P._load_checkpoint(tmp_path / "ok.checkpoint", False)
+    assert isinstance(ck["metrics"]["val_auc"], np.floating) and set(ck["state_dict"]) == set(state1234)
+    torch.save({"config": _Opaque(), "state_dict": {}}, tmp_path / "opaque.checkpoint")
+    with pytest.raises(RuntimeError, match="weights_only"):
+        P._load_checkpoint(tmp_path / "opaque.checkpoint", False)
+    assert isinstance(P._load_checkpoint(tmp_path / "opaque.checkpoint", True)["config"], _Opaque)
+    monkeypatch.setenv("SAVAD_TRUST_CHECKPOINT", "1")
+    assert isinstance(P._load_checkpoint(tmp_path / "opaque.checkpoint", False)["config"], _Opaque)
+
+
+class _Opaque:
+    """stands for a pickled config object (the reference stores an OmegaConf container)"""
+
+
+def test_no_kernel_spills():
+    """No kernel of the code object may spill VGPRs or use scratch memory (row_kernel_m did in round 2: 24 spilled
+    registers, 100 bytes of scratch).  Parsed from the code object's metadata notes (llvm-readelf --notes)."""
+    import shutil
+    import sys
+
+    if not (shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists()) or not Path("/opt/rocm/lib/llvm/bin/llvm-readelf").exists():
+        pytest.skip("no ROCm toolchain here")
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "scripts"))
+    from kernel_resources import kernel_resources
+
+    res = kernel_resources()
+    assert len(res) >= 30
+    for name, r in res.items():
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
+        assert r["vgpr_count"] + 0 <= 512, (name, r)
 
 
 def test_lds_dma_owns_m0(tmp_path):

@@ -550,10 +550,27 @@ SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* byt
 
 // Sizes everything savad_forward may otherwise have to (re)allocate for sequences of up to T_max frames -- today the
 // positional-encoding table -- so that later forwards with T <= T_max neither allocate nor synchronise.
+// Once every parameter has been set it also folds / packs the weights for the selected precision (and raises the bf16
+// kernels' LDS limits), so that even the FIRST forward after it launches nothing but its own kernels and can be captured
+// into a HIP graph.  With parameters still missing only the table is sized (the forward reports the missing key).
+namespace {
+int prepare_bf16_launch(savad_model* m);
+}
 SAVAD_EXPORT int savad_reserve(savad_handle m, int T_max, void* stream) {
     if (!m || T_max < 0) return fail(SAVAD_E_INVALID, "bad argument");
     if ((double)T_max * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "T_max=%d too large", T_max);
-    return ensure_pe(m, T_max, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure_pe(m, T_max, st))) return rc;
+    bool all_set = true;
+    for (const Param& p : m->params) all_set = all_set && p.set;
+    if (!all_set) return SAVAD_OK;
+    if ((rc = prepare_weights(m, st))) return rc;
+    if (m->precision == 1) {
+        if ((rc = prepare_frags(m, st))) return rc;
+        if ((rc = prepare_bf16_launch(m))) return rc;
+    }
+    return SAVAD_OK;
 }
 
 // bf16 precision stores the residual stream between kernels as fp16 (+-65504); every element that had to be clamped is
@@ -576,6 +593,27 @@ SAVAD_EXPORT int savad_set_precision(savad_handle m, int precision) {
 }
 
 namespace {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for every bf16 kernel, once per handle
+int prepare_bf16_launch(savad_model* m) {
+    int rc;
+    if (m->lds_attrs_set) return SAVAD_OK;
+    constexpr int r4 = bf::Ring<4>::NRING * bf::RING_BYTES, r8 = bf::Ring<8>::NRING * bf::RING_BYTES;
+    if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float, 4>, r4 + 3 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16, 4>, r4 + 3 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::attention_kernel_bf16<4>, r4))) return rc;
+    if ((rc = allow_lds(bf::row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::row_kernel_bf16<true, 4>, r4 + 9 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::attention_row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::attention_row_kernel_bf16<true, 4>, r4 + 9 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float, 8>, r8 + 3 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16, 8>, r8 + 3 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::attention_kernel_bf16<8>, r8))) return rc;
+    if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
+    m->lds_attrs_set = true;
+    return SAVAD_OK;
+}
 
 // bf16-operand forward: input_qkv -> [attention -> row] x L on fragment-major buffers
 int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, float* out, void* workspace,
@@ -612,22 +650,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     // every size tried (B=256, T=800: 0.86 vs 0.75 ms), kept as a tuning knob and covered by the tests.
     // row_mode 0 / 3 fuse attention and row chain per layer when T > 32 (plan_blocks); 1 / 2 keep them apart.
     const bool wide = m->row_mode == 2;
-    if (!m->lds_attrs_set) {
-        constexpr int r4 = bf::Ring<4>::NRING * bf::RING_BYTES, r8 = bf::Ring<8>::NRING * bf::RING_BYTES;
-        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float, 4>, r4 + 3 * D * 4))) return rc;
-        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16, 4>, r4 + 3 * D * 4))) return rc;
-        if ((rc = allow_lds(bf::attention_kernel_bf16<4>, r4))) return rc;
-        if ((rc = allow_lds(bf::row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
-        if ((rc = allow_lds(bf::row_kernel_bf16<true, 4>, r4 + 9 * D * 4))) return rc;
-        if ((rc = allow_lds(bf::attention_row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
-        if ((rc = allow_lds(bf::attention_row_kernel_bf16<true, 4>, r4 + 9 * D * 4))) return rc;
-        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float, 8>, r8 + 3 * D * 4))) return rc;
-        if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16, 8>, r8 + 3 * D * 4))) return rc;
-        if ((rc = allow_lds(bf::attention_kernel_bf16<8>, r8))) return rc;
-        if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
-        if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
-        m->lds_attrs_set = true;
-    }
+    if ((rc = prepare_bf16_launch(m))) return rc;
     Prof prof(m, st);
     auto run = [&](auto nw_tag) {
         constexpr int NW = decltype(nw_tag)::value;
@@ -1001,7 +1024,10 @@ int plan_predict(savad_model* m, int N, int half, int jump, int chunk, PredictPl
     // are ~9 % faster per window than 4096-window launches (5.27 vs 5.36 ms for 10 min of audio)
     p->windowed = m->precision == 0 && p->W <= 32 && m->cfg.num_layers <= PACKED_MAX_LAYERS && m->FP == F &&
                   (m->row_mode == 4 || (m->row_mode == 0 && p->n_items <= 1024 * (32 / p->W)));
-    p->chunk = p->windowed ? 1024 * (32 / p->W) : chunk;
+    // chunk-sized forwards write their log-probs at logp + first*W*2 floats and savad_forward wants 16-byte aligned
+    // pointers: an even chunk keeps every offset a multiple of 16 bytes whatever W is (windows are independent, so the
+    // chunking never changes a result beyond fp32 summation order)
+    p->chunk = p->windowed ? 1024 * (32 / p->W) : chunk + (chunk & 1);
     if (p->chunk > p->n_items) p->chunk = p->n_items > 0 ? p->n_items : 1;
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     size_t off = 0;

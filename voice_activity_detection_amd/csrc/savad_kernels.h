@@ -1323,16 +1323,27 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
     stage_bias(lb1, b1, DFF);
     stage_bias(lb2, b2, D);
     if (!LAST) stage_bias(lbn, bn, 3 * D);
-    // the out-projection accumulators start at the residual stream (loads issued now, consumed after phase 0)
+    // the out-projection accumulators start at the residual stream.  Without key splits the loads are issued now and
+    // consumed after phase 0; with splits they wait until the partials are combined: the combine keeps two partials
+    // (128 registers) in flight next to the 64 accumulators, and 64 more live registers made the kernel spill
+    // (24 VGPRs / 100 bytes of scratch in round 2; tests/test_abi_and_host.py::test_no_kernel_spills).
     f32x16 h1[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        h1[nb] = zero16();
-        add_block(h1[nb], hbuf + row * D + 32 * nb, h);
-    }
-    // ---- combine the attention splits: ctx = sum_s w_s O_s / sum_s w_s l_s (lane-local)
     f32x4 xg[16];
-    combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
+    auto load_residual = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            h1[nb] = zero16();
+            add_block(h1[nb], hbuf + row * D + 32 * nb, h);
+        }
+    };
+    // ---- combine the attention splits: ctx = sum_s w_s O_s / sum_s w_s l_s (lane-local)
+    if (S == 1) {
+        load_residual();
+        combine_splits(xg, Opart, ml, 1, row, rows, rows_pad, c, h);
+    } else {
+        combine_splits(xg, Opart, ml, S, row, rows, rows_pad, c, h);
+        load_residual();
+    }
     row_chain_m<LAST>(xg, h1, row, true, row < (size_t)rows, true, ring, lbo, lb1, lb2, lbn, LA, LB, Wo, W1, W2, Wn, bn, hbuf, q, k, v, out,
                       w, n, h);
 }

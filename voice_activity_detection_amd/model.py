@@ -111,8 +111,26 @@ class SelfAttentiveVAD(nn.Module):
             pass
 
     # The library handle, its device and the cached workspace are per-process runtime state: copies and pickles of
-    # the module (copy.deepcopy, torch.save(model), nn.DataParallel replicas) drop them and recreate them lazily.
+    # the module (copy.copy, copy.deepcopy, torch.save(model)) drop them and recreate them lazily -- a copy never
+    # shares (and so never double-frees) the original's native handle.
     _RUNTIME_ATTRS = ("_handle", "_handle_device", "_synced_versions", "_workspace")
+
+    def __copy__(self):
+        # explicit, so that a shallow copy never depends on which pickling protocol copy.copy() happens to use
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__dict__)
+        for name in self._RUNTIME_ATTRS:
+            new.__dict__[name] = None
+        return new
+
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel replicas are shallow __dict__ copies WITHOUT parameters (vad/training/trainer.py:115-116 is the
+        # reference's only use, in training -- out of scope): a replica would share this module's native handle, destroy
+        # it when it moves to its own device, and find no state_dict to push.  Multi-GPU inference here is one process
+        # per GPU (voice_activity_detection_amd.distributed.forward_sharded), as north_star asks.
+        raise _lib.SavadError(
+            "nn.DataParallel is not supported by the MI355X SelfAttentiveVAD: run one process per GPU and use "
+            "voice_activity_detection_amd.distributed.forward_sharded (one RCCL all_gather at the end)")
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -130,10 +148,9 @@ class SelfAttentiveVAD(nn.Module):
         # init code leaves data_ptr and _version unchanged): re-push the weights at the next forward.  A call that
         # changes nothing (the predictor's model.eval() before every batch) must cost nothing: the re-push is 54 copies
         # plus the fold / pack kernels, ~0.4 ms against a 0.09 ms forward.
-        if bool(mode) == self.training:
-            return self
-        self._synced_versions = None
-        return super().train(mode)
+        if bool(mode) != self.training:
+            self._synced_versions = None
+        return super().train(mode)  # always: children must follow the parent's mode even when it did not change
 
     def _param_versions(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -160,20 +177,42 @@ class SelfAttentiveVAD(nn.Module):
         self._synced_versions = versions
 
     # ---- forward ------------------------------------------------------------------------------
-    def forward(self, features: Tensor, out: Optional[Tensor] = None) -> Tensor:
-        """features [B, T, F] -> log-probabilities [B, T, 2] (fp32, on features.device).  `out` (optional, not in the
-        reference's signature) is a contiguous fp32 [B, T, 2] tensor to write into instead of allocating one."""
-        if features.dim() != 3 or features.size(2) != self.feature_size:
-            raise ValueError(f"features must be [B, T, {self.feature_size}], got {tuple(features.shape)}")
-        if features.device.type != "cuda":
+    def _prepare_call(self, device: torch.device):
+        """Shared entry checks of forward / predict_windows; call inside `with torch.cuda.device(device)`."""
+        if device.type != "cuda":
             raise _lib.SavadError(
                 "SelfAttentiveVAD (MI355X build) runs only on a HIP device tensor; there is no CPU fallback. "
                 "Move the model and the features to the GPU (model.to('cuda'), features.to('cuda')).")
         if self.training and self.dropout_p > 0:
             raise _lib.SavadError("training-mode dropout is outside this build's scope: call model.eval()")
-        device = features.device
         if self.precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.precision!r}")
+        pdev = self.classifier.weight.device
+        if pdev != device:
+            raise _lib.SavadError(f"model parameters are on {pdev}, features on {device}")
+        lib = _lib.load()
+        self._ensure_handle(device)
+        self.sync_weights()
+        _lib.check(lib.savad_set_attention_splits(self._handle, int(self.attention_splits)))
+        _lib.check(lib.savad_set_row_mode(self._handle, int(self.row_mode)))
+        _lib.check(lib.savad_set_precision(self._handle, 1 if self.precision == "bf16" else 0))
+        return lib
+
+    def _workspace_for(self, nbytes: int, device: torch.device) -> Tensor:
+        ws = self._workspace
+        if ws is None or ws.device != device or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)  # caching allocator owns it
+            self._workspace = ws
+        return ws
+
+    def forward(self, features: Tensor, out: Optional[Tensor] = None) -> Tensor:
+        """features [B, T, F] -> log-probabilities [B, T, 2] (fp32, on features.device).  `out` (optional, not in the
+        reference's signature) is a contiguous fp32 [B, T, 2] tensor to write into instead of allocating one."""
+        if features.dim() != 3 or features.size(2) != self.feature_size:
+            raise ValueError(f"features must be [B, T, {self.feature_size}], got {tuple(features.shape)}")
+        device = features.device
+        if device.type != "cuda" or self.precision not in ("fp32", "bf16"):
+            self._prepare_call(device)  # raises the matching error
         x = features.detach()
         x_dtype = 0
         if self.precision == "bf16" and x.dtype == torch.bfloat16:
@@ -188,22 +227,11 @@ class SelfAttentiveVAD(nn.Module):
             raise ValueError(f"out must be a contiguous float32 [{B}, {T}, 2] tensor on {device}")
         if B == 0 or T == 0:
             return out
-        lib = _lib.load()
         with torch.cuda.device(device):
-            self._ensure_handle(device)
-            first = next(self.parameters())
-            if first.device != device:
-                raise _lib.SavadError(f"model parameters are on {first.device}, features on {device}")
-            self.sync_weights()
-            _lib.check(lib.savad_set_attention_splits(self._handle, int(self.attention_splits)))
-            _lib.check(lib.savad_set_row_mode(self._handle, int(self.row_mode)))
-            _lib.check(lib.savad_set_precision(self._handle, 1 if self.precision == "bf16" else 0))
+            lib = self._prepare_call(device)
             nbytes = ctypes.c_size_t()
             _lib.check(lib.savad_workspace_bytes(self._handle, B, T, ctypes.byref(nbytes)))
-            ws = self._workspace
-            if ws is None or ws.device != device or ws.numel() < nbytes.value:
-                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)  # caching allocator owns it
-                self._workspace = ws
+            ws = self._workspace_for(nbytes.value, device)
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.savad_forward_ex(self._handle, ctypes.c_void_p(x.data_ptr()), x_dtype, B, T,
                                             ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
@@ -215,11 +243,9 @@ class SelfAttentiveVAD(nn.Module):
         """The whole of VADFromScratchPredictor.predict_probabilities (vad/predictor.py:159-262) in ONE library call
         (savad_predict_probabilities): feature [N, F] fp32 on the device -> (probs [N, W], mean [N]); the windows are
         read straight out of the feature matrix when the single-launch forward applies."""
-        if feature.device.type != "cuda":
-            raise _lib.SavadError("the MI355X predictor needs a HIP device (no CPU fallback)")
-        if self.training and self.dropout_p > 0:
-            raise _lib.SavadError("training-mode dropout is outside this build's scope: call model.eval()")
         device = feature.device
+        if device.type != "cuda":
+            self._prepare_call(device)  # raises: no CPU fallback
         feat = feature.detach().float().contiguous()
         if feat.dim() != 2 or feat.shape[1] != self.feature_size:
             raise ValueError(f"feature must be [N, {self.feature_size}], got {tuple(feat.shape)}")
@@ -231,17 +257,10 @@ class SelfAttentiveVAD(nn.Module):
         if N == 0:
             return probs, mean
         with torch.cuda.device(device):
-            self._ensure_handle(device)
-            self.sync_weights()
-            _lib.check(lib.savad_set_attention_splits(self._handle, int(self.attention_splits)))
-            _lib.check(lib.savad_set_row_mode(self._handle, int(self.row_mode)))
-            _lib.check(lib.savad_set_precision(self._handle, 1 if self.precision == "bf16" else 0))
+            self._prepare_call(device)
             nbytes = ctypes.c_size_t()
             _lib.check(lib.savad_predict_workspace_bytes(self._handle, N, int(half), int(jump), int(chunk), ctypes.byref(nbytes)))
-            ws = self._workspace
-            if ws is None or ws.device != device or ws.numel() < nbytes.value:
-                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
-                self._workspace = ws
+            ws = self._workspace_for(nbytes.value, device)
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.savad_predict_probabilities(self._handle, ctypes.c_void_p(feat.data_ptr()), N, int(half), int(jump),
                                                        int(chunk), ctypes.c_void_p(probs.data_ptr()),
@@ -249,14 +268,21 @@ class SelfAttentiveVAD(nn.Module):
                                                        ws.numel(), ctypes.c_void_p(stream)))
         return probs, mean
 
-    def reserve(self, max_frames: int, device=None):
-        """Pre-size the library's positional-encoding table for sequences of up to `max_frames` frames (savad_reserve):
-        forwards with T <= max_frames then run without any allocation or synchronisation inside the library."""
-        device = torch.device(device) if device is not None else next(self.parameters()).device
+    def reserve(self, max_frames: int, device=None, max_batch: int = 0):
+        """Everything a later forward would otherwise do once: pushes the parameters into the library, folds / packs
+        them for the selected precision, sizes the positional-encoding table for sequences of up to `max_frames` frames
+        (savad_reserve) and -- with `max_batch` -- the cached workspace for a [max_batch, max_frames, F] batch.  Forwards
+        with T <= max_frames (and B <= max_batch) then neither allocate nor synchronise nor launch anything but their own
+        kernels, so even the FIRST forward can be captured into a HIP graph."""
+        device = torch.device(device) if device is not None else self.classifier.weight.device
         with torch.cuda.device(device):
-            self._ensure_handle(device)
+            lib = self._prepare_call(device)
             stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(_lib.load().savad_reserve(self._handle, int(max_frames), ctypes.c_void_p(stream)))
+            _lib.check(lib.savad_reserve(self._handle, int(max_frames), ctypes.c_void_p(stream)))
+            if max_batch > 0 and max_frames > 0:
+                nbytes = ctypes.c_size_t()
+                _lib.check(lib.savad_workspace_bytes(self._handle, int(max_batch), int(max_frames), ctypes.byref(nbytes)))
+                self._workspace_for(nbytes.value, device)
 
     def residual_saturations(self) -> int:
         """precision "bf16" stores the residual stream as fp16 between kernels (+-65504): number of elements that had to
@@ -265,16 +291,18 @@ class SelfAttentiveVAD(nn.Module):
         if self._handle is None:
             return 0
         n = ctypes.c_ulonglong()
-        stream = torch.cuda.current_stream(self._handle_device).cuda_stream
-        _lib.check(_lib.load().savad_residual_saturations(self._handle, ctypes.byref(n), ctypes.c_void_p(stream)))
+        with torch.cuda.device(self._handle_device):
+            stream = torch.cuda.current_stream(self._handle_device).cuda_stream
+            _lib.check(_lib.load().savad_residual_saturations(self._handle, ctypes.byref(n), ctypes.c_void_p(stream)))
         return int(n.value)
 
     # ---- profiling hooks used by bench.py -------------------------------------------------------
     def set_profiling(self, capacity: int, skip: int = 0):
         """record the kernels of the next `capacity` forwards, after `skip` un-recorded ones (clocks settle)"""
-        _lib.check(_lib.load().savad_set_profiling(self._handle, int(capacity)))
-        if skip:
-            _lib.check(_lib.load().savad_profiling_skip(self._handle, int(skip)))
+        with torch.cuda.device(self._handle_device):
+            _lib.check(_lib.load().savad_set_profiling(self._handle, int(capacity)))
+            if skip:
+                _lib.check(_lib.load().savad_profiling_skip(self._handle, int(skip)))
 
     def kernel_times(self):
         """[(kernel name, average ms)] per launch position since set_profiling; sync the stream first."""

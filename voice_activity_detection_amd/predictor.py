@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 from datetime import timedelta
 from typing import Optional
@@ -77,15 +78,40 @@ class VADFromScratchPredictor:
         # 10 min of audio take 9.4 ms with 1000 against 5.1 ms with 16384
         self.chunk_size = int(chunk_size)
 
+    @staticmethod
+    def _load_checkpoint(checkpoint_path, trust: bool):
+        """torch.load restricted to tensors, containers and the numpy scalar / dtype reconstructors a reference
+        checkpoint's `metrics` dict holds (weights_only=True inside safe_globals); arbitrary pickles (e.g. a checkpoint
+        whose `config` is a pickled OmegaConf object) load only on explicit opt-in: trust=True or SAVAD_TRUST_CHECKPOINT=1."""
+        import numpy as np
+        safe = [np.dtype, np.ndarray, type(np.dtype("float64")), type(np.dtype("float32")), type(np.dtype("int64")),
+                type(np.dtype("int32")), type(np.dtype("bool"))]
+        for mod in ("numpy._core.multiarray", "numpy.core.multiarray"):
+            try:
+                m = __import__(mod, fromlist=["scalar", "_reconstruct"])
+                safe += [m.scalar, m._reconstruct]
+                break
+            except (ImportError, AttributeError):
+                continue
+        try:
+            with torch.serialization.safe_globals(safe):
+                return torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        except Exception as exc:  # pickle.UnpicklingError of an unlisted global
+            if not (trust or os.environ.get("SAVAD_TRUST_CHECKPOINT") == "1"):
+                raise RuntimeError(
+                    f"{checkpoint_path}: not loadable with weights_only=True ({str(exc).splitlines()[0]}). If you trust the "
+                    "file, pass trust_checkpoint=True / set SAVAD_TRUST_CHECKPOINT=1 to unpickle it in full "
+                    "(this can execute code embedded in the file).") from exc
+        return torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+
     @classmethod
-    def from_checkpoint(cls, checkpoint_path, device):
+    def from_checkpoint(cls, checkpoint_path, device, trust_checkpoint: bool = False):
         """vad/predictor.py:264-280: a training checkpoint holds {"config": ..., "state_dict": ...} plus what
         ModelCheckpointer adds (epoch, global_step, monitor_metric, a `metrics` dict of numpy scalars, optimizer /
         scheduler / grad-scaler state: vad/training/checkpointers/model_checkpointer.py:97-110); the model size, the
-        feature transform and the window geometry come from the config, the weights load strictly.  Like the
-        reference's plain torch.load, the file is unpickled in full (weights_only=False: numpy scalars are not on
-        torch's safe list) -- load only checkpoints you trust."""
-        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        feature transform and the window geometry come from the config, the weights load strictly.  Unlike the
+        reference's plain torch.load, the file is first read with weights_only=True (see _load_checkpoint)."""
+        ckpt = cls._load_checkpoint(checkpoint_path, trust_checkpoint)
         cfg = ckpt["config"]
 
         def get(c, *names, default=None):
