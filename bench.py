@@ -123,12 +123,57 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     return None
 
 
+def gpu_state():
+    """sclk / mclk / power / power cap of this rank's GPU from rocm-smi (None when rocm-smi is missing or slow): recorded
+    at the start and the end of every leg, so that a box-to-box or leg-to-leg clock difference is visible in the line."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--showclocks", "--showpower", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=8).stdout
+        card = json.loads(out)
+        card = card[sorted(card)[int(os.environ.get("LOCAL_RANK", "0")) % len(card)]]
+    except Exception:
+        return None
+    keep = {}
+    for k, v in card.items():
+        kl = k.lower()
+        if "sclk" in kl or "mclk" in kl or "fclk" in kl or "power" in kl:
+            keep[k.replace(" clock level", "").replace(" (W)", "_W").strip()] = v
+    return keep or None
+
+
+def rocprof_averages():
+    """{kernel short name: average ns} of the committed rocprofv3 --kernel-trace --stats run of this bench
+    (profiles/*_kernel_avg.json, written by scripts/summarize_profile.py), only when taken on the running kernel sources."""
+    want = kernel_source_hash()
+    for f in sorted((REPO / "profiles").glob("*_kernel_avg.json"), reverse=True):
+        try:
+            data = json.loads(f.read_text())
+        except Exception:
+            continue
+        if data.get("csrc_hash") == want:
+            return data.get("kernels", {}), f.name
+    return {}, None
+
+
+ROCPROF_NAMES = {  # bench launch label -> kernel short name in the rocprofv3 stats (fp32 M-split / fused regime, bf16 4-wave kernels)
+    "attention_row": "attention_row_kernel<false>", "attention_row_last": "attention_row_kernel<true>",
+    "input_qkv": "input_qkv_kernel_m", "packed_forward": "packed_forward_kernel",
+    "attention_bf16": "attention_kernel_bf16<4>", "row_bf16": "row_kernel_bf16<false, 4>", "row_last_bf16": "row_kernel_bf16<true, 4>",
+    "input_qkv_bf16": "input_qkv_kernel_bf16<__bf16, 4>",
+}
+
+
 def cpu_baseline(state, B: int, T: int, seconds: float):
     """The reference's CPU path cannot travel; time its two stand-ins on this host's cores on the SAME workload
     shape ([B, T, 80] fp32, inputs default_rng(0).uniform(-13.8, 4.2): BASELINE.md section 3): (a) the stock-PyTorch
     port (the reference's ATen ops), (b) the C oracle (OpenMP, one sequence per thread).  Each: 2 warm-ups, then
-    >= 10 passes (bounded by `seconds` per stand-in, never fewer than 3); median and min reported, the faster
-    median is `value`."""
+    passes until `seconds`/2 of them have run (never fewer than 3, never more than 30); median and min reported, the
+    faster median is `value`.  Bounded to ~`seconds` + the thread-count probe so that the GPU legs dominate the run."""
     from oracle import oracle, torch_port
 
     cores = os.cpu_count() or 1
@@ -140,16 +185,14 @@ def cpu_baseline(state, B: int, T: int, seconds: float):
         fn()
         fn()
         ts, t_start = [], time.perf_counter()
-        while len(ts) < 10 or (time.perf_counter() - t_start < budget and len(ts) < 30):
+        while len(ts) < 3 or (time.perf_counter() - t_start < budget and len(ts) < 30):
             t0 = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_start > budget and len(ts) >= 3:
-                break
         return ts
 
     # (a) stock-PyTorch port: pick the intra-op thread count with one pass each (oversubscription hurts), then time
-    cands = sorted({c for c in (8, 16, 32, 64, cores) if c <= cores})
+    cands = sorted({c for c in (8, 32, cores) if c <= cores})
     best_nt, best_t = cands[0], float("inf")
     for nt in cands:
         torch.set_num_threads(nt)
@@ -282,7 +325,7 @@ class Runner:
         return kt
 
 
-def roofline_block(ktimes, precision, B, T, ms_forward):
+def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False):
     peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
     e = 2 if precision == "bf16" else 4
     fwd_tflops = flops_per_frame(T) * B * T / (ms_forward * 1e-3) / 1e12
@@ -297,12 +340,17 @@ def roofline_block(ktimes, precision, B, T, ms_forward):
     dom_flops, dom_bytes = launch_work(dom, B, T, e)
     ach = dom_flops / (dom_ms * 1e-3) / 1e12
     per_kernel = {}
+    prof_avg, prof_file = rocprof_averages() if profiled_shape else ({}, None)
     for n, ts in by_name.items():
         fl, by = launch_work(n, B, T, e)
         ms_k = sum(ts) / len(ts)
         per_kernel[n] = {"launches": len(ts), "ms": round(ms_k, 4), "tflops": round(fl / (ms_k * 1e-3) / 1e12, 2),
                          "frac": round(fl / (ms_k * 1e-3) / 1e12 / peak, 4),
                          "hbm_frac": round(by / (ms_k * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4)}
+        ref_ns = prof_avg.get(ROCPROF_NAMES.get(n, ""))
+        if ref_ns:  # this run's HIP-event duration over the committed rocprofv3 average of the same kernel on the same sources
+            per_kernel[n]["rocprof_ms"] = round(ref_ns * 1e-6, 4)
+            per_kernel[n]["event_over_rocprof"] = round(ms_k / (ref_ns * 1e-6), 3)
     return {
         "bound": "mfma", "kernel": f"{dom} ({len(by_name[dom])} launches per forward)",
         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -315,7 +363,7 @@ def roofline_block(ktimes, precision, B, T, ms_forward):
         "hbm_frac": round(dom_bytes / (dom_ms * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4),
         "ms_per_launch": round(dom_ms, 4),
         "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / peak, 4),
-        "per_kernel": per_kernel,
+        "per_kernel": per_kernel, "rocprof_reference": prof_file,
         "kernels_ms": {f"{i}:{n}": round(t, 4) for i, (n, t) in enumerate(ktimes)},
     }
 
@@ -357,6 +405,95 @@ def clip_pipeline(state, dev, seconds, min_seconds):
             "finite": bool(torch.isfinite(probs).all().item()), "blocks": len(per_call)}
 
 
+def _event_blocks(fn, calls, min_seconds, warm=3):
+    """median / min ms per call of fn() over blocks of `calls` calls (HIP events on the current stream, >= 5 blocks and
+    >= min_seconds of timed work)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    per_call, spent = [], 0.0
+    while len(per_call) < 5 or spent < min_seconds:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(calls):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        per_call.append(ms / calls)
+        spent += ms * 1e-3
+    return statistics.median(per_call), min(per_call), len(per_call), out
+
+
+def config3_global_one_gpu(state, dev, min_seconds):
+    """BASELINE configs[3] at its stated GLOBAL size on ONE GPU: [2048, 800, 80] bf16 resident, evaluated as the eight
+    256-sequence shards the eight ranks of a node would each see (voice_activity_detection_amd.distributed.shard_bounds),
+    every shard's log-probs written into its slot of the gathered [2048, 800, 2] result -- the all_gather's layout."""
+    from voice_activity_detection_amd import SelfAttentiveVAD
+    from voice_activity_detection_amd.distributed import shard_bounds
+
+    Bg, T, world = 2048, 800, 8
+    model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(dev).eval()
+    model.precision = "bf16"
+    x = torch.empty((Bg, T, F_MEL), dtype=torch.bfloat16, device=dev)
+    for r in range(world):  # the same per-rank seeding as the N-GPU run (Runner: default_rng(rank))
+        lo, hi = shard_bounds(Bg, r, world)
+        x[lo:hi] = torch.from_numpy(np.random.default_rng(r).uniform(-13.8, 4.2, (hi - lo, T, F_MEL)).astype(np.float32)).to(dev)
+    y = torch.empty((Bg, T, 2), dtype=torch.float32, device=dev)
+    model.reserve(T, max_batch=Bg // world)
+
+    def one_pass():
+        with torch.no_grad():
+            for r in range(world):
+                lo, hi = shard_bounds(Bg, r, world)
+                model(features=x[lo:hi], out=y[lo:hi])
+        return y
+
+    med, mn, blocks, _ = _event_blocks(one_pass, 4, min_seconds)
+    with torch.no_grad():
+        whole = model(features=x)  # the global batch as ONE forward (2.1 GB workspace)
+    same = bool(torch.equal(whole, y))
+    med1, mn1, _, _ = _event_blocks(lambda: model(features=x, out=whole), 4, min_seconds / 2, warm=1)
+    frames = Bg * T
+    return {"workload": "BASELINE configs[3] global batch on ONE GPU: synthetic [B=2048, T=800, F=80] bf16, eight 256-sequence shards back to back",
+            "ms_per_pass": round(med, 4), "ms_per_pass_min": round(mn, 4), "frames_per_s": round(frames / (med * 1e-3), 1),
+            "forward_frac_of_bf16_peak": round(flops_per_frame(T) * frames / (med * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            "single_forward_ms": round(med1, 4), "single_forward_ms_min": round(mn1, 4), "single_forward_equals_sharded_bits": same,
+            "finite": bool(torch.isfinite(y).all().item()), "blocks": blocks, "unit": "frames/s"}
+
+
+def stream_one_hour(state, dev, min_seconds):
+    """BASELINE configs[4] at its full size on one GPU: 1 h of synthetic 16 kHz audio resident on the device -> log-mel
+    [360001, 80] -> 900 sliding windows T=800 hop=400 -> forward -> overlap merge -> per-frame probabilities; fp32 and
+    bf16 operands; real-time factor with and without the log-mel front-end."""
+    from voice_activity_detection_amd import SelfAttentiveVAD, StreamingPredictor
+    from voice_activity_detection_amd.features import log_mel
+
+    seconds = 3600
+    model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(dev).eval()
+    rng = np.random.default_rng(0)
+    audio = torch.from_numpy((rng.standard_normal(16000 * seconds, dtype=np.float32) * 0.1)).to(dev)
+    mel_med, mel_min, _, feat = _event_blocks(lambda: log_mel(audio, dev), 4, min_seconds / 2, warm=2)
+    N = int(feat.shape[0])
+    res = {"workload": f"BASELINE configs[4] on ONE GPU: {seconds} s of 16 kHz audio -> log-mel [{N},80] -> 900 windows T=800 hop=400 -> "
+                       "forward -> overlap merge -> probabilities", "audio_seconds": seconds, "frames": N,
+           "logmel_ms": round(mel_med, 4), "logmel_ms_min": round(mel_min, 4)}
+    for prec in ("fp32", "bf16"):
+        model.precision = prec
+        sp = StreamingPredictor(model, dev, 800, 400, max_batch=256)
+        med, mn, blocks, probs = _event_blocks(lambda: sp.predict_device(feat), 2 if prec == "fp32" else 8, min_seconds, warm=2)
+        res[prec] = {"ms_per_hour_of_audio": round(med, 4), "ms_min": round(mn, 4), "blocks": blocks,
+                     "rtf_without_logmel": round(med * 1e-3 / seconds, 10), "rtf_with_logmel": round((med + mel_med) * 1e-3 / seconds, 10),
+                     "frames_per_s": round(N / (med * 1e-3), 1), "finite": bool(torch.isfinite(probs).all().item()),
+                     "in_unit_interval": bool(((probs >= 0) & (probs <= 1)).all().item())}
+    model.precision = "fp32"
+    return res
+
+
 def workload_label(precision, B, T):
     if (precision, B, T) == ("fp32", 32, 800):
         tag = "BASELINE configs[1]"
@@ -389,10 +526,11 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = BASELINE configs[1] (default); bf16 = configs[2]: bf16 MFMA operands, bf16 features")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="timed work per measurement, in K-step blocks")
-    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP-event pass (no roofline per kernel)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / T=7 / configs[3] legs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / T=7 / configs[0] / configs[3] / configs[4] legs")
+    ap.add_argument("--legs", default="all", help="comma-separated secondary legs to run (default: all)")
     ap.add_argument("--gather", default="step", choices=["step", "final"],
                     help="multi-GPU: which gather mode `value` is quoted on (both are always measured): one all_gather per "
                          "forward (forward_sharded, default) or one all_gather of all K batches at the end of a block")
@@ -426,6 +564,7 @@ def main():
     frames_per_step = world * B * T
 
     # ---- the headline measurement
+    clocks0 = gpu_state()
     main_run.set_gather(args.gather, K)
     walls, evs, y = main_run.timed_blocks(K, args.warmup, args.min_seconds)
     head = summarize(walls, evs, K, frames_per_step)
@@ -444,42 +583,52 @@ def main():
                                 "final = each forward writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block"}
         main_run.set_gather(args.gather, K)
     ktimes = [] if args.no_events else main_run.kernel_profile(min(K, 20), head["ms_per_step"])
+    clocks1 = gpu_state()
 
     # ---- secondary legs, measured in the same run so that they are driver-witnessed
     secondary = {}
+    want = None if args.legs == "all" else set(args.legs.split(","))
+
+    def leg(key, fn):
+        """run one secondary leg; it must never take the headline line down with it"""
+        if want is not None and key not in want:
+            return
+        c0 = gpu_state()
+        try:
+            res = fn()
+        except Exception as exc:
+            res = {"error": f"{type(exc).__name__}: {exc}"}
+        res["clocks"] = {"start": c0, "end": gpu_state()}
+        secondary[key] = res
+        torch.cuda.empty_cache()
+
+    def shape_leg(prec, b2, t2, gm):
+        def run():
+            r = Runner(state, b2, t2, prec, dev, rank, world, dist, gm or "step")
+            r.set_gather(gm or "step", 20)
+            k2 = 20 if t2 > 32 else 50
+            w, e, y2 = r.timed_blocks(k2, 5, args.min_seconds)
+            s = summarize(w, e, k2, world * b2 * t2)
+            kt = [] if args.no_events else r.kernel_profile(10, s["ms_per_step"])
+            s.update({"workload": workload_label(prec, b2, t2), "global_batch": world * b2, "unit": "frames/s",
+                      "finite": bool(torch.isfinite(y2).all().item()),
+                      "roofline": roofline_block(kt, prec, b2, t2, s["ms_per_step"], profiled_shape=True)})
+            if gm:
+                s["parallelism"] = f"batch-shard x{world} + 1 RCCL all_gather of [{b2},{t2},2] f32 per forward"
+            return s
+        return run
+
     if not args.no_secondary:
-        legs = []
         if world == 1 and not use_dist:
             if (args.precision, B, T) != ("bf16", 256, 800):
-                legs.append(("configs2_bf16_b256_t800", "bf16", 256, 800, None))
+                leg("configs2_bf16_b256_t800", shape_leg("bf16", 256, 800, None))
             if (args.precision, B, T) != ("fp32", 1000, 7):
-                legs.append(("pipeline_fp32_b1000_t7", "fp32", 1000, 7, None))
+                leg("pipeline_fp32_b1000_t7", shape_leg("fp32", 1000, 7, None))
+            leg("configs0_clip10s_audio_to_probabilities", lambda: clip_pipeline(state, dev, 10.0, args.min_seconds))
+            leg("configs3_global_b2048_one_gpu", lambda: config3_global_one_gpu(state, dev, args.min_seconds))
+            leg("configs4_stream_1h", lambda: stream_one_hour(state, dev, args.min_seconds))
         else:
-            legs.append(("config3", "bf16", 256, 800, "step"))  # configs[3]: [256 x world, 800, 80] bf16, batch-sharded
-        for key, prec, b2, t2, gm in legs:
-            try:
-                r = Runner(state, b2, t2, prec, dev, rank, world, dist, gm or "step")
-                r.set_gather(gm or "step", 20)
-                k2 = 20 if t2 > 32 else 50
-                w, e, y2 = r.timed_blocks(k2, 5, args.min_seconds / 2)
-                s = summarize(w, e, k2, world * b2 * t2)
-                kt = [] if args.no_events else r.kernel_profile(10, s["ms_per_step"])
-                s.update({"workload": workload_label(prec, b2, t2), "global_batch": world * b2, "unit": "frames/s",
-                          "finite": bool(torch.isfinite(y2).all().item()),
-                          "roofline": roofline_block(kt, prec, b2, t2, s["ms_per_step"])})
-                if gm:
-                    s["parallelism"] = f"batch-shard x{world} + 1 RCCL all_gather of [{b2},{t2},2] f32 per forward"
-                secondary[key] = s
-                del r
-                torch.cuda.empty_cache()
-            except Exception as exc:  # a secondary leg must never take the headline line down with it
-                secondary[key] = {"error": f"{type(exc).__name__}: {exc}"}
-
-        if world == 1 and not use_dist:
-            try:  # configs[0] end to end on the device: 10 s of resident audio -> log-mel -> 7-frame windows -> forward -> boost
-                secondary["configs0_clip10s_audio_to_probabilities"] = clip_pipeline(state, dev, 10.0, args.min_seconds / 2)
-            except Exception as exc:
-                secondary["configs0_clip10s_audio_to_probabilities"] = {"error": f"{type(exc).__name__}: {exc}"}
+            leg("config3", shape_leg("bf16", 256, 800, "step"))  # configs[3]: [256 x world, 800, 80] bf16, batch-sharded
 
     if rank == 0:
         line = {
@@ -495,7 +644,8 @@ def main():
                        "parallelism": f"batch-shard x{world}" + ((" + 1 RCCL all_gather of the [B,T,2] log-probs per forward" if args.gather == "step"
                                                                    else " + 1 RCCL all_gather of all K batches' log-probs per block") if use_dist else "")},
             "finite": ok,
-            "roofline": roofline_block(ktimes, args.precision, B, T, head["ms_per_step"]),
+            "roofline": roofline_block(ktimes, args.precision, B, T, head["ms_per_step"], profiled_shape=True),
+            "clocks": {"start": clocks0, "end": clocks1},
         }
         if gather_modes:
             line.update(gather_modes)

@@ -77,8 +77,24 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_l2", "pmc_inst"):
                       f"{vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024):.3f}")
 
 
-# machine-readable HBM-side traffic per launch (consumed by bench.py's roofline.traffic)
+# machine-readable per-kernel average durations of the trace pass (consumed by bench.py: event_over_rocprof)
 import json
+kavg = {}
+for f in find("trace/**/*kernel_stats.csv"):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "savad" in row["Name"]:
+                kavg[short(row["Name"])] = float(row["AverageNs"])
+if kavg:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from bench import kernel_source_hash
+        with open(os.path.join(out, "kernel_avg.json"), "w") as fh:
+            json.dump({"csrc_hash": kernel_source_hash(), "kernels": kavg}, fh, indent=1, sort_keys=True)
+    except Exception as exc:  # noqa: BLE001
+        print("could not write kernel_avg.json:", exc)
+
+# machine-readable HBM-side traffic per launch (consumed by bench.py's roofline.traffic)
 traffic = {}
 for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for f in find(f"{sub}/**/*counter_collection.csv"):

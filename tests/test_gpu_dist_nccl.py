@@ -128,3 +128,41 @@ def test_streaming_predictor_sharded_branch_through_rccl(torch_cuda, model, stat
     assert torch.equal(plain, sharded)
     ref, _ = oracle.predict_streaming(state1234, feat, T=96, hop=48)
     assert np.abs(sharded.cpu().numpy() - ref).max() < (1e-4 if precision == "fp32" else 2e-2)
+
+
+def test_config3_global_batch_on_one_gpu(torch_cuda, model, state1234, rccl):
+    """BASELINE configs[3] at its STATED size: the global [2048, 800, 80] bf16 batch on one MI355X, pushed through
+    distributed.forward_sharded with a live RCCL group in the eight 256-sequence shards the eight ranks of a node would
+    see (shard_bounds).  Every shard must equal the unsharded forward of the same rows bit for bit, the global batch
+    as ONE forward must equal the concatenated shards bit for bit, and sampled sequences must match the oracle."""
+    from oracle import oracle
+    from voice_activity_detection_amd.distributed import forward_sharded, shard_bounds
+
+    torch = torch_cuda
+    Bg, T, world = 2048, 800, 8
+    x = feats(2048, (Bg, T, 80))
+    xd = torch.from_numpy(x).cuda().to(torch.bfloat16)
+    model.precision = "bf16"
+    try:
+        def fwd(t):
+            with torch.no_grad():
+                return model(features=t)
+
+        y = torch.empty((Bg, T, 2), dtype=torch.float32, device="cuda")
+        for r in range(world):
+            lo, hi = shard_bounds(Bg, r, world)
+            assert hi - lo == 256
+            got = forward_sharded(fwd, xd[lo:hi])          # rank r's call: its shard -> forward -> one all_gather
+            assert got.shape == (256, T, 2) and torch.equal(got, fwd(xd[lo:hi]))
+            y[lo:hi] = got
+        whole = fwd(xd)                                     # 1.64 M rows, ~2.1 GB workspace: one MI355X holds the global batch
+        torch.cuda.synchronize()
+        assert torch.equal(whole, y)
+        assert model.residual_saturations() == 0
+    finally:
+        model.precision = "fp32"
+    yh = y.cpu().numpy()
+    assert np.isfinite(yh).all() and np.abs(np.logaddexp(yh[..., 0], yh[..., 1])).max() < 1e-5
+    pick = [0, 255, 256, 1000, 1791, 2047]                  # first / last sequence of shards 0, 1, 3, 6, 7
+    xin = xd[pick].float().cpu().numpy()                    # the oracle sees the same bf16-rounded features
+    assert np.abs(yh[pick] - oracle.forward(state1234, xin)).max() < 2e-2  # BF16_TOL of tests/test_gpu_parity.py

@@ -369,6 +369,52 @@ def test_reserve_makes_forward_capturable(torch_cuda, state1234):
     assert np.abs(out.cpu().numpy() - oracle.forward(state1234, x)).max() < TIGHT
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_reserve_makes_the_first_forward_capturable(torch_cuda, state1234, precision):
+    """model.reserve(T, max_batch=B) pushes and packs the weights, sizes the PE table and the workspace: the module's
+    VERY FIRST forward is captured into a HIP graph (nothing but its own kernels may be enqueued: a weight push or a
+    fold / pack launch would be baked into the graph, an allocation or a synchronisation would fail the capture)."""
+    torch = torch_cuda
+    m = make_model(torch, state1234)
+    m.precision = precision
+    x = feats(78, (3, 300, 80))
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((3, 300, 2), dtype=torch.float32, device="cuda")
+    m.reserve(300, max_batch=3)
+    torch.cuda.synchronize()
+    versions = m._synced_versions
+    assert versions is not None
+    with torch.no_grad():
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            m(features=xd, out=out)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert m._synced_versions is versions  # no re-push happened inside the capture
+        ref = make_model(torch, state1234)
+        ref.precision = precision
+        assert torch.equal(out, ref(features=xd))
+
+
+def test_odd_chunk_sizes(torch_cuda, model):
+    """Any positive chunk_size is accepted (the reference's is 1000): an odd chunk with an odd window count used to hand
+    savad_forward an 8-mod-16 output pointer for the second chunk (bf16 precision, or fp32 clips beyond 4096 windows)."""
+    from voice_activity_detection_amd import VADFromScratchPredictor
+
+    torch = torch_cuda
+    for precision, n in (("bf16", 2100), ("fp32", 5001)):
+        model.precision = precision
+        try:
+            feat = torch.from_numpy(feats(4000 + n, (n, 80))).cuda()
+            p1, m1 = VADFromScratchPredictor(model, "cuda", chunk_size=1001).predict_probabilities_device(feat)
+            p0, m0 = VADFromScratchPredictor(model, "cuda", chunk_size=16384).predict_probabilities_device(feat)
+            torch.cuda.synchronize()
+            assert float((p1 - p0).abs().max()) < (2e-6 if precision == "fp32" else 1e-2) and float((m1 - m0).abs().max()) < 1e-2
+        finally:
+            model.precision = "fp32"
+
+
 def test_weight_update_is_seen(torch_cuda, state1234):
     from oracle import oracle
     from voice_activity_detection_amd.seeded import seeded_state_dict
@@ -870,3 +916,42 @@ def test_config3_size_batch(torch_cuda, model, state1234):
     x2 = x.copy()
     x2[200] = x[3]
     assert np.array_equal(run(torch_cuda, model, x2)[200], y[3])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config4_one_hour_stream_full_size(torch_cuda, model, state1234, precision):
+    """BASELINE configs[4] at its FULL size on one GPU: 1 h of audio = 360 001 frames -> 900 windows (T=800, hop=400,
+    zero-padded tail) -> per-frame probabilities.  Size-independent properties on the whole hour, and three stretches
+    (head, middle, zero-padded tail) against the oracle's own streaming mode run on the matching feature slices."""
+    from oracle import oracle
+    from voice_activity_detection_amd import StreamingPredictor
+
+    torch = torch_cuda
+    N, T, hop = 360001, 800, 400
+    feat = feats(3600, (N, 80))
+    fd = torch.from_numpy(feat).cuda()
+    model.precision = precision
+    try:
+        sp = StreamingPredictor(model, "cuda", T, hop, max_batch=256)
+        p = sp.predict_device(fd)
+        p2 = sp.predict_device(fd)
+        torch.cuda.synchronize()
+        assert torch.equal(p, p2)  # deterministic
+        other = StreamingPredictor(model, "cuda", T, hop, max_batch=225).predict_device(fd)  # 900 = 4 x 225: other chunking
+        assert torch.equal(other, p)  # a window's result does not depend on its batch slot or on the chunking
+    finally:
+        model.precision = "fp32"
+    ph = p.cpu().numpy()
+    assert ph.shape == (N,) and np.isfinite(ph).all() and ph.min() >= 0.0 and ph.max() <= 1.0
+    tol = TIGHT if precision == "fp32" else 1e-2
+    # head: frames [0, 1600) of the slice feat[0:2000] see the same windows as in the full hour
+    ref, _ = oracle.predict_streaming(state1234, feat[:2000], T, hop)
+    assert np.abs(ph[:1600] - ref[:1600]).max() < tol
+    # middle: windows 450..453 (slice starts on a hop boundary); local frames [400, 1600) have their global coverage
+    a = 450 * hop
+    ref, _ = oracle.predict_streaming(state1234, feat[a:a + 2000], T, hop)
+    assert np.abs(ph[a + 400:a + 1600] - ref[400:1600]).max() < tol
+    # tail: windows 896..899, the last one zero-padded past frame 360 000
+    a = 896 * hop
+    ref, _ = oracle.predict_streaming(state1234, feat[a:], T, hop)
+    assert ref.shape == (N - a,) and np.abs(ph[a + 400:] - ref[400:]).max() < tol
