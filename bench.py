@@ -23,6 +23,7 @@ import argparse
 import hashlib
 import json
 import os
+import re
 import statistics
 import sys
 import time
@@ -139,10 +140,15 @@ def gpu_state():
     except Exception:
         return None
     keep = {}
-    for k, v in card.items():
+    for k, v in card.items():  # e.g. "sclk clock speed:": "(2163Mhz)", "Current Socket Graphics Package Power (W)": "831.0"
         kl = k.lower()
-        if "sclk" in kl or "mclk" in kl or "fclk" in kl or "power" in kl:
-            keep[k.replace(" clock level", "").replace(" (W)", "_W").strip()] = v
+        m = re.search(r"([0-9.]+)", str(v))
+        if not m:
+            continue
+        if "clock speed" in kl:
+            keep[kl.split()[0] + "_mhz"] = int(float(m.group(1)))
+        elif "power" in kl:
+            keep[("power_cap_w" if "max" in kl else "power_w")] = float(m.group(1))
     return keep or None
 
 
