@@ -3,6 +3,7 @@
 //   input_qkv -> [attention(l) -> row(l)] x L      (row(L-1) ends in classifier + log-softmax)
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
+#include "savad_attn_pw_bf16.h"
 #ifdef SAVAD_ATTN2  // experiment builds only (scripts/ubench/attention2): -DSAVAD_ATTN2='"<header>"' adds bf16 row_mode 6
 #include SAVAD_ATTN2
 #endif
@@ -531,7 +532,7 @@ SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
         return SAVAD_OK;
     }
 #endif
-    if (!m || mode < 0 || mode > 4) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 5) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -611,6 +612,7 @@ int prepare_bf16_launch(savad_model* m) {
     if ((rc = allow_lds(bf::attention_kernel_bf16<8>, r8))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::attention_pw_kernel_bf16, bf::PW_LDS_BYTES))) return rc;
     m->lds_attrs_set = true;
     return SAVAD_OK;
 }
@@ -721,6 +723,8 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
                 hipLaunchKernelGGL(bf::attention2_kernel_bf16, dim3(8 * (((long)B * NG + 7) / 8)), dim3(256), bf::A2_NRING * bf::A2_STAGE_BYTES, st,
                                    qf, kf, vtf, ctxf, B, T, NG);
 #endif
+            } else if (m->row_mode == 5) {  // persistent 4 x 64-row attention (savad_attn_pw_bf16.h)
+                hipLaunchKernelGGL(bf::attention_pw_kernel_bf16, dim3(bf::PW_GRID), dim3(256), bf::PW_LDS_BYTES, st, qf, kf, vtf, ctxf, B, T);
             } else {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
                 hipLaunchKernelGGL((bf::attention_kernel_bf16<NW>), dim3(8 * (((long)B * NG + 7) / 8)), wg, ring, st, qf, kf, vtf, ctxf, B,
