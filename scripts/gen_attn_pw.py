@@ -34,6 +34,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / "voice_activity_detection_amd" / "csrc" / "savad_attn_pw_bf16.inc"
+OUT_TIMING = ROOT / "voice_activity_detection_amd" / "csrc" / "savad_attn_pw_bf16_timing.inc"
 OUT_CLOB = ROOT / "voice_activity_detection_amd" / "csrc" / "savad_attn_pw_bf16_clobbers.inc"
 
 # ---------------------------------------------------------------------------------------------- register map
@@ -49,10 +50,12 @@ V_L = {"A": 144, "B": 145}     # this lane's half of the running row sums
 V_RS = {"A": 146, "B": 147}    # row sum of the current tile
 V_MX = {"A": 148, "B": 149}    # row maxima
 V_T0, V_T1, V_T2, V_T3, V_T4, V_T5 = 150, 151, 152, 153, 154, 155
-V_OFF = [158, 159, 160, 161]   # lane * 16 + k * 4096 (DMA / Q / ctx offsets); V_OFF[0] = lane * 16
+V_LDSL = 156                   # LDS base + lane * 16
+V_ADDR_VT = 157                # tail items: V_ADDR_V + w * 2048 (this wave's feature block of the V^T fragments)
+V_OFF = [158, 159]             # lane * 16, lane * 16 + 4096 (global offsets of Q loads / ctx stores / DMA pieces)
 V_LANE16 = V_OFF[0]
 V_ADDR_V = 162                 # LDS address of the compute stage: slot base + lane * 16
-V_ADDR_K = 163                 # LDS address of the NEXT stage
+V_ADDR_K = 163                 # LDS address of the stage behind it
 V_H4 = 164                     # 4 * (lane >> 5)
 V_M = 165                      # lane & 31
 V_LIM = 166                    # key limit of a ragged tile for this lane
@@ -60,46 +63,54 @@ V_INV = {"A": 167, "B": 168}
 V_D = 169                      # cold path: reference shift
 V_AL = 170                     # cold path: rescale factor
 V_NEGB = 171                   # -1e30 (masked keys)
+V_ACC = 172                    # timing builds: lane c = cycles of category c, lane 31 = previous stamp
 V_QS = 176                     # Q staging for the next item: 16 fragments x 4 = v[176:239]
 V_CTX = {"A": 32, "B": 96}     # packed context of the finished item (32 registers each): registers dead at a seam
-S_RET = 24                     # s[24:25] return address of the cold-path subroutines
+S_RET = 24                     # s[24:25]: return address of the out-of-line subroutines (they never nest)
+S_SEQBLK, S_NSEQBLK = 26, 27   # first block (block space) of the current / next item's sequence
+S_VALID = {"A": 28, "B": 29}   # rows of block A / B that exist (T - 32 qb)
+S_NFLAGS, S_NQA = 30, 31       # the NEXT item (the compute cursor is advanced at the start of an item)
+S_RAGODD, S_RAGEVEN = 34, 35   # T % 32 when QB is odd / even, else 0
 S_QF, S_KF, S_VTF, S_CTXF = 36, 38, 40, 42
-S_B, S_T, S_QB, S_NST, S_NGF, S_TAILQ = 44, 45, 46, 47, 48, 49
+S_RAG, S_T, S_QB, S_NST, S_NGF, S_TAILQ = 44, 45, 46, 47, 48, 49
 S_XCD, S_J, S_BX, S_STRIDE, S_DQ, S_DR = 50, 51, 52, 53, 54, 55
 S_W, S_LDS = 56, 57
-S_C16, S_CM16, S_NEGBIG = 58, 59, 60
+S_QA = 60                      # first query block of the wave in this item
 S_CC = 61                      # compute cursor [phase, bi, g, valid]: s[61:64]
 S_DC = 65                      # dma cursor: s[65:68]
-S_DS = 69                      # dma: stage within its item
-S_DKS, S_DVS = 70, 72          # dma: K / V^T source of the stage being filled (64 bit each, this wave's KiB)
-S_DLDS = 74                    # dma: LDS byte address of the stage being filled (+ w KiB)
+S_DS = 69                      # dma: stage (within its item) that is issued next
+S_DKS, S_DVS = 70, 72          # dma: K / V^T source of that stage (64 bit each, + this wave's 4 KiB)
+S_DLDS = 74                    # dma: LDS byte address it goes to (+ this wave's 4 KiB)
 S_DSTREAM = 75                 # dma: stream stage counter
-S_CSTREAM = 76                 # compute: stream stage counter
-S_STEP = 77                    # compute: key block index of the next step
-S_QSRC = 78                    # s[78:79]: Q fragments of block A of the NEXT item; s[80:81]: of block B
-S_QSRCB = 80
-S_CDST = 82                    # s[82:83]: ctx destination of block A of the finished item; s[84:85] block B
-S_CDSTB = 84
-S_FLAGS = 86                   # current item: bit 0 wave active, bit 1 block B live
-S_PEND = 87                    # finished item waiting for its stores: bit 0 block A, bit 1 block B
-S_QPEND = 88                   # 1: Q of the next item still has to be requested
+S_KS = 76                      # LDS byte offset of the stage behind the compute stage (K reads)
+S_CNT = 77                     # 'mid' stages left in the item
+S_QSRC, S_QSRCB = 78, 80       # 64 bit each: Q fragments of blocks A / B of the NEXT item
+S_CDST, S_CDSTB = 82, 84       # 64 bit each: ctx destination of blocks A / B of the finished item
+S_FLAGS = 86                   # current item: bit 0 wave has a block, bit 1 it has two, bit 2 feature-split tail item
+S_PEND = 87                    # finished item waiting for its stores: bits as S_FLAGS
+S_QPEND = 88                   # 1: the once-per-item block (stores, Q request) still has to run behind a barrier
 S_T0, S_T1, S_T2, S_T3, S_T4, S_T5 = 89, 90, 91, 94, 92, 93   # s[S_T4:S_T5] is used as a 64-bit pair
-S_FORCE = 96                   # s[96:97]: all ones when tile i+1 must take the cold path (ragged last key block)
-S_QA = 98                      # first live query block of the wave (index within the sequence)
-S_RAG = 99                     # T & 31
-S_VALID = {"A": 28, "B": 29}   # rows of block A / B that exist (T - 32 qb), for the store mask
-S_NFLAGS = 30                  # flags of the NEXT item (compute cursor is advanced early)
-S_NQA = 31
-S_SEQBLK = 26                  # first block of the current item's sequence (block space)
-S_NSEQBLK = 27
+S_LDSW = 95                    # LDS base + w * 4096
+S_FE, S_FO = 96, 98            # 64 bit each: all ones when the tile checked at the end of an even / odd step must take the
+                               # cold path (ragged last key block)
+S_TM = 58                      # timing builds: s[58:59]
+TIMING = False
+PAD = 0              # experiments: s_nop 0 instructions in front (shifts the stream by 4 bytes each)
+COUNT_ONLY = False   # timing builds: only the cold-path call counters, no stamps
+SPLIT_MAX = 2   # tail groups of up to this many query blocks are feature-split items (experiments: 0, 1)
+ABLATE = 0   # experiments (results WRONG): 1 no DMA pieces, 2 no barrier, 4 no row maxima / reference check, 8 no exp / sum / pack,
+             # 16 no LDS operand reads
 
 NEG_BIG_BITS = 0xF149F2CA      # -1.0e30f
 BLK, FRAG, STAGE, NRING = 8192, 1024, 32768, 4
+DUMP = NRING * STAGE           # LDS offset of the stage nobody reads: once the stream is exhausted the DMA keeps its
+                               # cadence (8 pieces per stage, so every vmcnt(8) keeps its meaning) and lands there
 
 
 class Asm:
     def __init__(self):
         self.lines = []
+        self.tail = []   # out-of-line blocks, appended behind the main stream
         self.n = 0
 
     def i(self, text):
@@ -115,6 +126,14 @@ class Asm:
         self.n += 1
         return f".Lpw_{stem}_{self.n}"
 
+    def ool_call(self, target):
+        """a not-taken-in-the-common-case branch on SCC == 1 to an out-of-line stub that calls subroutine `target`
+        (return address in S_RET) and comes back behind the branch"""
+        stub, back = self.uniq("stub"), self.uniq("back")
+        self.i(f"s_cbranch_scc1 {stub}")
+        self.label(back)
+        self.tail += [stub + ":", f"\ts_call_b64 {sr(S_RET, 2)}, {target}", f"\ts_branch {back}"]
+
 
 def vr(b, n=1):
     return f"v{b}" if n == 1 else f"v[{b}:{b + n - 1}]"
@@ -126,6 +145,20 @@ def ar(b, n=1):
 
 def sr(b, n=1):
     return f"s{b}" if n == 1 else f"s[{b}:{b + n - 1}]"
+
+
+def stamp(a, cat):
+    """timing builds: cycles since the previous stamp are added to category `cat` (SCC is clobbered; LDS reads drained)"""
+    if not TIMING or COUNT_ONLY:
+        return
+    a.i(f"s_memtime {sr(S_TM, 2)}")
+    a.i("s_waitcnt lgkmcnt(0)")
+    a.i(f"v_readlane_b32 {sr(S_TM + 1)}, {vr(V_ACC)}, 31")
+    a.i(f"s_sub_u32 {sr(S_TM + 1)}, {sr(S_TM)}, {sr(S_TM + 1)}")
+    a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 31")
+    a.i(f"v_readlane_b32 {sr(S_TM)}, {vr(V_ACC)}, {cat}")
+    a.i(f"s_add_u32 {sr(S_TM)}, {sr(S_TM)}, {sr(S_TM + 1)}")
+    a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, {cat}")
 
 
 # ------------------------------------------------------------------------------------------------ building blocks
@@ -255,12 +288,26 @@ def emit_block_addr(a, dst, base, blk_s, tmp_hi, tmp_lo):
     a.i(f"s_addc_u32 {sr(dst + 1)}, {sr(base + 1)}, {sr(tmp_hi)}")
 
 
+# ------------------------------------------------------------------------------------------------ DMA stream
+def dma_half_ops(half):
+    """this wave's 4 KiB of one half stage (0: K, 1: V^T): one M0 write, four pieces told apart by the immediate offset
+    (it moves the global source AND the LDS destination: scripts/ubench/dma_issue.hip) -> [m0 write, piece x 4]"""
+    src = S_DKS if half == 0 else S_DVS
+    m0 = f"s_mov_b32 m0, {sr(S_DLDS)}" if half == 0 else f"s_add_u32 m0, {sr(S_DLDS)}, 16384"
+    return [m0, "s_nop 0"] + [f"global_load_lds_dwordx4 {vr(V_OFF[0])}, {sr(src, 2)} offset:{k * FRAG}" for k in range(4)]
+
+
+def emit_dma_half(a, half):
+    for op in dma_half_ops(half):
+        a.i(op)
+
+
 def emit_dma_item_setup(a):
-    """K / V^T source of stage 0 of the DMA cursor's item (+ this wave's KiB)"""
+    """K / V^T source of stage 0 of the DMA cursor's item (+ this wave's 4 KiB)"""
     emit_seq_block(a, S_DC, S_T0)
     emit_block_addr(a, S_DKS, S_KF, S_T0, S_T2, S_T1)
     emit_block_addr(a, S_DVS, S_VTF, S_T0, S_T2, S_T1)
-    a.i(f"s_lshl_b32 {sr(S_T1)}, {sr(S_W)}, 10")
+    a.i(f"s_lshl_b32 {sr(S_T1)}, {sr(S_W)}, 12")
     a.i(f"s_add_u32 {sr(S_DKS)}, {sr(S_DKS)}, {sr(S_T1)}")
     a.i(f"s_addc_u32 {sr(S_DKS + 1)}, {sr(S_DKS + 1)}, 0")
     a.i(f"s_add_u32 {sr(S_DVS)}, {sr(S_DVS)}, {sr(S_T1)}")
@@ -268,59 +315,80 @@ def emit_dma_item_setup(a):
     a.i(f"s_mov_b32 {sr(S_DS)}, 0")
 
 
-def emit_dma_lds(a):
-    """S_DLDS = LDS base + (stream stage & 3) * 32 KiB + w KiB"""
-    a.i(f"s_and_b32 {sr(S_T0)}, {sr(S_DSTREAM)}, {NRING - 1}")
-    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_T0)}, 15")
-    a.i(f"s_lshl_b32 {sr(S_T1)}, {sr(S_W)}, 10")
-    a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_T0)}, {sr(S_T1)}")
-    a.i(f"s_add_u32 {sr(S_DLDS)}, {sr(S_LDS)}, {sr(S_T0)}")
+def dma_slot_ops():
+    """the next stage of the stream goes to the next ring slot"""
+    return [f"s_add_u32 {sr(S_DSTREAM)}, {sr(S_DSTREAM)}, 1", f"s_and_b32 {sr(S_T0)}, {sr(S_DSTREAM)}, {NRING - 1}",
+            f"s_lshl_b32 {sr(S_T0)}, {sr(S_T0)}, 15", f"s_add_u32 {sr(S_DLDS)}, {sr(S_LDSW)}, {sr(S_T0)}"]
 
 
 def emit_dma_advance(a):
-    """after the 8 pieces of a stage have been issued: next stage of the item, or stage 0 of the next item"""
-    l_next, l_end = a.uniq("dnext"), a.uniq("dend")
-    a.i(f"s_add_u32 {sr(S_DSTREAM)}, {sr(S_DSTREAM)}, 1")
-    emit_dma_lds(a)
+    """after both halves of a stage have been issued: the common case (next stage of the same item) in line, the switch
+    to the next item (or to the dump slot once the stream is exhausted) out of line"""
+    stub, back = a.uniq("dstub"), a.uniq("dback")
     a.i(f"s_add_u32 {sr(S_DS)}, {sr(S_DS)}, 1")
-    a.i(f"s_cmp_lt_u32 {sr(S_DS)}, {sr(S_NST)}")
-    a.i(f"s_cbranch_scc0 {l_next}")
+    a.i(f"s_cmp_ge_u32 {sr(S_DS)}, {sr(S_NST)}")
+    a.i(f"s_cbranch_scc1 {stub}")
     a.i(f"s_add_u32 {sr(S_DKS)}, {sr(S_DKS)}, {2 * BLK}")
     a.i(f"s_addc_u32 {sr(S_DKS + 1)}, {sr(S_DKS + 1)}, 0")
     a.i(f"s_add_u32 {sr(S_DVS)}, {sr(S_DVS)}, {2 * BLK}")
     a.i(f"s_addc_u32 {sr(S_DVS + 1)}, {sr(S_DVS + 1)}, 0")
-    a.i(f"s_branch {l_end}")
-    a.label(l_next)
+    for op in dma_slot_ops():
+        a.i(op)
+    a.label(back)
+    a.tail += [stub + ":", f"\ts_call_b64 {sr(S_RET, 2)}, .Lpw_dma_next_item", f"\ts_branch {back}"]
+
+
+def emit_dma_next_item_sub(a):
+    a.label(".Lpw_dma_next_item")
+    l_dump = a.uniq("dump")
+    a.i(f"s_cmp_eq_u32 {sr(S_DC + 3)}, 0")
+    a.i(f"s_cbranch_scc1 {l_dump}")
     emit_cursor_next(a, S_DC, "d")
     a.i(f"s_cmp_eq_u32 {sr(S_DC + 3)}, 0")
-    a.i(f"s_cbranch_scc1 {l_end}")
+    a.i(f"s_cbranch_scc1 {l_dump}")
     emit_dma_item_setup(a)
-    a.label(l_end)
+    for op in dma_slot_ops():
+        a.i(op)
+    a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
+    a.label(l_dump)   # stream exhausted: same cadence, harmless destination, last valid sources
+    a.i(f"s_add_u32 {sr(S_DLDS)}, {sr(S_LDSW)}, {DUMP}")
+    a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
 
 
+# ------------------------------------------------------------------------------------------------ items
 def emit_item_params(a, c, flags, qa, seqblk):
-    """item of cursor c -> flags (bit 0: wave has a query block, bit 1: it has two), qa = first query block of the
-    wave, seqblk = first block of the sequence"""
+    """item of cursor c -> flags (bit 0: wave has a query block, bit 1: it has two, bit 2: feature-split tail item),
+    qa = first query block of the wave, seqblk = first block of the sequence.
+    A tail group of one or two query blocks is a FEATURE-SPLIT item: every wave takes the same block(s), computes the
+    scores and the softmax redundantly, and owns one of the four 32-feature blocks of the context."""
+    l_split, l_end = a.uniq("ipsplit"), a.uniq("ipend")
     emit_seq_block(a, c, seqblk)
     a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(c + 2)}, 3")          # first query block of the group
     a.i(f"s_sub_u32 {sr(S_T1)}, {sr(S_QB)}, {sr(S_T0)}")   # query blocks left in the sequence
     a.i(f"s_min_u32 {sr(S_T1)}, {sr(S_T1)}, 8")
+    a.i(f"s_cmp_le_u32 {sr(S_T1)}, {SPLIT_MAX}")
+    a.i(f"s_cbranch_scc1 {l_split}")
     a.i(f"s_lshl_b32 {sr(S_T2)}, {sr(S_W)}, 1")
     a.i(f"s_add_u32 {sr(qa)}, {sr(S_T0)}, {sr(S_T2)}")
     a.i(f"s_sub_i32 {sr(S_T1)}, {sr(S_T1)}, {sr(S_T2)}")   # live blocks of this wave (may be <= 0)
     a.i(f"s_max_i32 {sr(S_T1)}, {sr(S_T1)}, 0")
     a.i(f"s_min_i32 {sr(S_T1)}, {sr(S_T1)}, 2")
-    a.i(f"s_mov_b32 {sr(flags)}, 0")
     a.i(f"s_cmp_ge_u32 {sr(S_T1)}, 1")
     a.i(f"s_cselect_b32 {sr(flags)}, 1, 0")
     a.i(f"s_cmp_ge_u32 {sr(S_T1)}, 2")
     a.i(f"s_cselect_b32 {sr(S_T2)}, 2, 0")
     a.i(f"s_or_b32 {sr(flags)}, {sr(flags)}, {sr(S_T2)}")
+    a.i(f"s_branch {l_end}")
+    a.label(l_split)
+    a.i(f"s_mov_b32 {sr(qa)}, {sr(S_T0)}")
+    a.i(f"s_cmp_ge_u32 {sr(S_T1)}, 2")
+    a.i(f"s_cselect_b32 {sr(flags)}, 7, 5")
+    a.label(l_end)
 
 
 def emit_q_request(a):
     """request the NEXT item's Q fragments into the staging registers (S_NFLAGS / S_NQA / S_NSEQBLK describe it)"""
-    l_skip, l_b = a.uniq("qskip"), a.uniq("qb")
+    l_skip = a.uniq("qskip")
     a.i(f"s_bitcmp1_b32 {sr(S_NFLAGS)}, 0")
     a.i(f"s_cbranch_scc0 {l_skip}")
     a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_NSEQBLK)}, {sr(S_NQA)}")
@@ -329,7 +397,6 @@ def emit_q_request(a):
     a.i(f"s_cselect_b32 {sr(S_T0)}, 1, 0")                 # block B = A + 1 when it exists, else A again
     a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_T3)}, {sr(S_T0)}")
     emit_block_addr(a, S_QSRCB, S_QF, S_T3, S_T2, S_T1)
-    a.i("s_nop 4")
     for blk, src in (("A", S_QSRC), ("B", S_QSRCB)):
         for f in range(8):
             dst = V_QS + (0 if blk == "A" else 32) + 4 * f
@@ -338,7 +405,11 @@ def emit_q_request(a):
 
 
 def emit_ctx_stores(a):
-    """stores of the finished item's packed context (S_PEND bits), 8 x 1 KiB per block"""
+    """stores of the finished item's packed context (S_PEND: S_FLAGS of that item).  Ordinary item: 8 fragments per
+    block; feature-split item: this wave's two fragments (feature block w) per block, packed at the front."""
+    l_split, l_end = a.uniq("stsplit"), a.uniq("stend")
+    a.i(f"s_bitcmp1_b32 {sr(S_PEND)}, 2")
+    a.i(f"s_cbranch_scc1 {l_split}")
     for blk, bit, dst in (("A", 0, S_CDST), ("B", 1, S_CDSTB)):
         l_skip = a.uniq("stskip")
         a.i(f"s_bitcmp1_b32 {sr(S_PEND)}, {bit}")
@@ -346,189 +417,232 @@ def emit_ctx_stores(a):
         for f in range(8):
             a.i(f"global_store_dwordx4 {vr(V_OFF[f // 4])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{(f % 4) * FRAG}")
         a.label(l_skip)
+    a.i(f"s_branch {l_end}")
+    a.label(l_split)   # S_CDST / S_CDSTB already point at fragment 2w of the block
+    for blk, bit, dst in (("A", 0, S_CDST), ("B", 1, S_CDSTB)):
+        l_skip = a.uniq("stskip")
+        a.i(f"s_bitcmp1_b32 {sr(S_PEND)}, {bit}")
+        a.i(f"s_cbranch_scc0 {l_skip}")
+        for f in range(2):
+            a.i(f"global_store_dwordx4 {vr(V_OFF[0])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{f * FRAG}")
+        a.label(l_skip)
+    a.label(l_end)
     a.i(f"s_mov_b32 {sr(S_PEND)}, 0")
 
 
-def emit_stage_addrs(a):
-    """LDS addresses of the compute stage (V_ADDR_V) and of the one behind it (V_ADDR_K)"""
-    a.i(f"s_and_b32 {sr(S_T0)}, {sr(S_CSTREAM)}, {NRING - 1}")
-    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_T0)}, 15")
-    a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_T0)}, {sr(S_LDS)}")
-    a.i(f"s_add_u32 {sr(S_T1)}, {sr(S_CSTREAM)}, 1")
-    a.i(f"s_and_b32 {sr(S_T1)}, {sr(S_T1)}, {NRING - 1}")
-    a.i(f"s_lshl_b32 {sr(S_T1)}, {sr(S_T1)}, 15")
-    a.i(f"s_add_u32 {sr(S_T1)}, {sr(S_T1)}, {sr(S_LDS)}")
-    a.i(f"v_add_u32 {vr(V_ADDR_V)}, {sr(S_T0)}, {vr(V_LANE16)}")
-    a.i(f"v_add_u32 {vr(V_ADDR_K)}, {sr(S_T1)}, {vr(V_LANE16)}")
-
-
-def emit_barrier(a):
-    """own share of stream stage (compute stage + 1) landed, then everybody's; afterwards the slot of the stage before
-    the compute stage may be refilled.  While the DMA cursor is live the 8 newest requests are the stage after that."""
-    l_z, l_b = a.uniq("wz"), a.uniq("wb")
-    a.i(f"s_cmp_eq_u32 {sr(S_DC + 3)}, 0")
-    a.i(f"s_cbranch_scc1 {l_z}")
-    a.i("s_waitcnt vmcnt(8)")
-    a.i(f"s_branch {l_b}")
-    a.label(l_z)
-    a.i("s_waitcnt vmcnt(0)")
-    a.label(l_b)
-    a.i("s_barrier")
-
-
-def emit_post_barrier(a):
-    """once per item, right after the barrier of its first stage: stores of the previous item, Q request for the next"""
-    l_skip = a.uniq("pbskip")
-    a.i(f"s_cmp_eq_u32 {sr(S_QPEND)}, 0")
-    a.i(f"s_cbranch_scc1 {l_skip}")
+def emit_post_barrier_sub(a):
+    """once per item, behind the barrier of its first stage: stores of the previous item, Q request for the next"""
+    a.label(".Lpw_post_barrier")
     emit_ctx_stores(a)
     emit_q_request(a)
     a.i(f"s_mov_b32 {sr(S_QPEND)}, 0")
-    a.label(l_skip)
+    a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
+
+
+def rotate_ops(tail):
+    """the stage behind the compute stage becomes the compute stage"""
+    ops = [f"v_mov_b32 {vr(V_ADDR_V)}, {vr(V_ADDR_K)}", f"s_add_u32 {sr(S_KS)}, {sr(S_KS)}, {STAGE}",
+           f"s_and_b32 {sr(S_KS)}, {sr(S_KS)}, {NRING * STAGE - 1}", f"v_add_u32 {vr(V_ADDR_K)}, {sr(S_KS)}, {vr(V_LDSL)}"]
+    if tail:
+        ops += [f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11", f"v_add_u32 {vr(V_ADDR_VT)}, {sr(S_T0)}, {vr(V_ADDR_V)}"]
+    return ops
+
+
+def emit_stage_top(a):
+    """own share of the stage behind the compute stage landed (the 8 newest requests are the stage after that), then
+    everybody's; afterwards the slot of the stage before the compute stage may be refilled"""
+    a.i("s_waitcnt vmcnt(8)")
+    if not ABLATE & 2:
+        a.i("s_barrier")
+    a.i(f"s_cmp_lg_u32 {sr(S_QPEND)}, 0")
+    a.ool_call(".Lpw_post_barrier")
 
 
 # ------------------------------------------------------------------------------------------------ one step
-def emit_step(a, par, has_next, vblk, kblk_next, dma, advance, check):
+def spread(gaps, ops, lo, hi):
+    """ops (kept in order) evenly over gaps[lo:hi]"""
+    n = hi - lo
+    if n <= 0 or not ops:
+        gaps[max(lo, 0) if lo < len(gaps) else len(gaps) - 1].extend(ops)
+        return
+    for k, op in enumerate(ops):
+        gaps[lo + (k * n) // len(ops)].append(op)
+
+
+def emit_step(a, par, has_next, vblk, kblk_next, tail, dma, book, force):
     """Key block i (parity par: its scores sit in buffer par; the next tile's go to 1 - par).
-    has_next : S^T(i+1) is computed (K(i+1) fragments are in a[192:223])
+    has_next : S^T(i+1) is computed (K(i+1) fragments are in a[192:223]) and its row maxima are checked at the end
     vblk     : LDS offset of V^T(i) inside the compute stage (0 / 8192)
-    kblk_next: LDS offset of K(i+2) inside the next stage, or None
-    dma      : list of (k, half) pieces of the stage being filled issued in this step
-    advance  : the DMA cursor moves on after the last piece
-    check    : the row maxima of tile i+1 are evaluated and the cold path called when a reference has to move"""
+    kblk_next: LDS offset of K(i+2) inside the stage behind it, or None
+    tail     : 0 ordinary item (blocks A, B, four feature blocks each); 1 / 2 feature-split item with block A / A and B
+               (this wave's feature block only: two V^T fragments, two PV MFMAs per block)
+    dma      : list of single instructions (M0 writes and pieces) issued in the second half of the step
+    book     : list of single bookkeeping instructions (SALU / address VALU) issued in the second half of the step
+    force    : register pair that forces the cold path for tile i+1"""
     cur, nxt = par, 1 - par
-    smA, smB = softmax_ops(cur, "A"), softmax_ops(cur, "B")
-    gaps = [[] for _ in range(32)]
-    for n, f in enumerate([0, 2, 4, 6, 1, 3, 5, 7]):  # V^T fragments in the order phase B consumes them
-        gaps[n].append(vread(f, vblk))
-    pos = 0
-    for n in range(14):                               # softmax A: 40 ops over gaps 0..13
-        take = 3 if n < 12 else 2
-        gaps[n].extend(smA[pos:pos + take])
-        pos += take
-    assert pos == 40
-    for n in range(8):                                # softmax B: exponentials in gaps 8..15 ...
-        gaps[8 + n].extend(smB[2 * n:2 * n + 2])
-    chain = smB[16:]                                  # ... chain + packing in gaps 16..23 (PV of block A)
-    for n in range(8):
-        gaps[16 + n].extend(chain[3 * n:3 * n + 3])
-    if kblk_next is not None:
-        for f in range(8):
-            gaps[16 + f].append(kread(f, V_ADDR_K, kblk_next))
-    if has_next and check:
-        mA, mB = max_ops(nxt, "A", V_MX["A"]), max_ops(nxt, "B", V_MX["B"])
-        seq = []
-        for x, y in zip(mA, mB):
-            seq += [x, y]
-        seq.append(f"v_max_f32 {vr(V_T1)}, {vr(V_MX['A'])}, {vr(V_MX['B'])}")
-        seq += half_exchange(V_T1, V_T0, "v_max_f32")
-        seq.append(f"v_cmp_lt_f32 vcc, {sr(S_C16)}, {vr(V_T1)}")
-        per = (len(seq) + 7) // 8
-        for n in range(8):
-            gaps[24 + n].extend(seq[per * n:per * (n + 1)])
-    mf = []
+    blocks = ("A",) if tail == 1 else ("A", "B")
+    mf, seg = [], {}
+    seg["S"] = (0, 0)
     if has_next:
         for ks in range(8):
-            mf.append(mfma_s(nxt, "A", ks))
-            mf.append(mfma_s(nxt, "B", ks))
+            for blk in blocks:
+                mf.append(mfma_s(nxt, blk, ks))
+        seg["S"] = (0, len(mf))
+    for blk in blocks:
+        lo = len(mf)
+        if tail:
+            for j in range(2):
+                O = A_O[blk]
+                mf.append(f"v_mfma_f32_32x32x16_bf16 {ar(O, 16)}, {ar(A_V + 4 * j, 4)}, {vr(V_P[blk] + 4 * j, 4)}, {ar(O, 16)}")
+        else:
+            for j in range(2):
+                for nbd in range(4):
+                    mf.append(mfma_pv(blk, nbd, j))
+        seg[blk] = (lo, len(mf))
+    if "B" not in seg:
+        seg["B"] = seg["A"]
+    N = len(mf)
+    gaps = [[] for _ in range(N)]
+    pre = []   # fillers with no MFMA to hide behind (last step of an item: no S segment)
+    sS, sA, sB = seg["S"], seg["A"], seg["B"]
+    # V^T(i) fragments, in the order the PV MFMAs consume them
+    if tail:
+        vr_ops = [f"ds_read_b128 {ar(A_V + 4 * j, 4)}, {vr(V_ADDR_VT)} offset:{16384 + vblk + j * FRAG}" for j in range(2)]
     else:
-        mf += [None] * 16
-    for blk in ("A", "B"):
-        for j in range(2):
-            for nbd in range(4):
-                mf.append(mfma_pv(blk, nbd, j))
-    dma_gaps = {4: [25, 27, 29, 31], 8: [17, 19, 21, 23, 25, 27, 29, 31], 0: []}[len(dma)]
+        vr_ops = [vread(f, vblk) for f in (0, 2, 4, 6, 1, 3, 5, 7)]
+    sm = {blk: softmax_ops(cur, blk) for blk in blocks}
+    if ABLATE & 8:
+        sm = {blk: [] for blk in blocks}
+    if ABLATE & 16:
+        vr_ops = []
+    if sS[1] > sS[0]:
+        spread(gaps, vr_ops, sS[0], sS[0] + max(1, (sS[1] - sS[0]) // 2))
+        spread(gaps, sm["A"], sS[0], sS[1] - 1 if len(blocks) == 2 else sS[1])
+        if len(blocks) == 2:
+            spread(gaps, sm["B"][:16], (sS[0] + sS[1]) // 2, sS[1])
+            spread(gaps, sm["B"][16:], sA[0], sA[1])
+    else:
+        pre += vr_ops + sm["A"]
+        if len(blocks) == 2:
+            pre += sm["B"][:16]
+            spread(gaps, sm["B"][16:], sA[0], sA[1])
+    second = (sB[0], sB[1]) if len(blocks) == 2 and not tail else (sA[0] + (sA[1] - sA[0]) // 2, N)
+    if kblk_next is not None and not ABLATE & 16:
+        # (before `second`: the bookkeeping there rotates the address register these reads use)
+        spread(gaps, [kread(f, V_ADDR_K, kblk_next) for f in range(8)], sA[0], max(sA[0] + 1, second[0]) if tail else sA[1])
+    check = has_next and not ABLATE & 4
+    if check:
+        seq = []
+        mx = [max_ops(nxt, blk, V_MX[blk]) for blk in blocks]
+        for k in range(8):
+            for m in mx:
+                seq.append(m[k])
+        if len(blocks) == 2:
+            seq.append(f"v_max_f32 {vr(V_T1)}, {vr(V_MX['A'])}, {vr(V_MX['B'])}")
+        else:
+            seq.append(f"v_mov_b32 {vr(V_T1)}, {vr(V_MX['A'])}")
+        seq += half_exchange(V_T1, V_T0, "v_max_f32")
+        seq.append(f"v_cmp_lt_f32 vcc, 0x41800000, {vr(V_T1)}")
+        if tail and not ABLATE & 128:  # only 2 - 4 MFMAs separate the last score MFMA from its first reader
+            seq = ["s_nop 7", "s_nop 7"] + seq
+        spread(gaps, seq, second[0], second[1])
+    if not ABLATE & 1:
+        spread(gaps, dma, second[0], second[1])
+    spread(gaps, book, second[0], second[1])
     a.i("s_waitcnt lgkmcnt(0)")       # K(i+1) fragments, requested one phase ago
-    for n in range(32):
-        if n == 16:
+    for op in pre:
+        a.i(op)
+    for n in range(N):
+        if n == sA[0]:
             a.i("s_waitcnt lgkmcnt(0)")  # V^T(i) fragments
-        if mf[n] is not None:
-            a.i(mf[n])
+        a.i(mf[n])
         for op in gaps[n]:
             a.i(op)
-        if n in dma_gaps:
-            for op in dma_piece_ops(*dma[dma_gaps.index(n)]):
-                a.i(op)
-    if advance:
-        emit_dma_advance(a)
-    if has_next and check:
-        l_cont = a.uniq("cont")
-        a.i(f"s_or_b64 {sr(S_T4, 2)}, vcc, {sr(S_FORCE, 2)}")
-        a.i(f"s_cbranch_scc0 {l_cont}")
-        a.i(f"s_call_b64 {sr(S_RET, 2)}, .Lpw_cold_{nxt}")
-        a.label(l_cont)
+    if check and not ABLATE & 64:
+        a.i(f"s_or_b64 {sr(S_T4, 2)}, vcc, {sr(force, 2)}")
+        a.ool_call(f".Lpw_cold_{nxt}" if tail != 1 else f".Lpw_cold1_{nxt}")
 
 
-K_PIECES = [(k, 0) for k in range(4)]
-V_PIECES = [(k, 1) for k in range(4)]
+def fo_ops():
+    """S_FO = all ones when the tile checked at the end of the stage's odd step (STEP + 2) is the ragged last one:
+    only in the last 'mid' stage of an item with an odd number of key blocks"""
+    # (SCC producer and consumer stay together: other SALU instructions may be placed between the items of this list)
+    return [f"s_cmp_eq_u32 {sr(S_CNT)}, 1\n\ts_cselect_b32 {sr(S_T0)}, {sr(S_RAGODD)}, 0",
+            f"s_cmp_lg_u32 {sr(S_T0)}, 0\n\ts_cselect_b64 {sr(S_FO, 2)}, -1, 0"]
 
 
-def emit_stage(a, kind, with_dma):
-    """kind: 'mid' (two steps, both followed by another tile), 'last2' (QB even: the second step is the item's
-    last), 'last1' (QB odd: a single step, the item's last)"""
-    emit_barrier(a)
-    emit_post_barrier(a)
-    emit_stage_addrs(a)
-    # the ragged last key block (T % 32 != 0) goes through the cold path, which masks it
+def emit_stage(a, kind, tail):
+    """kind: 'mid' (two steps, both followed by another tile), 'last2' (QB even: the second step is the item's last),
+    'last1' (QB odd: a single step, the item's last).  Every stage: one barrier, 8 DMA pieces, one stream advance."""
+    stamp(a, 11)
+    emit_stage_top(a)
+    stamp(a, 2)
+    kh, vh = dma_half_ops(0), dma_half_ops(1)
     if kind == "mid":
-        # tile 2s+1 is never the last here; tile 2s+2 is the last one iff S_STEP + 3 == QB
-        emit_step(a, 0, True, 0, 0, K_PIECES if with_dma else [], False, True)
-        emit_force_for(a, 3)   # FORCE for the check of the second step: tile S_STEP + 2
-        emit_step(a, 1, True, BLK, BLK, V_PIECES if with_dma else [], with_dma, True)
+        emit_step(a, 0, True, 0, 0, tail, kh, fo_ops(), S_FE)
+        stamp(a, 4)
+        emit_step(a, 1, True, BLK, BLK, tail, vh, rotate_ops(tail) + [f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"], S_FO)
+        emit_dma_advance(a)
+        stamp(a, 5)
     elif kind == "last2":
-        emit_force_for(a, 2)   # the second tile of the stage is the last one
-        emit_step(a, 0, True, 0, None, K_PIECES if with_dma else [], False, True)
-        emit_step(a, 1, False, BLK, None, V_PIECES if with_dma else [], with_dma, False)
+        emit_step(a, 0, True, 0, None, tail, kh, [], S_FE)
+        stamp(a, 4)
+        emit_step(a, 1, False, BLK, None, tail, vh, rotate_ops(tail), S_FO)
+        emit_dma_advance(a)
+        stamp(a, 6)
     else:
-        emit_step(a, 0, False, 0, None, (K_PIECES + V_PIECES) if with_dma else [], with_dma, False)
-
-
-def emit_force_for(a, delta):
-    """S_FORCE = all ones when (S_STEP + delta == QB) and the sequence has a ragged last key block"""
-    a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_STEP)}, {delta}")
-    a.i(f"s_cmp_eq_u32 {sr(S_T0)}, {sr(S_QB)}")
-    a.i(f"s_cselect_b32 {sr(S_T0)}, {sr(S_RAG)}, 0")
-    a.i(f"s_cmp_lg_u32 {sr(S_T0)}, 0")
-    a.i(f"s_cselect_b64 {sr(S_FORCE, 2)}, -1, 0")
+        emit_step(a, 0, False, 0, None, tail, kh + vh, rotate_ops(tail), S_FE)
+        emit_dma_advance(a)
+        stamp(a, 6)
 
 
 # ------------------------------------------------------------------------------------------------ cold path
-def emit_cold(a, buf, first):
+def emit_cold(a, buf, first, blocks=("A", "B")):
     """Reference move of the freshly computed score tile in buffer `buf` (scores relative to the current reference):
     ragged last key block masked first; first = the item's first tile (reference := row maximum when it is more than
     2^16 away from 0, nothing to rescale); otherwise O and l of rows whose maximum exceeds the reference by 2^16 are
     rescaled.  Operation for operation online_softmax_shifted() of savad_kernels_bf16.h.  Entered with every MFMA
     that wrote the tile (and, when not first, every PV MFMA) at least 8 MFMAs or 24 wait states behind."""
+    force = S_FE if buf == 1 or first else S_FO   # tile in buffer 1 is checked by an even step, buffer 0 by an odd step
     l_nomask = a.uniq("nomask")
+    if TIMING:   # lane 12 + buf (14: first) counts the calls
+        c = 14 if first else 12 + buf
+        a.i(f"v_readlane_b32 {sr(S_TM)}, {vr(V_ACC)}, {c}")
+        a.i(f"s_add_u32 {sr(S_TM)}, {sr(S_TM)}, 1")
+        a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, {c}")
     a.i("s_nop 7")
     a.i("s_nop 7")
     a.i("s_nop 7")
-    a.i(f"s_cmp_eq_u64 {sr(S_FORCE, 2)}, 0")
+    a.i(f"s_cmp_eq_u64 {sr(force, 2)}, 0")
     a.i(f"s_cbranch_scc1 {l_nomask}")
-    # lim = T - 32 * tile - 4h = RAG - 4h for the last tile: key 8(r>>2) + (r&3) exists iff it is < lim
+    # last tile: key 8(r>>2) + (r&3) of this lane exists iff it is < T%32 - 4h
     a.i(f"v_sub_u32 {vr(V_LIM)}, {sr(S_RAG)}, {vr(V_H4)}")
-    for blk in ("A", "B"):
+    for blk in blocks:
         S = V_S[(buf, blk)]
         for r in range(16):
-            kidx = 8 * (r >> 2) + (r & 3)
-            a.i(f"v_cmp_lt_i32 vcc, {kidx}, {vr(V_LIM)}")
+            a.i(f"v_cmp_lt_i32 vcc, {8 * (r >> 2) + (r & 3)}, {vr(V_LIM)}")
             a.i(f"v_cndmask_b32 {vr(S + r)}, {vr(V_NEGB)}, {vr(S + r)}, vcc")
     a.label(l_nomask)
-    for blk in ("A", "B"):
+    for blk in blocks:
         S = V_S[(buf, blk)]
         l_skip = a.uniq("coldskip")
         for op in max_ops(buf, blk, V_MX[blk]):
             a.i(op)
         for op in half_exchange(V_MX[blk], V_T0, "v_max_f32"):
             a.i(op)
-        # move = mx > 16 (|| first && mx < -16); d = move ? mx : 0
-        a.i(f"v_cmp_lt_f32 vcc, {sr(S_C16)}, {vr(V_MX[blk])}")
         if first:
-            a.i(f"v_cmp_gt_f32 {sr(S_T4, 2)}, {sr(S_CM16)}, {vr(V_MX[blk])}")
+            a.i(f"v_cmp_gt_f32 vcc, 0xc1800000, {vr(V_MX[blk])}")       # (first && mx < -16) ...
+            a.i(f"s_mov_b64 {sr(S_T4, 2)}, vcc")
+        a.i(f"v_cmp_lt_f32 vcc, 0x41800000, {vr(V_MX[blk])}")           # move = mx > 16 ...
+        if first:
             a.i(f"s_or_b64 vcc, vcc, {sr(S_T4, 2)}")
-        a.i(f"s_cmp_eq_u64 vcc, 0")
+        a.i("s_cmp_eq_u64 vcc, 0")
         a.i(f"s_cbranch_scc1 {l_skip}")
-        a.i(f"v_cndmask_b32 {vr(V_D)}, 0, {vr(V_MX[blk])}, vcc")
+        if TIMING:   # lane 15: blocks that really moved
+            a.i(f"v_readlane_b32 {sr(S_TM)}, {vr(V_ACC)}, 15")
+            a.i(f"s_add_u32 {sr(S_TM)}, {sr(S_TM)}, 1")
+            a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 15")
+        a.i(f"v_cndmask_b32 {vr(V_D)}, 0, {vr(V_MX[blk])}, vcc")       # d = move ? mx : 0
         if not first:
             a.i(f"v_exp_f32 {vr(V_AL)}, -{vr(V_D)}")
             a.i("s_nop 0")
@@ -550,23 +664,17 @@ def emit_cold(a, buf, first):
 # ------------------------------------------------------------------------------------------------ item prologue / epilogue
 def emit_item_prologue(a):
     """Q of this item from staging into a[128:191]; S^T(0) with C = 0 beside the zeroing of O; reference of tile 0"""
-    l_q8, l_qd = a.uniq("q8"), a.uniq("qd")
-    a.i(f"s_cmp_eq_u32 {sr(S_DC + 3)}, 0")
-    a.i(f"s_cbranch_scc1 {l_q8}")
     a.i("s_waitcnt vmcnt(8)")   # the staged Q is older than the newest stage of DMA pieces
-    a.i(f"s_branch {l_qd}")
-    a.label(l_q8)
-    a.i("s_waitcnt vmcnt(0)")
-    a.label(l_qd)
     for r in range(64):
         a.i(f"v_accvgpr_write_b32 {ar(A_Q['A'] + r)}, {vr(V_QS + r)}")
-    emit_stage_addrs(a)
     for f in range(8):
         a.i(kread(f, V_ADDR_V, 0))
     for blk in ("A", "B"):
         a.i(f"v_mov_b32 {vr(V_L[blk])}, 0")
         for r in range(16):
             a.i(f"v_mov_b32 {vr(V_NEGM[blk] + r)}, 0")
+    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11")
+    a.i(f"v_add_u32 {vr(V_ADDR_VT)}, {sr(S_T0)}, {vr(V_ADDR_V)}")
     a.i("s_waitcnt lgkmcnt(0)")
     n = 0
     for ks in range(8):
@@ -575,53 +683,106 @@ def emit_item_prologue(a):
             for _ in range(8):
                 a.i(f"v_accvgpr_write_b32 {ar(n)}, 0")
                 n += 1
-    assert n == 128
     for f in range(8):
         a.i(kread(f, V_ADDR_V, BLK))   # K(1): the stage's second block
     # tile 0 is the last tile only when QB == 1, which this kernel never sees (T > 32)
-    a.i(f"s_mov_b64 {sr(S_FORCE, 2)}, 0")
+    a.i(f"s_mov_b64 {sr(S_FE, 2)}, 0")
+    a.i(f"s_mov_b64 {sr(S_FO, 2)}, 0")
     a.i(f"s_call_b64 {sr(S_RET, 2)}, .Lpw_coldfirst_0")
-    a.i(f"s_mov_b32 {sr(S_STEP)}, 0")
+    a.i(f"s_sub_u32 {sr(S_CNT)}, {sr(S_QB)}, 1")
+    a.i(f"s_lshr_b32 {sr(S_CNT)}, {sr(S_CNT)}, 1")
 
 
-def emit_item_epilogue(a):
+def emit_normalise(a, blk, nregs, dst):
+    """context block(s) of query block blk: a[A_O[blk] .. + nregs) / row sum -> bf16 pairs in v[dst ..]; rows of a ragged
+    last query block that do not exist store exact zeros (as store_ctx of savad_kernels_bf16.h)"""
+    a.i(f"v_mov_b32 {vr(V_T0)}, {vr(V_L[blk])}")
+    a.i("s_nop 1")
+    a.i(f"v_permlane32_swap_b32 {vr(V_L[blk])}, {vr(V_T0)}")
+    a.i(f"v_add_f32 {vr(V_T0)}, {vr(V_L[blk])}, {vr(V_T0)}")
+    x, out = V_T0, V_INV[blk]
+    t0, t1, t2, t3 = V_T1, V_T2, V_T3, V_T4
+    # 1.0f / x as hipcc emits it (IEEE): v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup
+    a.i(f"v_div_scale_f32 {vr(t0)}, {sr(S_T4, 2)}, {vr(x)}, {vr(x)}, 1.0")
+    a.i(f"v_rcp_f32 {vr(t1)}, {vr(t0)}")
+    a.i("s_nop 0")
+    a.i(f"v_fma_f32 {vr(t2)}, -{vr(t0)}, {vr(t1)}, 1.0")
+    a.i(f"v_fmac_f32 {vr(t1)}, {vr(t2)}, {vr(t1)}")
+    a.i(f"v_div_scale_f32 {vr(t2)}, vcc, 1.0, {vr(x)}, 1.0")
+    a.i(f"v_mul_f32 {vr(t3)}, {vr(t2)}, {vr(t1)}")
+    a.i(f"v_fma_f32 {vr(out)}, -{vr(t0)}, {vr(t3)}, {vr(t2)}")
+    a.i(f"v_fmac_f32 {vr(t3)}, {vr(out)}, {vr(t1)}")
+    a.i(f"v_fma_f32 {vr(t2)}, -{vr(t0)}, {vr(t3)}, {vr(t2)}")
+    a.i("s_nop 1")
+    a.i(f"v_div_fmas_f32 {vr(t2)}, {vr(t2)}, {vr(t1)}, {vr(t3)}")
+    a.i(f"v_div_fixup_f32 {vr(out)}, {vr(t2)}, {vr(x)}, 1.0")
+    a.i(f"v_cmp_gt_i32 vcc, {sr(S_VALID[blk])}, {vr(V_M)}")
+    a.i("s_nop 1")
+    a.i(f"v_cndmask_b32 {vr(out)}, 0, {vr(out)}, vcc")   # (rows that do not exist: factor 0, cleaned up below)
+    l_rag, l_end = a.uniq("nrag"), a.uniq("nend")
+    a.i(f"s_cmp_lt_i32 {sr(S_VALID[blk])}, 32")
+    a.i(f"s_cbranch_scc1 {l_rag}")
+    for ragged in (False, True):
+        if ragged:
+            a.label(l_rag)
+        for e in range(nregs // 2):
+            a.i(f"v_accvgpr_read_b32 {vr(V_T1)}, {ar(A_O[blk] + 2 * e)}")
+            a.i(f"v_accvgpr_read_b32 {vr(V_T2)}, {ar(A_O[blk] + 2 * e + 1)}")
+            a.i(f"v_mul_f32 {vr(V_T1)}, {vr(V_T1)}, {vr(out)}")
+            a.i(f"v_mul_f32 {vr(V_T2)}, {vr(V_T2)}, {vr(out)}")
+            if ragged:   # 0 * inf / NaN of a row that does not exist must still store 0
+                a.i(f"v_cvt_pk_bf16_f32 {vr(V_T1)}, {vr(V_T1)}, {vr(V_T2)}")
+                a.i(f"v_cndmask_b32 {vr(dst + e)}, 0, {vr(V_T1)}, vcc")
+            else:
+                a.i(f"v_cvt_pk_bf16_f32 {vr(dst + e)}, {vr(V_T1)}, {vr(V_T2)}")
+        if not ragged:
+            a.i(f"s_branch {l_end}")
+    a.label(l_end)
+
+
+def emit_item_epilogue(a, tail):
     """normalise O by the row sums, pack to bf16 fragments into the staging registers of the stores, describe them"""
     a.i("s_nop 7")
     a.i("s_nop 7")
     a.i("s_nop 7")
-    for blk in ("A", "B"):
-        # total row sum: both halves
-        a.i(f"v_mov_b32 {vr(V_T0)}, {vr(V_L[blk])}")
-        a.i("s_nop 1")
-        a.i(f"v_permlane32_swap_b32 {vr(V_L[blk])}, {vr(V_T0)}")
-        a.i(f"v_add_f32 {vr(V_T0)}, {vr(V_L[blk])}, {vr(V_T0)}")
-        x, out = V_T0, V_INV[blk]
-        t0, t1, t2, t3 = V_T1, V_T2, V_T3, V_T4
-        a.i(f"v_div_scale_f32 {vr(t0)}, {sr(S_T4, 2)}, {vr(x)}, {vr(x)}, 1.0")
-        a.i(f"v_rcp_f32 {vr(t1)}, {vr(t0)}")
-        a.i("s_nop 0")
-        a.i(f"v_fma_f32 {vr(t2)}, -{vr(t0)}, {vr(t1)}, 1.0")
-        a.i(f"v_fmac_f32 {vr(t1)}, {vr(t2)}, {vr(t1)}")
-        a.i(f"v_div_scale_f32 {vr(t2)}, vcc, 1.0, {vr(x)}, 1.0")
-        a.i(f"v_mul_f32 {vr(t3)}, {vr(t2)}, {vr(t1)}")
-        a.i(f"v_fma_f32 {vr(out)}, -{vr(t0)}, {vr(t3)}, {vr(t2)}")
-        a.i(f"v_fmac_f32 {vr(t3)}, {vr(out)}, {vr(t1)}")
-        a.i(f"v_fma_f32 {vr(t2)}, -{vr(t0)}, {vr(t3)}, {vr(t2)}")
-        a.i("s_nop 1")
-        a.i(f"v_div_fmas_f32 {vr(t2)}, {vr(t2)}, {vr(t1)}, {vr(t3)}")
-        a.i(f"v_div_fixup_f32 {vr(out)}, {vr(t2)}, {vr(x)}, 1.0")
-        # rows of the block that do not exist (ragged last query block) store exact zeros
-        a.i(f"v_cmp_gt_i32 vcc, {sr(S_VALID[blk])}, {vr(V_M)}")
-        a.i("s_nop 1")
-        for nbd in range(4):
-            for e in range(8):
-                r0 = 16 * nbd + 2 * e
-                a.i(f"v_accvgpr_read_b32 {vr(V_T1)}, {ar(A_O[blk] + r0)}")
-                a.i(f"v_accvgpr_read_b32 {vr(V_T2)}, {ar(A_O[blk] + r0 + 1)}")
-                a.i(f"v_mul_f32 {vr(V_T1)}, {vr(V_T1)}, {vr(V_INV[blk])}")
-                a.i(f"v_mul_f32 {vr(V_T2)}, {vr(V_T2)}, {vr(V_INV[blk])}")
-                a.i(f"v_cvt_pk_bf16_f32 {vr(V_T1)}, {vr(V_T1)}, {vr(V_T2)}")
-                a.i(f"v_cndmask_b32 {vr(V_CTX[blk] + 8 * nbd + e)}, 0, {vr(V_T1)}, vcc")
+    blocks = ("A",) if tail == 1 else ("A", "B")
+    for blk in blocks:
+        emit_normalise(a, blk, 16 if tail else 64, V_CTX[blk])
+    a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_SEQBLK)}, {sr(S_QA)}")
+    emit_block_addr(a, S_CDST, S_CTXF, S_T3, S_T2, S_T1)
+    a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_T3)}, 1")
+    emit_block_addr(a, S_CDSTB, S_CTXF, S_T3, S_T2, S_T1)
+    if tail:   # this wave's two fragments: 2w, 2w + 1
+        a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11")
+        for d in (S_CDST, S_CDSTB):
+            a.i(f"s_add_u32 {sr(d)}, {sr(d)}, {sr(S_T0)}")
+            a.i(f"s_addc_u32 {sr(d + 1)}, {sr(d + 1)}, 0")
+    a.i(f"s_mov_b32 {sr(S_PEND)}, {sr(S_FLAGS)}")
+
+
+def emit_item_body(a, tail, tag):
+    """the stages of an item whose prologue has run: 'mid' loop, then the last stage by the parity of QB"""
+    l_mid, l_last, l_l1, l_done = (f".Lpw_{tag}_{x}" for x in ("mid", "last", "last1", "done"))
+    a.i(f"s_cmp_eq_u32 {sr(S_CNT)}, 0")
+    a.i(f"s_cbranch_scc1 {l_last}")
+    a.label(l_mid)
+    emit_stage(a, "mid", tail)
+    a.i(f"s_cmp_lg_u32 {sr(S_CNT)}, 0")
+    a.i(f"s_cbranch_scc1 {l_mid}")
+    a.label(l_last)
+    a.i(f"s_bitcmp1_b32 {sr(S_QB)}, 0")
+    a.i(f"s_cbranch_scc1 {l_l1}")
+    a.i(f"s_cmp_lg_u32 {sr(S_RAGEVEN)}, 0")
+    a.i(f"s_cselect_b64 {sr(S_FE, 2)}, -1, 0")
+    emit_stage(a, "last2", tail)
+    a.i(f"s_branch {l_done}")
+    a.label(l_l1)
+    emit_stage(a, "last1", tail)
+    a.label(l_done)
+    stamp(a, 11)
+    emit_item_epilogue(a, tail)
+    stamp(a, 8)
+    a.i("s_branch .Lpw_next_item")
 
 
 def emit_all():
@@ -632,7 +793,6 @@ def emit_all():
     a.i(f"s_mov_b64 {sr(S_KF, 2)}, %1")
     a.i(f"s_mov_b64 {sr(S_VTF, 2)}, %2")
     a.i(f"s_mov_b64 {sr(S_CTXF, 2)}, %3")
-    a.i(f"s_mov_b32 {sr(S_B)}, %4")
     a.i(f"s_mov_b32 {sr(S_T)}, %5")
     a.i(f"s_mov_b32 {sr(S_XCD)}, %6")
     a.i(f"s_mov_b32 {sr(S_J)}, %7")
@@ -644,7 +804,14 @@ def emit_all():
     a.i(f"s_mov_b32 {sr(S_W)}, %13")
     a.i(f"s_mov_b32 {sr(S_LDS)}, %14")
     a.i(f"v_mov_b32 {vr(V_LANE16)}, %15")
-    a.i(f"s_mov_b64 exec, -1")
+    a.i("s_mov_b64 exec, -1")
+    for _ in range(PAD):
+        a.i("s_nop 0")
+    if TIMING:
+        a.i(f"v_mov_b32 {vr(V_ACC)}, 0")
+        a.i(f"s_memtime {sr(S_TM, 2)}")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 31")
     # ---- derived constants
     a.i(f"s_add_u32 {sr(S_QB)}, {sr(S_T)}, 31")
     a.i(f"s_lshr_b32 {sr(S_QB)}, {sr(S_QB)}, 5")
@@ -653,24 +820,28 @@ def emit_all():
     a.i(f"s_lshr_b32 {sr(S_NGF)}, {sr(S_QB)}, 3")
     a.i(f"s_and_b32 {sr(S_TAILQ)}, {sr(S_QB)}, 7")
     a.i(f"s_and_b32 {sr(S_RAG)}, {sr(S_T)}, 31")
-    # sequences of this XCD: b = 8 bi + xcd < B
-    a.i(f"s_add_u32 {sr(S_BX)}, {sr(S_B)}, 7")
+    a.i(f"s_bitcmp1_b32 {sr(S_QB)}, 0")
+    a.i(f"s_cselect_b32 {sr(S_RAGODD)}, {sr(S_RAG)}, 0")
+    a.i(f"s_cselect_b32 {sr(S_RAGEVEN)}, 0, {sr(S_RAG)}")
+    a.i(f"s_add_u32 {sr(S_BX)}, %4, 7")                      # sequences of this XCD: b = 8 bi + xcd < B
     a.i(f"s_sub_u32 {sr(S_BX)}, {sr(S_BX)}, {sr(S_XCD)}")
     a.i(f"s_lshr_b32 {sr(S_BX)}, {sr(S_BX)}, 3")
-    a.i(f"s_mov_b32 {sr(S_C16)}, 0x41800000")
-    a.i(f"s_mov_b32 {sr(S_CM16)}, 0xc1800000")
-    a.i(f"s_mov_b32 {sr(S_NEGBIG)}, {hex(NEG_BIG_BITS)}")
-    for k in range(1, 4):
-        a.i(f"v_add_u32 {vr(V_OFF[k])}, {k * 4096}, {vr(V_LANE16)}")
+    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 12")
+    a.i(f"s_add_u32 {sr(S_LDSW)}, {sr(S_LDS)}, {sr(S_T0)}")
+    a.i(f"v_add_u32 {vr(V_OFF[1])}, 4096, {vr(V_LANE16)}")
     a.i(f"v_lshrrev_b32 {vr(V_M)}, 4, {vr(V_LANE16)}")        # lane
     a.i(f"v_lshrrev_b32 {vr(V_H4)}, 5, {vr(V_M)}")            # h
     a.i(f"v_lshlrev_b32 {vr(V_H4)}, 2, {vr(V_H4)}")           # 4 h
     a.i(f"v_and_b32 {vr(V_M)}, 31, {vr(V_M)}")
-    a.i(f"v_mov_b32 {vr(V_NEGB)}, {sr(S_NEGBIG)}")
+    a.i(f"v_mov_b32 {vr(V_NEGB)}, {hex(NEG_BIG_BITS)}")
+    a.i(f"v_add_u32 {vr(V_LDSL)}, {sr(S_LDS)}, {vr(V_LANE16)}")
+    a.i(f"v_mov_b32 {vr(V_ADDR_V)}, {vr(V_LDSL)}")            # the stream's stage 0 sits in slot 0, stage 1 in slot 1
+    a.i(f"s_mov_b32 {sr(S_KS)}, {STAGE}")
+    a.i(f"v_add_u32 {vr(V_ADDR_K)}, {sr(S_KS)}, {vr(V_LDSL)}")
     a.i(f"s_mov_b32 {sr(S_PEND)}, 0")
     a.i(f"s_mov_b32 {sr(S_QPEND)}, 0")
     a.i(f"s_mov_b32 {sr(S_DSTREAM)}, 0")
-    a.i(f"s_mov_b32 {sr(S_CSTREAM)}, 0")
+    a.i(f"s_mov_b32 {sr(S_DLDS)}, {sr(S_LDSW)}")
     # ---- cursors
     a.i(f"s_mov_b32 {sr(S_DC + 1)}, {sr(S_CC + 1)}")
     a.i(f"s_mov_b32 {sr(S_DC + 2)}, {sr(S_CC + 2)}")
@@ -682,40 +853,22 @@ def emit_all():
     emit_item_params(a, S_CC, S_NFLAGS, S_NQA, S_NSEQBLK)
     emit_q_request(a)
     emit_dma_item_setup(a)
-    emit_dma_lds(a)
     for _ in range(3):
-        l_skip = a.uniq("pdskip")
-        a.i(f"s_cmp_eq_u32 {sr(S_DC + 3)}, 0")
-        a.i(f"s_cbranch_scc1 {l_skip}")
-        for half in (0, 1):
-            for k in range(4):
-                for op in dma_piece_ops(k, half):
-                    a.i(op)
+        emit_dma_half(a, 0)
+        emit_dma_half(a, 1)
         emit_dma_advance(a)
-        a.label(l_skip)
     # stage 0 has landed for everybody before the first item's prologue reads K(0), K(1) from it
-    l_z, l_b = a.uniq("iwz"), a.uniq("iwb")
-    a.i(f"s_cmp_eq_u32 {sr(S_DC + 3)}, 0")
-    a.i(f"s_cbranch_scc1 {l_z}")
     a.i("s_waitcnt vmcnt(16)")
-    a.i(f"s_branch {l_b}")
-    a.label(l_z)
-    a.i("s_waitcnt vmcnt(0)")
-    a.label(l_b)
     a.i("s_barrier")
 
     # ================================================================================ item loop
     a.label(".Lpw_item")
-    # the item the compute cursor points at was described as "next" by the previous round
     a.i(f"s_mov_b32 {sr(S_FLAGS)}, {sr(S_NFLAGS)}")
     a.i(f"s_mov_b32 {sr(S_QA)}, {sr(S_NQA)}")
     a.i(f"s_mov_b32 {sr(S_SEQBLK)}, {sr(S_NSEQBLK)}")
-    # rows that exist in block A / B: T - 32 qb
-    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_QA)}, 5")
+    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_QA)}, 5")              # rows that exist in block A / B: T - 32 qb
     a.i(f"s_sub_i32 {sr(S_VALID['A'])}, {sr(S_T)}, {sr(S_T0)}")
     a.i(f"s_sub_i32 {sr(S_VALID['B'])}, {sr(S_VALID['A'])}, 32")
-    # ctx destinations of THIS item are needed when it is finished; the pending stores of the previous item still use
-    # S_CDST: they are issued in this item's first stage, BEFORE the epilogue overwrites them.
     # advance the compute cursor and describe the next item (its Q is requested behind this item's first barrier)
     emit_cursor_next(a, S_CC, "c")
     a.i(f"s_mov_b32 {sr(S_NFLAGS)}, 0")
@@ -727,58 +880,33 @@ def emit_all():
     a.i(f"s_mov_b32 {sr(S_QPEND)}, 1")
     a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 0")
     a.i("s_cbranch_scc0 .Lpw_idle_item")
-
+    stamp(a, 0)
     emit_item_prologue(a)
-    a.label(".Lpw_stage")
-    a.i(f"s_sub_u32 {sr(S_T0)}, {sr(S_QB)}, {sr(S_STEP)}")
-    a.i(f"s_cmp_gt_u32 {sr(S_T0)}, 2")
-    a.i("s_cbranch_scc1 .Lpw_mid")
-    a.i(f"s_cmp_eq_u32 {sr(S_T0)}, 2")
-    a.i("s_cbranch_scc1 .Lpw_last2")
-    a.i("s_branch .Lpw_last1")
-    for kind in ("mid", "last2", "last1"):
-        a.label(f".Lpw_{kind}")
-        a.i(f"s_cmp_eq_u32 {sr(S_DC + 3)}, 0")
-        a.i(f"s_cbranch_scc1 .Lpw_{kind}_nodma")
-        emit_stage(a, kind, True)
-        a.i(f"s_branch .Lpw_{kind}_done")
-        a.label(f".Lpw_{kind}_nodma")
-        emit_stage(a, kind, False)
-        a.label(f".Lpw_{kind}_done")
-        a.i(f"s_add_u32 {sr(S_CSTREAM)}, {sr(S_CSTREAM)}, 1")
-        if kind == "mid":
-            a.i(f"s_add_u32 {sr(S_STEP)}, {sr(S_STEP)}, 2")
-            a.i("s_branch .Lpw_stage")
-        else:
-            a.i("s_branch .Lpw_item_done")
-    a.label(".Lpw_item_done")
-    emit_item_epilogue(a)
-    # describe the stores (issued behind the next barrier, or at the end of the kernel)
-    a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_SEQBLK)}, {sr(S_QA)}")
-    emit_block_addr(a, S_CDST, S_CTXF, S_T3, S_T2, S_T1)
-    a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_T3)}, 1")
-    emit_block_addr(a, S_CDSTB, S_CTXF, S_T3, S_T2, S_T1)
-    a.i(f"s_and_b32 {sr(S_PEND)}, {sr(S_FLAGS)}, 3")
-    a.i("s_branch .Lpw_next_item")
+    stamp(a, 1)
+    a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 2")
+    a.i("s_cbranch_scc0 .Lpw_normal_item")
+    a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 1")
+    a.i("s_cbranch_scc0 .Lpw_tail1_item")
+    emit_item_body(a, 2, "t2")
+    a.label(".Lpw_tail1_item")
+    emit_item_body(a, 1, "t1")
+    a.label(".Lpw_normal_item")
+    emit_item_body(a, 0, "n")
 
     # ---- a wave without a query block in this item: keeps the stream and the barriers going
     a.label(".Lpw_idle_item")
-    a.i(f"s_mov_b32 {sr(S_STEP)}, 0")
+    a.i(f"s_mov_b32 {sr(S_CNT)}, {sr(S_NST)}")
     a.label(".Lpw_idle_stage")
-    emit_barrier(a)
-    emit_post_barrier(a)
-    l_nod = a.uniq("idlenodma")
-    a.i(f"s_cmp_eq_u32 {sr(S_DC + 3)}, 0")
-    a.i(f"s_cbranch_scc1 {l_nod}")
-    for half in (0, 1):
-        for k in range(4):
-            for op in dma_piece_ops(k, half):
-                a.i(op)
+    emit_stage_top(a)
+    if not ABLATE & 1:
+        emit_dma_half(a, 0)
+        emit_dma_half(a, 1)
     emit_dma_advance(a)
-    a.label(l_nod)
-    a.i(f"s_add_u32 {sr(S_CSTREAM)}, {sr(S_CSTREAM)}, 1")
-    a.i(f"s_add_u32 {sr(S_STEP)}, {sr(S_STEP)}, 2")
-    a.i(f"s_cmp_lt_u32 {sr(S_STEP)}, {sr(S_QB)}")
+    for op in rotate_ops(False):
+        a.i(op)
+    stamp(a, 9)
+    a.i(f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1")
+    a.i(f"s_cmp_lg_u32 {sr(S_CNT)}, 0")
     a.i("s_cbranch_scc1 .Lpw_idle_stage")
 
     a.label(".Lpw_next_item")
@@ -786,21 +914,40 @@ def emit_all():
     a.i("s_cbranch_scc0 .Lpw_item")
     # ---- the last item's stores
     emit_ctx_stores(a)
+    stamp(a, 10)
+    if TIMING:  # wave 0 of workgroup 0 publishes its counters
+        l_nopub = a.uniq("nopub")
+        a.i(f"s_or_b32 {sr(S_T0)}, {sr(S_XCD)}, {sr(S_J)}")
+        a.i(f"s_or_b32 {sr(S_T0)}, {sr(S_T0)}, {sr(S_W)}")
+        a.i(f"s_cmp_lg_u32 {sr(S_T0)}, 0")
+        a.i(f"s_cbranch_scc1 {l_nopub}")
+        a.i("s_mov_b32 exec_hi, 0")
+        a.i(f"v_lshlrev_b32 {vr(V_T0)}, 2, {vr(V_M)}")
+        a.i(f"global_store_dword {vr(V_T0)}, {vr(V_ACC)}, %16")   # the input operand's own register (s0..s23 are never written)
+        a.i("s_mov_b32 exec_hi, -1")
+        a.label(l_nopub)
     a.label(".Lpw_end")
     a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a.i("s_branch .Lpw_exit")
-    # ---- cold paths (subroutines)
+    # ---- out-of-line code: stubs, subroutines
+    a.lines += a.tail
+    a.tail = []
     for buf in (0, 1):
         a.label(f".Lpw_cold_{buf}")
         emit_cold(a, buf, False)
+        a.label(f".Lpw_cold1_{buf}")
+        emit_cold(a, buf, False, blocks=("A",))
     a.label(".Lpw_coldfirst_0")
     emit_cold(a, 0, True)
+    emit_post_barrier_sub(a)
+    emit_dma_next_item_sub(a)
+    a.lines += a.tail
     a.label(".Lpw_exit")
     return a
 
 
 def render(a):
-    body = "\n".join(x for x in a.lines if x is not None)
+    body = "\n".join(a.lines)
     return ("// generated by scripts/gen_attn_pw.py -- do not edit (python scripts/gen_attn_pw.py rewrites it)\n"
             "R\"ASMPW(\n" + body + "\n)ASMPW\"\n")
 
@@ -821,15 +968,34 @@ def render_clobbers():
 
 
 def main():
+    global TIMING, ABLATE
+    if "--out" in sys.argv:  # experiment variant: [--ablate MASK] [--timing] --out FILE
+        ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1]) if "--ablate" in sys.argv else 0
+        TIMING = "--timing" in sys.argv or "--count" in sys.argv
+        global COUNT_ONLY
+        COUNT_ONLY = "--count" in sys.argv
+        if "--pad" in sys.argv:
+            global PAD
+            PAD = int(sys.argv[sys.argv.index("--pad") + 1])
+        if "--split-max" in sys.argv:
+            global SPLIT_MAX
+            SPLIT_MAX = int(sys.argv[sys.argv.index("--split-max") + 1])
+        Path(sys.argv[sys.argv.index("--out") + 1]).write_text(render(emit_all()))
+        return
+    TIMING = True
+    timing_text = render(emit_all())
+    TIMING = False
     a = emit_all()
     text, clob = render(a), render_clobbers()
     if "--check" in sys.argv:
-        if not OUT.exists() or OUT.read_text() != text or not OUT_CLOB.exists() or OUT_CLOB.read_text() != clob:
-            print(f"{OUT} is stale: run python scripts/gen_attn_pw.py", file=sys.stderr)
+        stale = [f for f, t in ((OUT, text), (OUT_CLOB, clob), (OUT_TIMING, timing_text)) if not f.exists() or f.read_text() != t]
+        if stale:
+            print(f"stale: {[str(f) for f in stale]}: run python scripts/gen_attn_pw.py", file=sys.stderr)
             sys.exit(1)
         return
     OUT.write_text(text)
     OUT_CLOB.write_text(clob)
+    OUT_TIMING.write_text(timing_text)
     print(f"{OUT}: {len(a.lines)} lines", file=sys.stderr)
 
 

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""row_mode 1 vs 5 with query / key weights x6 (reference moves on most tiles): pw_peaked.py B T [scale]"""
+import sys
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+from voice_activity_detection_amd import SelfAttentiveVAD, seeded_features, seeded_state_dict
+B, T = int(sys.argv[1]), int(sys.argv[2])
+sc = float(sys.argv[3]) if len(sys.argv) > 3 else 6.0
+st = {k: v.copy() for k, v in seeded_state_dict(1234).items()}
+for l in range(3):
+    st[f"encoder.layers.{l}.self_attention.query_projection.weight"] *= sc
+    st[f"encoder.layers.{l}.self_attention.key_projection.weight"] *= sc
+m = SelfAttentiveVAD(80, 3, 128, 0.5)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+m = m.cuda().eval(); m.precision = "bf16"
+x = torch.from_numpy(seeded_features(91, (B, T, 80))).cuda()
+ys = {}
+for mode in (1, 5):
+    m.row_mode = mode
+    with torch.no_grad(): ys[mode] = m(features=x).clone()
+d = (ys[1] - ys[5]).abs().amax(dim=2).cpu().numpy()
+for b in range(B):
+    bad = np.nonzero(d[b] > 0)[0]
+    print(f"x{sc} T={T} seq {b}: {len(bad)} frames differ", (bad[:6].tolist(), bad[-6:].tolist()) if len(bad) else "", "max", d[b].max(), "finite", bool(torch.isfinite(ys[5]).all()))

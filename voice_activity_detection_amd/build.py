@@ -9,7 +9,8 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 SRC = PKG / "csrc" / "savad.hip"
-DEPS = sorted((PKG / "csrc").glob("*.h")) + sorted((PKG / "csrc").glob("*.hip")) + [PKG.parent / "include" / "savad.h"]
+DEPS = (sorted((PKG / "csrc").glob("*.h")) + sorted((PKG / "csrc").glob("*.hip")) + sorted((PKG / "csrc").glob("*.inc")) +
+        [PKG.parent / "include" / "savad.h"])
 LIB = PKG / "libsavad.so"
 
 
