@@ -84,7 +84,8 @@ S_DLDS = 74                    # dma: LDS byte address it goes to (+ this wave's
 S_DSTREAM = 75                 # dma: stream stage counter
 S_KS = 76                      # LDS byte offset of the stage behind the compute stage (K reads)
 S_CNT = 77                     # 'mid' stages left in the item
-S_QSRC, S_QSRCB = 78, 80       # 64 bit each: Q fragments of blocks A / B of the NEXT item
+S_DBASE = 78                   # dma: LDS base the ring slot offset is added to (this wave's share; moved once the stream is exhausted)
+S_TD = 79                      # dma: scratch of the in-gap stream advance
 S_CDST, S_CDSTB = 82, 84       # 64 bit each: ctx destination of blocks A / B of the finished item
 S_FLAGS = 86                   # current item: bit 0 wave has a block, bit 1 it has two, bit 2 feature-split tail item
 S_PEND = 87                    # finished item waiting for its stores: bits as S_FLAGS
@@ -317,25 +318,32 @@ def emit_dma_item_setup(a):
 
 def dma_slot_ops():
     """the next stage of the stream goes to the next ring slot"""
-    return [f"s_add_u32 {sr(S_DSTREAM)}, {sr(S_DSTREAM)}, 1", f"s_and_b32 {sr(S_T0)}, {sr(S_DSTREAM)}, {NRING - 1}",
-            f"s_lshl_b32 {sr(S_T0)}, {sr(S_T0)}, 15", f"s_add_u32 {sr(S_DLDS)}, {sr(S_LDSW)}, {sr(S_T0)}"]
+    return [f"s_add_u32 {sr(S_DSTREAM)}, {sr(S_DSTREAM)}, 1", f"s_and_b32 {sr(S_TD)}, {sr(S_DSTREAM)}, {NRING - 1}",
+            f"s_lshl_b32 {sr(S_TD)}, {sr(S_TD)}, 15", f"s_add_u32 {sr(S_DLDS)}, {sr(S_DBASE)}, {sr(S_TD)}"]
+
+
+def dma_advance_ops(a):
+    """after both halves of a stage have been issued.  A list of items that may be placed in MFMA gaps (each item
+    keeps its SCC producer and consumer together).  The in-line part ALWAYS runs: sources += one stage, next ring slot;
+    when the item's last stage has been issued, an out-of-line call first points the sources one stage in front of the
+    next item's first stage -- or, once the stream is exhausted, keeps them where they are and moves the LDS base so
+    that the ring arithmetic lands in the dump slot."""
+    stub, back = a.uniq("dstub"), a.uniq("dback")
+    a.tail += [stub + ":", f"\ts_call_b64 {sr(S_RET, 2)}, .Lpw_dma_next_item", f"\ts_branch {back}"]
+    return [f"s_add_u32 {sr(S_DS)}, {sr(S_DS)}, 1\n\ts_cmp_ge_u32 {sr(S_DS)}, {sr(S_NST)}\n\ts_cbranch_scc1 {stub}\n{back}:",
+            f"s_add_u32 {sr(S_DKS)}, {sr(S_DKS)}, {2 * BLK}\n\ts_addc_u32 {sr(S_DKS + 1)}, {sr(S_DKS + 1)}, 0",
+            f"s_add_u32 {sr(S_DVS)}, {sr(S_DVS)}, {2 * BLK}\n\ts_addc_u32 {sr(S_DVS + 1)}, {sr(S_DVS + 1)}, 0"] + dma_slot_ops()
 
 
 def emit_dma_advance(a):
-    """after both halves of a stage have been issued: the common case (next stage of the same item) in line, the switch
-    to the next item (or to the dump slot once the stream is exhausted) out of line"""
-    stub, back = a.uniq("dstub"), a.uniq("dback")
-    a.i(f"s_add_u32 {sr(S_DS)}, {sr(S_DS)}, 1")
-    a.i(f"s_cmp_ge_u32 {sr(S_DS)}, {sr(S_NST)}")
-    a.i(f"s_cbranch_scc1 {stub}")
-    a.i(f"s_add_u32 {sr(S_DKS)}, {sr(S_DKS)}, {2 * BLK}")
-    a.i(f"s_addc_u32 {sr(S_DKS + 1)}, {sr(S_DKS + 1)}, 0")
-    a.i(f"s_add_u32 {sr(S_DVS)}, {sr(S_DVS)}, {2 * BLK}")
-    a.i(f"s_addc_u32 {sr(S_DVS + 1)}, {sr(S_DVS + 1)}, 0")
-    for op in dma_slot_ops():
+    for op in dma_advance_ops(a):
         a.i(op)
-    a.label(back)
-    a.tail += [stub + ":", f"\ts_call_b64 {sr(S_RET, 2)}, .Lpw_dma_next_item", f"\ts_branch {back}"]
+
+
+def emit_back_one_stage(a):
+    for r in (S_DKS, S_DVS):
+        a.i(f"s_sub_u32 {sr(r)}, {sr(r)}, {2 * BLK}")
+        a.i(f"s_subb_u32 {sr(r + 1)}, {sr(r + 1)}, 0")
 
 
 def emit_dma_next_item_sub(a):
@@ -347,11 +355,15 @@ def emit_dma_next_item_sub(a):
     a.i(f"s_cmp_eq_u32 {sr(S_DC + 3)}, 0")
     a.i(f"s_cbranch_scc1 {l_dump}")
     emit_dma_item_setup(a)
-    for op in dma_slot_ops():
-        a.i(op)
+    emit_back_one_stage(a)
     a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
-    a.label(l_dump)   # stream exhausted: same cadence, harmless destination, last valid sources
-    a.i(f"s_add_u32 {sr(S_DLDS)}, {sr(S_LDSW)}, {DUMP}")
+    a.label(l_dump)   # stream exhausted: same cadence, harmless destination, the last valid sources again
+    emit_back_one_stage(a)
+    a.i(f"s_add_u32 {sr(S_TD)}, {sr(S_DSTREAM)}, 1")
+    a.i(f"s_and_b32 {sr(S_TD)}, {sr(S_TD)}, {NRING - 1}")
+    a.i(f"s_lshl_b32 {sr(S_TD)}, {sr(S_TD)}, 15")
+    a.i(f"s_add_u32 {sr(S_DBASE)}, {sr(S_LDSW)}, {DUMP}")
+    a.i(f"s_sub_u32 {sr(S_DBASE)}, {sr(S_DBASE)}, {sr(S_TD)}")
     a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
 
 
@@ -392,15 +404,15 @@ def emit_q_request(a):
     a.i(f"s_bitcmp1_b32 {sr(S_NFLAGS)}, 0")
     a.i(f"s_cbranch_scc0 {l_skip}")
     a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_NSEQBLK)}, {sr(S_NQA)}")
-    emit_block_addr(a, S_QSRC, S_QF, S_T3, S_T2, S_T1)
-    a.i(f"s_bitcmp1_b32 {sr(S_NFLAGS)}, 1")
-    a.i(f"s_cselect_b32 {sr(S_T0)}, 1, 0")                 # block B = A + 1 when it exists, else A again
-    a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_T3)}, {sr(S_T0)}")
-    emit_block_addr(a, S_QSRCB, S_QF, S_T3, S_T2, S_T1)
-    for blk, src in (("A", S_QSRC), ("B", S_QSRCB)):
+    for blk in ("A", "B"):
+        if blk == "B":
+            a.i(f"s_bitcmp1_b32 {sr(S_NFLAGS)}, 1")
+            a.i(f"s_cselect_b32 {sr(S_T0)}, 1, 0")             # block B = A + 1 when it exists, else A again
+            a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_T3)}, {sr(S_T0)}")
+        emit_block_addr(a, S_T4, S_QF, S_T3, S_T2, S_T1)
         for f in range(8):
             dst = V_QS + (0 if blk == "A" else 32) + 4 * f
-            a.i(f"global_load_dwordx4 {vr(dst, 4)}, {vr(V_OFF[f // 4])}, {sr(src, 2)} offset:{(f % 4) * FRAG}")
+            a.i(f"global_load_dwordx4 {vr(dst, 4)}, {vr(V_OFF[f // 4])}, {sr(S_T4, 2)} offset:{(f % 4) * FRAG}")
     a.label(l_skip)
 
 
@@ -444,7 +456,7 @@ def rotate_ops(tail):
     ops = [f"v_mov_b32 {vr(V_ADDR_V)}, {vr(V_ADDR_K)}", f"s_add_u32 {sr(S_KS)}, {sr(S_KS)}, {STAGE}",
            f"s_and_b32 {sr(S_KS)}, {sr(S_KS)}, {NRING * STAGE - 1}", f"v_add_u32 {vr(V_ADDR_K)}, {sr(S_KS)}, {vr(V_LDSL)}"]
     if tail:
-        ops += [f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11", f"v_add_u32 {vr(V_ADDR_VT)}, {sr(S_T0)}, {vr(V_ADDR_V)}"]
+        ops += [f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11\n\tv_add_u32 {vr(V_ADDR_VT)}, {sr(S_T0)}, {vr(V_ADDR_V)}"]
     return ops
 
 
@@ -452,6 +464,7 @@ def emit_stage_top(a):
     """own share of the stage behind the compute stage landed (the 8 newest requests are the stage after that), then
     everybody's; afterwards the slot of the stage before the compute stage may be refilled"""
     a.i("s_waitcnt vmcnt(8)")
+    stamp(a, 3)
     if not ABLATE & 2:
         a.i("s_barrier")
     a.i(f"s_cmp_lg_u32 {sr(S_QPEND)}, 0")
@@ -546,8 +559,9 @@ def emit_step(a, par, has_next, vblk, kblk_next, tail, dma, book, force):
         if tail and not ABLATE & 128:  # only 2 - 4 MFMAs separate the last score MFMA from its first reader
             seq = ["s_nop 7", "s_nop 7"] + seq
         spread(gaps, seq, second[0], second[1])
-    if not ABLATE & 1:
-        spread(gaps, dma, second[0], second[1])
+    if ABLATE & 1:
+        dma = [op for op in dma if not (op.startswith("global_load_lds") or "m0" in op)]
+    spread(gaps, dma, second[0], second[1])
     spread(gaps, book, second[0], second[1])
     a.i("s_waitcnt lgkmcnt(0)")       # K(i+1) fragments, requested one phase ago
     for op in pre:
@@ -578,22 +592,20 @@ def emit_stage(a, kind, tail):
     emit_stage_top(a)
     stamp(a, 2)
     kh, vh = dma_half_ops(0), dma_half_ops(1)
+    c_even, c_odd, c_last = (4, 5, 6) if not tail else (20, 21, 22)
     if kind == "mid":
         emit_step(a, 0, True, 0, 0, tail, kh, fo_ops(), S_FE)
-        stamp(a, 4)
-        emit_step(a, 1, True, BLK, BLK, tail, vh, rotate_ops(tail) + [f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"], S_FO)
-        emit_dma_advance(a)
-        stamp(a, 5)
+        stamp(a, c_even)
+        emit_step(a, 1, True, BLK, BLK, tail, vh + dma_advance_ops(a), rotate_ops(tail) + [f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"], S_FO)
+        stamp(a, c_odd)
     elif kind == "last2":
         emit_step(a, 0, True, 0, None, tail, kh, [], S_FE)
-        stamp(a, 4)
-        emit_step(a, 1, False, BLK, None, tail, vh, rotate_ops(tail), S_FO)
-        emit_dma_advance(a)
-        stamp(a, 6)
+        stamp(a, c_even)
+        emit_step(a, 1, False, BLK, None, tail, vh + dma_advance_ops(a), rotate_ops(tail), S_FO)
+        stamp(a, c_last)
     else:
-        emit_step(a, 0, False, 0, None, tail, kh + vh, rotate_ops(tail), S_FE)
-        emit_dma_advance(a)
-        stamp(a, 6)
+        emit_step(a, 0, False, 0, None, tail, kh + vh + dma_advance_ops(a), rotate_ops(tail), S_FE)
+        stamp(a, c_last)
 
 
 # ------------------------------------------------------------------------------------------------ cold path
@@ -812,6 +824,10 @@ def emit_all():
         a.i(f"s_memtime {sr(S_TM, 2)}")
         a.i("s_waitcnt lgkmcnt(0)")
         a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 31")
+        a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 16")       # lanes 16 / 17: shader clock at entry / exit
+        a.i(f"s_memrealtime {sr(S_TM, 2)}")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 18")       # lanes 18 / 19: 100 MHz clock at entry / exit
     # ---- derived constants
     a.i(f"s_add_u32 {sr(S_QB)}, {sr(S_T)}, 31")
     a.i(f"s_lshr_b32 {sr(S_QB)}, {sr(S_QB)}, 5")
@@ -842,6 +858,7 @@ def emit_all():
     a.i(f"s_mov_b32 {sr(S_QPEND)}, 0")
     a.i(f"s_mov_b32 {sr(S_DSTREAM)}, 0")
     a.i(f"s_mov_b32 {sr(S_DLDS)}, {sr(S_LDSW)}")
+    a.i(f"s_mov_b32 {sr(S_DBASE)}, {sr(S_LDSW)}")
     # ---- cursors
     a.i(f"s_mov_b32 {sr(S_DC + 1)}, {sr(S_CC + 1)}")
     a.i(f"s_mov_b32 {sr(S_DC + 2)}, {sr(S_CC + 2)}")
@@ -917,6 +934,12 @@ def emit_all():
     stamp(a, 10)
     if TIMING:  # wave 0 of workgroup 0 publishes its counters
         l_nopub = a.uniq("nopub")
+        a.i(f"s_memtime {sr(S_TM, 2)}")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 17")
+        a.i(f"s_memrealtime {sr(S_TM, 2)}")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 19")
         a.i(f"s_or_b32 {sr(S_T0)}, {sr(S_XCD)}, {sr(S_J)}")
         a.i(f"s_or_b32 {sr(S_T0)}, {sr(S_T0)}, {sr(S_W)}")
         a.i(f"s_cmp_lg_u32 {sr(S_T0)}, 0")

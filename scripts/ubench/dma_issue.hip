@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256, 1) void k(const char* src, long long* cyc, int
     const char* s = src + (size_t)blockIdx.x * 65536 + w * 4096;
     const unsigned v1 = lane16 + 1024, v2 = lane16 + 2048, v3 = lane16 + 3072;
     const unsigned la = (unsigned)(size_t)smem + lane16;
+    long long r0 = __builtin_amdgcn_s_memrealtime();
     long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
         const char* sp = s + (size_t)(it & 63) * 16384 * 256;  // walks 256 MB: HBM / MALL traffic as in the real kernel
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256, 1) void k(const char* src, long long* cyc, int
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     long long t1 = __builtin_readcyclecounter();
     asm volatile("" ::: "a0", "a15", "a31", "a47", "a63", "a95");
-    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = r1 - r0; }
     if (sink && threadIdx.x == 12345) sink[0] = smem[lane16];
 }
 
@@ -86,14 +88,14 @@ __global__ void where(const unsigned* src, unsigned* out) {
 template <int MODE>
 void run(const char* name, const char* src, long long* cyc) {
     hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    const int iters = 2000;
+    const int iters = 20000;
     k<MODE><<<256, 256, 131072>>>(src, cyc, 200, nullptr);
     hipDeviceSynchronize();
     k<MODE><<<256, 256, 131072>>>(src, cyc, iters, nullptr);
     hipDeviceSynchronize();
-    long long c = 0;
-    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    printf("%-64s %8.1f cycles per 32 MFMAs (%5.2f per MFMA)\n", name, (double)c / iters, (double)c / iters / 32);
+    long long c[2] = {0, 0};
+    hipMemcpy(c, cyc, 16, hipMemcpyDeviceToHost);
+    printf("%-64s %8.1f cycles per 32 MFMAs (%5.2f per MFMA)  clock %.0f MHz\n", name, (double)c[0] / iters, (double)c[0] / iters / 32, (double)c[0] / (double)c[1] * 100.0);
 }
 
 int main() {
@@ -101,7 +103,7 @@ int main() {
     long long* cyc;
     hipMalloc(&src, (size_t)512 << 20);
     hipMemset(src, 0, (size_t)512 << 20);
-    hipMalloc(&cyc, 8);
+    hipMalloc(&cyc, 16);
     {
         std::vector<unsigned> h(4096);
         for (int i = 0; i < 4096; ++i) h[i] = i;

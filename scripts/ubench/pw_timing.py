@@ -10,7 +10,7 @@ m = SelfAttentiveVAD(80, 3, 128, 0.5)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()})
 m = m.cuda().eval(); m.precision = "bf16"; m.row_mode = 5
 x = torch.from_numpy(seeded_features(1, (B, T, 80))).cuda()
-for _ in range(4): m(x)
+for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 600): m(x)   # long enough for the clocks to ramp
 torch.cuda.synchronize()
 lib = _lib.load()
 lib.savad_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
@@ -18,9 +18,11 @@ buf = (ctypes.c_longlong * 16)()
 lib.savad_debug_stamps(buf, 16)
 w = []
 for v in buf: w += [v & 0xffffffff, (v >> 32) & 0xffffffff]
-names = {0: "kernel prologue / between items", 1: "item prologue (Q copy, S(0), first reference)", 2: "wait + barrier", 3: "post-barrier block + addresses",
-         4: "even step", 5: "odd step (+ DMA advance)", 6: "last step of an item", 8: "item epilogue", 9: "idle stages", 10: "tail", 11: "stage dispatch"}
+names = {0: "kernel prologue / between items", 1: "item prologue (Q copy, S(0), first reference)", 2: "barrier", 3: "vmcnt(8) wait",
+         4: "even step", 5: "odd step", 23: "DMA advance", 6: "last step of an item", 20: "tail item: even step", 21: "tail item: odd step", 22: "tail item: last step", 8: "item epilogue", 9: "idle stages", 10: "tail", 11: "stage dispatch"}
 tot = sum(w[c] for c in names)
+cyc, rt = (w[17] - w[16]) & 0xffffffff, (w[19] - w[18]) & 0xffffffff
+print(f"wave 0 of WG 0: {cyc} shader cycles in {rt / 100.0:.1f} us -> {cyc / max(rt, 1) * 100:.0f} MHz")
 print("cold calls buf0/buf1/first:", w[12], w[13], w[14], "blocks moved:", w[15])
 print(f"B={B} T={T}: wave 0 of WG 0, cycles per category (total {tot}):")
 for c, n in names.items(): print(f"  {n:48s} {w[c]:9d}  {100.0 * w[c] / max(tot, 1):5.1f} %")
