@@ -70,7 +70,6 @@ S_RET = 24                     # s[24:25]: return address of the out-of-line sub
 S_SEQBLK, S_NSEQBLK = 26, 27   # first block (block space) of the current / next item's sequence
 S_VALID = {"A": 28, "B": 29}   # rows of block A / B that exist (T - 32 qb)
 S_NFLAGS, S_NQA = 30, 31       # the NEXT item (the compute cursor is advanced at the start of an item)
-S_RAGODD, S_RAGEVEN = 34, 35   # T % 32 when QB is odd / even, else 0
 S_QF, S_KF, S_VTF, S_CTXF = 36, 38, 40, 42
 S_RAG, S_T, S_QB, S_NST, S_NGF, S_TAILQ = 44, 45, 46, 47, 48, 49
 S_XCD, S_J, S_BX, S_STRIDE, S_DQ, S_DR = 50, 51, 52, 53, 54, 55
@@ -92,8 +91,6 @@ S_PEND = 87                    # finished item waiting for its stores: bits as S
 S_QPEND = 88                   # 1: the once-per-item block (stores, Q request) still has to run behind a barrier
 S_T0, S_T1, S_T2, S_T3, S_T4, S_T5 = 89, 90, 91, 94, 92, 93   # s[S_T4:S_T5] is used as a 64-bit pair
 S_LDSW = 95                    # LDS base + w * 4096
-S_FE, S_FO = 96, 98            # 64 bit each: all ones when the tile checked at the end of an even / odd step must take the
-                               # cold path (ragged last key block)
 S_TM = 58                      # timing builds: s[58:59]
 TIMING = False
 PAD = 0              # experiments: s_nop 0 instructions in front (shifts the stream by 4 bytes each)
@@ -102,6 +99,9 @@ SPLIT_MAX = 2   # tail groups of up to this many query blocks are feature-split 
 ABLATE = 0   # experiments (results WRONG): 1 no DMA pieces, 2 no barrier, 4 no row maxima / reference check, 8 no exp / sum / pack,
              # 16 no LDS operand reads
 
+CHECK_BITS = "0x47700000"      # 61440.0 = 0.9375 * 2^16: a row whose maximum exceeds the reference by MORE than 2^16 has an
+                               # exponential >= 2^16 (1 - ulp) in its sum, whatever v_exp_f32 rounds to: the check is a strict
+                               # superset of online_softmax_shifted()'s own test, which the out-of-line path then applies exactly
 NEG_BIG_BITS = 0xF149F2CA      # -1.0e30f
 BLK, FRAG, STAGE, NRING = 8192, 1024, 32768, 4
 DUMP = NRING * STAGE           # LDS offset of the stage nobody reads: once the stream is exhausted the DMA keeps its
@@ -482,27 +482,19 @@ def spread(gaps, ops, lo, hi):
         gaps[lo + (k * n) // len(ops)].append(op)
 
 
-def emit_step(a, par, has_next, vblk, kblk_next, tail, dma, book, force):
-    """Key block i (parity par: its scores sit in buffer par; the next tile's go to 1 - par).
-    has_next : S^T(i+1) is computed (K(i+1) fragments are in a[192:223]) and its row maxima are checked at the end
-    vblk     : LDS offset of V^T(i) inside the compute stage (0 / 8192)
-    kblk_next: LDS offset of K(i+2) inside the stage behind it, or None
-    tail     : 0 ordinary item (blocks A, B, four feature blocks each); 1 / 2 feature-split item with block A / A and B
-               (this wave's feature block only: two V^T fragments, two PV MFMAs per block)
-    dma      : list of single instructions (M0 writes and pieces) issued in the second half of the step
-    book     : list of single bookkeeping instructions (SALU / address VALU) issued in the second half of the step
-    force    : register pair that forces the cold path for tile i+1"""
-    cur, nxt = par, 1 - par
-    blocks = ("A",) if tail == 1 else ("A", "B")
-    mf, seg = [], {}
-    seg["S"] = (0, 0)
-    if has_next:
-        for ks in range(8):
-            for blk in blocks:
-                mf.append(mfma_s(nxt, blk, ks))
-        seg["S"] = (0, len(mf))
+def softmax_split(buf, blk):
+    """softmax_ops(buf, blk) in three groups: exponentials + row sum (what the reference check needs), bf16 packing,
+    and the update of the running row sum (which must wait for the check)"""
+    ops = softmax_ops(buf, blk)
+    pack = [op for op in ops if op.startswith("v_cvt_pk")]
+    lsum = [ops[-1]]
+    head = [op for op in ops[:-1] if not op.startswith("v_cvt_pk")]
+    return head, pack, lsum
+
+
+def pv_mfmas(blocks, tail):
+    mf = []
     for blk in blocks:
-        lo = len(mf)
         if tail:
             for j in range(2):
                 O = A_O[blk]
@@ -511,163 +503,244 @@ def emit_step(a, par, has_next, vblk, kblk_next, tail, dma, book, force):
             for j in range(2):
                 for nbd in range(4):
                     mf.append(mfma_pv(blk, nbd, j))
-        seg[blk] = (lo, len(mf))
-    if "B" not in seg:
-        seg["B"] = seg["A"]
-    N = len(mf)
-    gaps = [[] for _ in range(N)]
-    pre = []   # fillers with no MFMA to hide behind (last step of an item: no S segment)
-    sS, sA, sB = seg["S"], seg["A"], seg["B"]
-    # V^T(i) fragments, in the order the PV MFMAs consume them
+    return mf
+
+
+def emit_step(a, i_par, has_prev, has_next, tail, dma, book):
+    """Key block i (parity i_par: its scores sit in buffer i_par; the next tile's go to the other one).  Two-stage
+    pipeline: the step issues  [O^T += V^T(i-1) P^T(i-1)]  (has_prev)  then  [S^T(i+1) = K(i+1) Q^T]  (has_next)  while the
+    VALU works through tile i: exponentials, row sums, bf16 packing -- nothing the MFMAs of this step wait for.
+      first half   beside the PV MFMAs : K(i+1) fragment reads, exponentials of both blocks, row sum of block A
+      second half  beside the S^T MFMAs: V^T(i) fragment reads, row sum of block B, packing (P(i-1) has been consumed),
+                                         DMA pieces, stream advance, address rotation, the reference check
+    tail: 0 ordinary item; 1 / 2 feature-split item with block A / A and B (this wave's feature block only)."""
+    cur, nxt = i_par, 1 - i_par
+    blocks = ("A",) if tail == 1 else ("A", "B")
+    mfP = pv_mfmas(blocks, tail) if has_prev else []
+    mfS = []
+    if has_next:
+        for ks in range(8):
+            for blk in blocks:
+                mfS.append(mfma_s(nxt, blk, ks))
+    mf = mfP + mfS
+    nP, N = len(mfP), len(mfP) + len(mfS)
+    gaps = [[] for _ in range(max(N, 1))]
+    # LDS reads: K(i+1) = second block of the compute stage (i even) or first block of the stage behind it (i odd)
+    kr = [kread(f, V_ADDR_V, BLK) if i_par == 0 else kread(f, V_ADDR_K, 0) for f in range(8)] if has_next else []
+    vblk = BLK * i_par
     if tail:
         vr_ops = [f"ds_read_b128 {ar(A_V + 4 * j, 4)}, {vr(V_ADDR_VT)} offset:{16384 + vblk + j * FRAG}" for j in range(2)]
     else:
         vr_ops = [vread(f, vblk) for f in (0, 2, 4, 6, 1, 3, 5, 7)]
-    sm = {blk: softmax_ops(cur, blk) for blk in blocks}
-    if ABLATE & 8:
-        sm = {blk: [] for blk in blocks}
     if ABLATE & 16:
-        vr_ops = []
-    if sS[1] > sS[0]:
-        spread(gaps, vr_ops, sS[0], sS[0] + max(1, (sS[1] - sS[0]) // 2))
-        spread(gaps, sm["A"], sS[0], sS[1] - 1 if len(blocks) == 2 else sS[1])
-        if len(blocks) == 2:
-            spread(gaps, sm["B"][:16], (sS[0] + sS[1]) // 2, sS[1])
-            spread(gaps, sm["B"][16:], sA[0], sA[1])
+        kr, vr_ops = [], []
+    head, pack, lsum = {}, {}, {}
+    for blk in blocks:
+        head[blk], pack[blk], lsum[blk] = softmax_split(cur, blk)
+        if ABLATE & 8:
+            head[blk], pack[blk], lsum[blk] = [], [], []
+    exps = {blk: head[blk][:16] for blk in blocks}
+    adds = {blk: head[blk][16:] for blk in blocks}
+    one, two = [], []       # VALU work of the first / second half, in order
+    if len(blocks) == 2:
+        for k in range(len(exps["A"])):
+            one += [exps["A"][k], exps["B"][k]]
+        one += adds["A"]
+        two += adds["B"]
     else:
-        pre += vr_ops + sm["A"]
+        one += exps["A"]
+        two += adds["A"]
+    for blk in blocks:
+        two += pack[blk]
+    check = []
+    if not ABLATE & 4 and head["A"]:
         if len(blocks) == 2:
-            pre += sm["B"][:16]
-            spread(gaps, sm["B"][16:], sA[0], sA[1])
-    second = (sB[0], sB[1]) if len(blocks) == 2 and not tail else (sA[0] + (sA[1] - sA[0]) // 2, N)
-    if kblk_next is not None and not ABLATE & 16:
-        # (before `second`: the bookkeeping there rotates the address register these reads use)
-        spread(gaps, [kread(f, V_ADDR_K, kblk_next) for f in range(8)], sA[0], max(sA[0] + 1, second[0]) if tail else sA[1])
-    check = has_next and not ABLATE & 4
-    if check:
-        seq = []
-        mx = [max_ops(nxt, blk, V_MX[blk]) for blk in blocks]
-        for k in range(8):
-            for m in mx:
-                seq.append(m[k])
-        if len(blocks) == 2:
-            seq.append(f"v_max_f32 {vr(V_T1)}, {vr(V_MX['A'])}, {vr(V_MX['B'])}")
+            check.append(f"v_max_f32 {vr(V_T1)}, {vr(V_RS['A'])}, {vr(V_RS['B'])}")
+            check.append(f"v_cmp_nge_f32 vcc, {CHECK_BITS}, {vr(V_T1)}")      # !(threshold >= largest row sum)
         else:
-            seq.append(f"v_mov_b32 {vr(V_T1)}, {vr(V_MX['A'])}")
-        seq += half_exchange(V_T1, V_T0, "v_max_f32")
-        seq.append(f"v_cmp_lt_f32 vcc, 0x41800000, {vr(V_T1)}")
-        if tail and not ABLATE & 128:  # only 2 - 4 MFMAs separate the last score MFMA from its first reader
-            seq = ["s_nop 7", "s_nop 7"] + seq
-        spread(gaps, seq, second[0], second[1])
+            check.append(f"v_cmp_nge_f32 vcc, {CHECK_BITS}, {vr(V_RS['A'])}")
+    two += check
     if ABLATE & 1:
         dma = [op for op in dma if not (op.startswith("global_load_lds") or "m0" in op)]
-    spread(gaps, dma, second[0], second[1])
-    spread(gaps, book, second[0], second[1])
-    a.i("s_waitcnt lgkmcnt(0)")       # K(i+1) fragments, requested one phase ago
-    for op in pre:
-        a.i(op)
+    a.i("s_waitcnt lgkmcnt(0)")       # V^T(i-1) fragments (requested in the previous step)
+    pre = []
+    if nP >= 4:
+        # the last MFMA of S^T(i) was issued at the very end of the previous step: its readers start 2 MFMAs in
+        spread(gaps, kr, 0, max(1, nP // 2))
+        spread(gaps, one, 2, nP)
+    elif nP > 0:   # feature-split items: 2 PV MFMAs
+        pre = ["s_nop 7", "s_nop 7"] if has_prev else []
+        spread(gaps, kr, 0, nP)
+        spread(gaps, one, 0, nP)
+    else:
+        pre = kr + one
+    if N - nP > 0:
+        spread(gaps, vr_ops, nP, nP + max(1, (N - nP) // 2))
+        spread(gaps, two, nP, N)
+        spread(gaps, dma, nP, N)
+        spread(gaps, book, nP + (N - nP) // 2, N)
+        post = []
+    else:
+        post = vr_ops + two + dma + book
     for n in range(N):
-        if n == sA[0]:
-            a.i("s_waitcnt lgkmcnt(0)")  # V^T(i) fragments
+        if n == 0:
+            for op in pre:
+                a.i(op)
+        if n == nP and has_next:
+            a.i("s_waitcnt lgkmcnt(0)")  # K(i+1) fragments
         a.i(mf[n])
         for op in gaps[n]:
             a.i(op)
-    if check and not ABLATE & 64:
-        a.i(f"s_or_b64 {sr(S_T4, 2)}, vcc, {sr(force, 2)}")
-        a.ool_call(f".Lpw_cold_{nxt}" if tail != 1 else f".Lpw_cold1_{nxt}")
+    if N == 0:
+        for op in pre:
+            a.i(op)
+    for op in post:
+        a.i(op)
+    if check:
+        a.i("s_nop 4")   # (VALU wrote VCC just before: nothing documents that the SALU read waits for it)
+        a.i("s_cmp_lg_u64 vcc, 0" if not ABLATE & 256 else "s_cmp_eq_u32 0, 0")   # (256: always take the cold path)
+        a.ool_call(f".Lpw_coldmid_{cur}_{int(has_next)}_{len(blocks)}")
+    for blk in blocks:
+        for op in lsum[blk]:
+            a.i(op)
 
 
-def fo_ops():
-    """S_FO = all ones when the tile checked at the end of the stage's odd step (STEP + 2) is the ragged last one:
-    only in the last 'mid' stage of an item with an odd number of key blocks"""
-    # (SCC producer and consumer stay together: other SALU instructions may be placed between the items of this list)
-    return [f"s_cmp_eq_u32 {sr(S_CNT)}, 1\n\ts_cselect_b32 {sr(S_T0)}, {sr(S_RAGODD)}, 0",
-            f"s_cmp_lg_u32 {sr(S_T0)}, 0\n\ts_cselect_b64 {sr(S_FO, 2)}, -1, 0"]
+def emit_drain(a, tail):
+    """O^T += V^T P^T of the item's last tile"""
+    blocks = ("A",) if tail == 1 else ("A", "B")
+    a.i("s_waitcnt lgkmcnt(0)")
+    for op in pv_mfmas(blocks, tail):
+        a.i(op)
 
 
-def emit_stage(a, kind, tail):
-    """kind: 'mid' (two steps, both followed by another tile), 'last2' (QB even: the second step is the item's last),
-    'last1' (QB odd: a single step, the item's last).  Every stage: one barrier, 8 DMA pieces, one stream advance."""
-    stamp(a, 11)
-    emit_stage_top(a)
-    stamp(a, 2)
-    kh, vh = dma_half_ops(0), dma_half_ops(1)
-    c_even, c_odd, c_last = (4, 5, 6) if not tail else (20, 21, 22)
-    if kind == "mid":
-        emit_step(a, 0, True, 0, 0, tail, kh, fo_ops(), S_FE)
-        stamp(a, c_even)
-        emit_step(a, 1, True, BLK, BLK, tail, vh + dma_advance_ops(a), rotate_ops(tail) + [f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"], S_FO)
-        stamp(a, c_odd)
-    elif kind == "last2":
-        emit_step(a, 0, True, 0, None, tail, kh, [], S_FE)
-        stamp(a, c_even)
-        emit_step(a, 1, False, BLK, None, tail, vh + dma_advance_ops(a), rotate_ops(tail), S_FO)
-        stamp(a, c_last)
-    else:
-        emit_step(a, 0, False, 0, None, tail, kh + vh + dma_advance_ops(a), rotate_ops(tail), S_FE)
-        stamp(a, c_last)
-
-
-# ------------------------------------------------------------------------------------------------ cold path
-def emit_cold(a, buf, first, blocks=("A", "B")):
-    """Reference move of the freshly computed score tile in buffer `buf` (scores relative to the current reference):
-    ragged last key block masked first; first = the item's first tile (reference := row maximum when it is more than
-    2^16 away from 0, nothing to rescale); otherwise O and l of rows whose maximum exceeds the reference by 2^16 are
-    rescaled.  Operation for operation online_softmax_shifted() of savad_kernels_bf16.h.  Entered with every MFMA
-    that wrote the tile (and, when not first, every PV MFMA) at least 8 MFMAs or 24 wait states behind."""
-    force = S_FE if buf == 1 or first else S_FO   # tile in buffer 1 is checked by an even step, buffer 0 by an odd step
-    l_nomask = a.uniq("nomask")
-    if TIMING:   # lane 12 + buf (14: first) counts the calls
-        c = 14 if first else 12 + buf
-        a.i(f"v_readlane_b32 {sr(S_TM)}, {vr(V_ACC)}, {c}")
-        a.i(f"s_add_u32 {sr(S_TM)}, {sr(S_TM)}, 1")
-        a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, {c}")
+def emit_mask(a, buf, blocks):
+    """ragged last key block (T % 32 != 0): scores of keys that do not exist -> -1e30 (lane (m, h), register r <-> key
+    8 (r >> 2) + 4 h + (r & 3)); the MFMAs that wrote the tile are at least 16 MFMAs behind"""
+    l_skip = a.uniq("nomask")
+    a.i(f"s_cmp_eq_u32 {sr(S_RAG)}, 0")
+    a.i(f"s_cbranch_scc1 {l_skip}")
+    a.i("s_nop 7")   # the MFMAs that wrote the tile were the last instructions of the previous step
     a.i("s_nop 7")
-    a.i("s_nop 7")
-    a.i("s_nop 7")
-    a.i(f"s_cmp_eq_u64 {sr(force, 2)}, 0")
-    a.i(f"s_cbranch_scc1 {l_nomask}")
-    # last tile: key 8(r>>2) + (r&3) of this lane exists iff it is < T%32 - 4h
     a.i(f"v_sub_u32 {vr(V_LIM)}, {sr(S_RAG)}, {vr(V_H4)}")
     for blk in blocks:
         S = V_S[(buf, blk)]
         for r in range(16):
             a.i(f"v_cmp_lt_i32 vcc, {8 * (r >> 2) + (r & 3)}, {vr(V_LIM)}")
             a.i(f"v_cndmask_b32 {vr(S + r)}, {vr(V_NEGB)}, {vr(S + r)}, vcc")
-    a.label(l_nomask)
-    for blk in blocks:
-        S = V_S[(buf, blk)]
-        l_skip = a.uniq("coldskip")
-        for op in max_ops(buf, blk, V_MX[blk]):
-            a.i(op)
-        for op in half_exchange(V_MX[blk], V_T0, "v_max_f32"):
-            a.i(op)
-        if first:
-            a.i(f"v_cmp_gt_f32 vcc, 0xc1800000, {vr(V_MX[blk])}")       # (first && mx < -16) ...
-            a.i(f"s_mov_b64 {sr(S_T4, 2)}, vcc")
-        a.i(f"v_cmp_lt_f32 vcc, 0x41800000, {vr(V_MX[blk])}")           # move = mx > 16 ...
-        if first:
-            a.i(f"s_or_b64 vcc, vcc, {sr(S_T4, 2)}")
-        a.i("s_cmp_eq_u64 vcc, 0")
-        a.i(f"s_cbranch_scc1 {l_skip}")
-        if TIMING:   # lane 15: blocks that really moved
-            a.i(f"v_readlane_b32 {sr(S_TM)}, {vr(V_ACC)}, 15")
-            a.i(f"s_add_u32 {sr(S_TM)}, {sr(S_TM)}, 1")
-            a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 15")
-        a.i(f"v_cndmask_b32 {vr(V_D)}, 0, {vr(V_MX[blk])}, vcc")       # d = move ? mx : 0
-        if not first:
-            a.i(f"v_exp_f32 {vr(V_AL)}, -{vr(V_D)}")
+    a.label(l_skip)
+
+
+def emit_stage(a, kind, tail):
+    """kind: 'fmid' (the item's first stage, steps 0 and 1, tile 2 exists), 'mid' (two steps in the middle), 'last2' (the
+    item's last two tiles), 'last1' (its last tile alone), 'flast2' (an item of two tiles).  Every stage: one barrier,
+    8 DMA pieces, one stream advance, one rotation of the ring addresses."""
+    stamp(a, 11)
+    emit_stage_top(a)
+    stamp(a, 2)
+    kh, vh = dma_half_ops(0), dma_half_ops(1)
+    c_even, c_odd, c_last = (4, 5, 6) if not tail else (20, 21, 22)
+    blocks = ("A",) if tail == 1 else ("A", "B")
+    odd_book = rotate_ops(tail)
+    if kind in ("mid", "fmid"):
+        emit_step(a, 0, kind == "mid", True, tail, kh, [])
+        stamp(a, c_even)
+        emit_step(a, 1, True, True, tail, vh + dma_advance_ops(a),
+                  odd_book + ([f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"] if kind == "mid" else []))
+        stamp(a, c_odd)
+    elif kind in ("last2", "flast2"):
+        emit_step(a, 0, kind == "last2", True, tail, kh, [])
+        stamp(a, c_even)
+        emit_mask(a, 1, blocks)
+        emit_step(a, 1, True, False, tail, vh + dma_advance_ops(a), odd_book)
+        stamp(a, c_last)
+    else:
+        emit_mask(a, 0, blocks)
+        emit_step(a, 0, True, False, tail, kh + vh + dma_advance_ops(a), odd_book)
+        stamp(a, c_last)
+
+
+# ------------------------------------------------------------------------------------------------ cold paths
+def emit_move(a, buf, blk, first, also_next, l_skip):
+    """online_softmax_shifted() of savad_kernels_bf16.h for one query block's tile in buffer `buf`: row maximum (both
+    halves); rows whose maximum exceeds the reference by 2^16 (first tile: is more than 2^16 away from 0) move their
+    reference there: d = move ? mx : 0; l and O scaled by 2^-d (not on the first tile: both are still zero), scores and
+    -reference shifted by d -- and the scores of the NEXT tile too when its MFMAs already ran against the old reference"""
+    S = V_S[(buf, blk)]
+    for op in max_ops(buf, blk, V_MX[blk]):
+        a.i(op)
+    for op in half_exchange(V_MX[blk], V_T0, "v_max_f32"):
+        a.i(op)
+    if first:
+        a.i(f"v_cmp_gt_f32 vcc, 0xc1800000, {vr(V_MX[blk])}")       # (first && mx < -16) ...
+        a.i(f"s_mov_b64 {sr(S_T4, 2)}, vcc")
+    a.i(f"v_cmp_lt_f32 vcc, 0x41800000, {vr(V_MX[blk])}")           # move = mx > 16 ...
+    if first:
+        a.i(f"s_or_b64 vcc, vcc, {sr(S_T4, 2)}")
+    a.i("s_cmp_eq_u64 vcc, 0")
+    a.i(f"s_cbranch_scc1 {l_skip}")
+    if TIMING:   # lane 15: blocks that really moved
+        a.i(f"v_readlane_b32 {sr(S_TM)}, {vr(V_ACC)}, 15")
+        a.i(f"s_add_u32 {sr(S_TM)}, {sr(S_TM)}, 1")
+        a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, 15")
+    a.i(f"v_cndmask_b32 {vr(V_D)}, 0, {vr(V_MX[blk])}, vcc")       # d = move ? mx : 0
+    if not first:
+        a.i(f"v_exp_f32 {vr(V_AL)}, -{vr(V_D)}")
+        a.i("s_nop 0")
+        a.i(f"v_mul_f32 {vr(V_L[blk])}, {vr(V_L[blk])}, {vr(V_AL)}")
+        for r in range(64):
+            a.i(f"v_accvgpr_read_b32 {vr(V_T2)}, {ar(A_O[blk] + r)}")
             a.i("s_nop 0")
-            a.i(f"v_mul_f32 {vr(V_L[blk])}, {vr(V_L[blk])}, {vr(V_AL)}")
-            for r in range(64):
-                a.i(f"v_accvgpr_read_b32 {vr(V_T2)}, {ar(A_O[blk] + r)}")
-                a.i("s_nop 0")
-                a.i(f"v_mul_f32 {vr(V_T2)}, {vr(V_T2)}, {vr(V_AL)}")
-                a.i(f"v_accvgpr_write_b32 {ar(A_O[blk] + r)}, {vr(V_T2)}")
-        for r in range(16):
-            a.i(f"v_sub_f32 {vr(S + r)}, {vr(S + r)}, {vr(V_D)}")
-        for r in range(16):
-            a.i(f"v_sub_f32 {vr(V_NEGM[blk] + r)}, {vr(V_NEGM[blk] + r)}, {vr(V_D)}")
+            a.i(f"v_mul_f32 {vr(V_T2)}, {vr(V_T2)}, {vr(V_AL)}")
+            a.i(f"v_accvgpr_write_b32 {ar(A_O[blk] + r)}, {vr(V_T2)}")
+    for r in range(16):
+        a.i(f"v_sub_f32 {vr(S + r)}, {vr(S + r)}, {vr(V_D)}")
+    for r in range(16):
+        a.i(f"v_sub_f32 {vr(V_NEGM[blk] + r)}, {vr(V_NEGM[blk] + r)}, {vr(V_D)}")
+    if also_next:   # the next tile's scores ran against the old reference: again, as the reference kernel would have
+        a.i("s_nop 1")  # computed them (K(i+1) is still in a[192:223]); C = the new -reference
+        for ks in range(8):
+            a.i(mfma_s(1 - buf, blk, ks))
+
+
+def emit_count(a, lane):
+    if TIMING:
+        a.i(f"v_readlane_b32 {sr(S_TM)}, {vr(V_ACC)}, {lane}")
+        a.i(f"s_add_u32 {sr(S_TM)}, {sr(S_TM)}, 1")
+        a.i(f"v_writelane_b32 {vr(V_ACC)}, {sr(S_TM)}, {lane}")
+
+
+def emit_cold_first(a):
+    """the item's first tile (buffer 0, both blocks): the reference is SET (nothing to rescale)"""
+    a.label(".Lpw_coldfirst_0")
+    emit_count(a, 14)
+    a.i("s_nop 7")
+    a.i("s_nop 7")
+    a.i("s_nop 7")
+    for blk in ("A", "B"):
+        l_skip = a.uniq("cfskip")
+        emit_move(a, 0, blk, True, False, l_skip)
+        a.label(l_skip)
+    a.i("s_nop 1")
+    a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
+
+
+def emit_cold_mid(a, cur, has_next, nblocks):
+    """A row sum of tile i (buffer cur) left 2^16 or is not a number: entered between the score MFMAs of tile i+1 and the
+    PV MFMAs of tile i, with the exponentials, row sums and block A's probabilities of tile i computed against the
+    standing reference and the running row sums not yet updated.  Per block: the exact test of online_softmax_shifted();
+    when a reference really moves, O / l / scores / -reference are brought to it (the next tile's scores too: they were
+    computed against the old one) and the block's exponentials, row sum and probabilities are redone."""
+    a.label(f".Lpw_coldmid_{cur}_{int(has_next)}_{nblocks}")
+    emit_count(a, 12 + cur)
+    a.i("s_nop 7")   # every MFMA of the next tile's scores (and every PV MFMA of the previous tile) has retired
+    a.i("s_nop 7")
+    a.i("s_nop 7")
+    for blk in ("A", "B")[:nblocks]:
+        l_skip = a.uniq("cmskip")
+        emit_move(a, cur, blk, False, has_next, l_skip)
+        head, pack, _ = softmax_split(cur, blk)
+        for op in head + pack:   # (block B's packing runs again behind the check: same values)
+            a.i(op)
         a.label(l_skip)
     a.i("s_nop 1")
     a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
@@ -695,13 +768,10 @@ def emit_item_prologue(a):
             for _ in range(8):
                 a.i(f"v_accvgpr_write_b32 {ar(n)}, 0")
                 n += 1
-    for f in range(8):
-        a.i(kread(f, V_ADDR_V, BLK))   # K(1): the stage's second block
     # tile 0 is the last tile only when QB == 1, which this kernel never sees (T > 32)
-    a.i(f"s_mov_b64 {sr(S_FE, 2)}, 0")
-    a.i(f"s_mov_b64 {sr(S_FO, 2)}, 0")
     a.i(f"s_call_b64 {sr(S_RET, 2)}, .Lpw_coldfirst_0")
-    a.i(f"s_sub_u32 {sr(S_CNT)}, {sr(S_QB)}, 1")
+    a.i(f"s_sub_u32 {sr(S_CNT)}, {sr(S_QB)}, 3")          # 'mid' stages between the first and the last: (QB - 3) / 2
+    a.i(f"s_max_i32 {sr(S_CNT)}, {sr(S_CNT)}, 0")
     a.i(f"s_lshr_b32 {sr(S_CNT)}, {sr(S_CNT)}, 1")
 
 
@@ -773,8 +843,12 @@ def emit_item_epilogue(a, tail):
 
 
 def emit_item_body(a, tail, tag):
-    """the stages of an item whose prologue has run: 'mid' loop, then the last stage by the parity of QB"""
-    l_mid, l_last, l_l1, l_done = (f".Lpw_{tag}_{x}" for x in ("mid", "last", "last1", "done"))
+    """the stages of an item whose prologue has run: QB == 2: 'flast2'; else 'fmid', (QB - 3) / 2 x 'mid', then 'last2' (QB
+    even) or 'last1' (QB odd); the PV MFMAs of the last tile; the epilogue"""
+    l_mid, l_last, l_l1, l_done, l_two = (f".Lpw_{tag}_{x}" for x in ("mid", "last", "last1", "done", "two"))
+    a.i(f"s_cmp_eq_u32 {sr(S_QB)}, 2")
+    a.i(f"s_cbranch_scc1 {l_two}")
+    emit_stage(a, "fmid", tail)
     a.i(f"s_cmp_eq_u32 {sr(S_CNT)}, 0")
     a.i(f"s_cbranch_scc1 {l_last}")
     a.label(l_mid)
@@ -784,13 +858,15 @@ def emit_item_body(a, tail, tag):
     a.label(l_last)
     a.i(f"s_bitcmp1_b32 {sr(S_QB)}, 0")
     a.i(f"s_cbranch_scc1 {l_l1}")
-    a.i(f"s_cmp_lg_u32 {sr(S_RAGEVEN)}, 0")
-    a.i(f"s_cselect_b64 {sr(S_FE, 2)}, -1, 0")
     emit_stage(a, "last2", tail)
     a.i(f"s_branch {l_done}")
     a.label(l_l1)
     emit_stage(a, "last1", tail)
+    a.i(f"s_branch {l_done}")
+    a.label(l_two)
+    emit_stage(a, "flast2", tail)
     a.label(l_done)
+    emit_drain(a, tail)
     stamp(a, 11)
     emit_item_epilogue(a, tail)
     stamp(a, 8)
@@ -836,9 +912,6 @@ def emit_all():
     a.i(f"s_lshr_b32 {sr(S_NGF)}, {sr(S_QB)}, 3")
     a.i(f"s_and_b32 {sr(S_TAILQ)}, {sr(S_QB)}, 7")
     a.i(f"s_and_b32 {sr(S_RAG)}, {sr(S_T)}, 31")
-    a.i(f"s_bitcmp1_b32 {sr(S_QB)}, 0")
-    a.i(f"s_cselect_b32 {sr(S_RAGODD)}, {sr(S_RAG)}, 0")
-    a.i(f"s_cselect_b32 {sr(S_RAGEVEN)}, 0, {sr(S_RAG)}")
     a.i(f"s_add_u32 {sr(S_BX)}, %4, 7")                      # sequences of this XCD: b = 8 bi + xcd < B
     a.i(f"s_sub_u32 {sr(S_BX)}, {sr(S_BX)}, {sr(S_XCD)}")
     a.i(f"s_lshr_b32 {sr(S_BX)}, {sr(S_BX)}, 3")
@@ -955,13 +1028,11 @@ def emit_all():
     # ---- out-of-line code: stubs, subroutines
     a.lines += a.tail
     a.tail = []
-    for buf in (0, 1):
-        a.label(f".Lpw_cold_{buf}")
-        emit_cold(a, buf, False)
-        a.label(f".Lpw_cold1_{buf}")
-        emit_cold(a, buf, False, blocks=("A",))
-    a.label(".Lpw_coldfirst_0")
-    emit_cold(a, 0, True)
+    for cur in (0, 1):
+        for hn in (True, False):
+            for nb in (1, 2):
+                emit_cold_mid(a, cur, hn, nb)
+    emit_cold_first(a)
     emit_post_barrier_sub(a)
     emit_dma_next_item_sub(a)
     a.lines += a.tail

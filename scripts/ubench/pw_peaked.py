@@ -2,6 +2,8 @@
 """row_mode 1 vs 5 with query / key weights x6 (reference moves on most tiles): pw_peaked.py B T [scale]"""
 import sys
 from pathlib import Path
+import os
+if len(sys.argv) > 4: os.environ["SAVAD_LIB"] = os.path.abspath(sys.argv[4])
 import numpy as np, torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from voice_activity_detection_amd import SelfAttentiveVAD, seeded_features, seeded_state_dict
