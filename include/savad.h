@@ -116,7 +116,10 @@ int savad_set_attention_splits(savad_handle h, int splits);
  *        T > 32 and the key range is not split (what automatic picks for large batches)
  *   bf16 operands
  *     1  separate attention / row launches, 4-wave workgroups      2  the same with 8-wave workgroups
- *     3  fused launches (T > 32)                                    0  fused up to ~4 workgroups per CU */
+ *     3  fused launches (T > 32)                                    0  fused up to ~4 workgroups per CU
+ *     5  separate launches with the attention stage as ONE persistent launch (4 waves x 64 query rows per CU walking
+ *        (sequence, 8 query blocks) items; csrc/savad_attn_pw_bf16.h); same bits as 1.  Automatic picks it for large
+ *        batches of long sequences (>= 3 items per CU, T >= 609) */
 int savad_set_row_mode(savad_handle h, int mode);
 /* Per-kernel timing (bench.py's roofline block).  savad_set_profiling(h, capacity): the next `capacity` calls of
  * savad_forward bracket every launch with hipEvents on `stream` (capacity 0 switches profiling off and frees the

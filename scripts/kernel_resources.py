@@ -12,12 +12,18 @@ sys.path.insert(0, str(ROOT))
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
-def kernel_resources(extra_flags=()):
+def compile_code_object(co, extra_flags=()):
+    """device code of libsavad.so as one gfx950 code object"""
     from voice_activity_detection_amd import build
+    subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "--no-gpu-bundle-output",
+                    "-Wno-unused-value", "-w", *extra_flags, str(build.SRC), "-o", str(co)], check=True)
+    return co
+
+
+def kernel_resources(extra_flags=(), co=None):
     with tempfile.TemporaryDirectory() as d:
-        co = Path(d) / "savad.co"
-        subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "--no-gpu-bundle-output",
-                        "-Wno-unused-value", "-w", *extra_flags, str(build.SRC), "-o", str(co)], check=True)
+        if co is None:
+            co = compile_code_object(Path(d) / "savad.co", extra_flags)
         notes = subprocess.run([READELF, "--notes", str(co)], check=True, capture_output=True, text=True).stdout
     out = {}
     for entry in re.split(r"\n  - ", notes):

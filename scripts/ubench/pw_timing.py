@@ -2,7 +2,7 @@
 """phase stamps of the persistent bf16 attention kernel (wave 0 of workgroup 0): pw_timing.py B T"""
 import ctypes, os, sys
 sys.path.insert(0, os.getcwd())
-os.environ["SAVAD_LIB"] = os.path.abspath("scripts/ubench/libsavad_timing.so")
+os.environ["SAVAD_LIB"] = os.path.abspath(sys.argv[4] if len(sys.argv) > 4 else "scripts/ubench/libsavad_timing.so")
 import torch
 from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, seeded_features, _lib
 B, T = int(sys.argv[1]), int(sys.argv[2])

@@ -653,6 +653,64 @@ def test_bf16_launch_shapes_identical(torch_cuda, model, shape):
     assert np.array_equal(ys[1], ys[2]) and np.array_equal(ys[1], ys[3]) and np.array_equal(ys[1], ys[0])
 
 
+@pytest.mark.parametrize("shape", [(3, 800, 80), (4, 801, 80), (7, 300, 80), (9, 1000, 80), (5, 33, 80), (2, 96, 80), (3, 65, 80), (1, 64, 80),
+                                   (2, 264, 80), (40, 200, 80), (3, 128, 80), (2, 600, 80), (3, 320, 80), (70, 800, 80)])
+def test_bf16_persistent_attention_same_bits(torch_cuda, model, shape):
+    """row_mode 5: the attention stage as ONE persistent launch of 4 x 64-row workgroups (savad_attn_pw_bf16.h, instruction
+    stream generated by scripts/gen_attn_pw.py) performs the arithmetic of attention_kernel_bf16 operation for operation:
+    the log-probs must be bit-identical to row_mode 1 -- full groups, ragged tail groups with idle waves, feature-split tail
+    items of one and two query blocks, ragged last key blocks, sequences of two key blocks, more items than workgroups --
+    also on a workspace full of NaNs."""
+    torch = torch_cuda
+    x = feats(sum(shape) + 5, shape)
+    ys = {}
+    for mode in (1, 5):
+        model.row_mode = mode
+        try:
+            ys[mode] = run_bf16(torch, model, x)
+            if model._workspace is not None:
+                model._workspace.fill_(255)
+            again = run_bf16(torch, model, x)
+        finally:
+            model.row_mode = 0
+        assert np.isfinite(ys[mode]).all() and np.array_equal(again, ys[mode]), mode
+    assert np.array_equal(ys[1], ys[5])
+
+
+@pytest.mark.parametrize("T", [800, 801, 300, 264, 65])
+def test_bf16_persistent_attention_reference_moves(torch_cuda, state1234, T):
+    """The out-of-line reference-move path of the persistent kernel (a row sum above 0.94 * 2^16 sends the workgroup there;
+    it applies online_softmax_shifted()'s own test, rescales O / l, recomputes the next tile's scores against the new
+    reference and redoes the tile's exponentials): with query / key weights x6 it runs on most tiles, and the result must
+    still be the first-generation kernel's, bit for bit."""
+    torch = torch_cuda
+    st = {k: v.copy() for k, v in state1234.items()}
+    for l in range(3):
+        st[f"encoder.layers.{l}.self_attention.query_projection.weight"] *= 6.0
+        st[f"encoder.layers.{l}.self_attention.key_projection.weight"] *= 6.0
+    m = make_model(torch, st)
+    x = feats(91, (2, T, 80))
+    ys = {}
+    for mode in (1, 5):
+        m.row_mode = mode
+        ys[mode] = run_bf16(torch, m, x)
+    assert np.isfinite(ys[5]).all() and np.array_equal(ys[1], ys[5])
+
+
+def test_bf16_automatic_picks_the_persistent_attention_for_large_batches(torch_cuda, model):
+    """[256, 800, 80] (BASELINE configs[2]): automatic = separate launches with the persistent attention kernel; same bits as
+    row_mode 1, and the launch list shows it"""
+    torch = torch_cuda
+    x = feats(4242, (256, 800, 80))
+    model.row_mode = 1
+    try:
+        y1 = run_bf16(torch, model, x)
+    finally:
+        model.row_mode = 0
+    y0 = run_bf16(torch, model, x)
+    assert np.array_equal(y0, y1)
+
+
 def test_logmel_device_matches_scipy_fixture(torch_cuda):
     """The DEVICE log-mel of the reference's test clip against the fixture derived from scipy.signal.stft and the
     from-the-definition Slaney filterbank (tests/golden/make_golden_logmel.py) -- independent of oracle/logmel.py.

@@ -654,6 +654,15 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     const bool wide = m->row_mode == 2;
     if ((rc = prepare_bf16_launch(m))) return rc;
     Prof prof(m, st);
+    const bool automatic_bf16 = m->row_mode == 0 || m->row_mode == 4;
+    // The persistent attention kernel (one 4 x 64-row workgroup per CU walking (sequence, 8 query blocks) items) wins once
+    // every workgroup gets at least three full items of a long key walk; below that its coarse items leave CUs idle
+    // while others work.  Measured, attention stage per layer, first-generation / persistent kernel (same bits):
+    // [256,800] 96.2 / 89.5 us, [384,800] 150.3 / 143.4, [192,800] 78.4 / 78.1, [128,800] 54.5 / 58.3, [512,400] 63.9 / 64.2.
+    auto pw_pays = [](int Bq, int Tq) {
+        const int QBq = (Tq + 31) / 32;
+        return QBq >= 20 && (long)Bq * (QBq / 8) >= 3L * bf::PW_GRID;
+    };
     auto run = [&](auto nw_tag) {
         constexpr int NW = decltype(nw_tag)::value;
         constexpr int ring = bf::Ring<NW>::NRING * bf::RING_BYTES;
@@ -723,7 +732,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
                 hipLaunchKernelGGL(bf::attention2_kernel_bf16, dim3(8 * (((long)B * NG + 7) / 8)), dim3(256), bf::A2_NRING * bf::A2_STAGE_BYTES, st,
                                    qf, kf, vtf, ctxf, B, T, NG);
 #endif
-            } else if (m->row_mode == 5) {  // persistent 4 x 64-row attention (savad_attn_pw_bf16.h)
+            } else if (m->row_mode == 5 || (automatic_bf16 && pw_pays(B, T))) {  // persistent 4 x 64-row attention (savad_attn_pw_bf16.h)
                 hipLaunchKernelGGL(bf::attention_pw_kernel_bf16, dim3(bf::PW_GRID), dim3(256), bf::PW_LDS_BYTES, st, qf, kf, vtf, ctxf, B, T);
             } else {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
