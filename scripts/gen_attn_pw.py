@@ -5,8 +5,9 @@
 each wave owning 64 query rows (two 32-row query blocks A / B), with the whole 512-entry register file owned by the
 instruction stream below (no compiler-allocated register inside it).
 
-    python scripts/gen_attn_pw.py            # rewrites the .inc
-    python scripts/gen_attn_pw.py --check    # exit 1 when the committed .inc is stale (tests/test_abi_and_host.py)
+    python scripts/gen_attn_pw.py            # rewrites the .inc files
+    python scripts/gen_attn_pw.py --check    # exit 1 when a committed .inc is stale (tests/test_abi_and_host.py)
+    python scripts/gen_attn_pw.py --out F [--ablate MASK] [--timing | --count] [--split-max N] [--pad N]   # experiments
 
 Data layout: savad_kernels_bf16.h (fragment-major q / k / v^T / ctx, 1 KiB per K-step fragment of 32 rows).
 Arithmetic: identical, operation for operation, to attention_kernel_bf16 (online softmax in the base-2 domain relative
@@ -16,18 +17,27 @@ drifts 2^16 above it) -- the two kernels produce the same bits, which is how thi
 Structure
   work items : (sequence b, group g of 8 query blocks); a workgroup walks its items (all full groups first, then the
                ragged tail groups); sequences with b % 8 == xcd stay on one XCD, so the groups of a sequence share
-               its K / V^T in that XCD's L2.
-  K / V^T    : 64 keys (K 2 blocks | V^T 2 blocks = 32 KiB) per LDS stage, ring of 4 stages, filled by LDS-DMA
-               (global_load_lds_dwordx4, 1 KiB per instruction, 8 per wave and stage) three stages ahead of the
-               compute; the stream runs continuously ACROSS items (a second item cursor feeds the DMA).
-  per stage  : ONE barrier; two steps (key blocks) of 32 MFMAs each:
-               phase A  16 x  S^T(i+1) = K(i+1) Q^T    beside  exp / row sum / bf16 pack of tile i, V^T(i) reads
-               phase B  16 x  O^T += V^T(i) P^T(i)     beside  K(i+2) reads, row maxima of tile i+1, DMA pieces
+               its K / V^T in that XCD's L2.  A tail group of one or two query blocks is a FEATURE-SPLIT item: all
+               four waves take the same block(s) and each owns one 32-feature block of the context.
+  K / V^T    : 64 keys (K 2 blocks | V^T 2 blocks = 32 KiB) per LDS stage, ring of 4 stages (+ a fifth slot nobody
+               reads, where the DMA lands once the stream is exhausted: the cadence of 8 pieces per stage, and with it
+               the meaning of every vmcnt(8), never changes), filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+               instruction, one M0 write per half stage: the immediate offset moves source AND destination) three
+               stages ahead of the compute; the stream runs continuously ACROSS items (a second item cursor feeds it).
+  per stage  : ONE barrier; two steps (key blocks).  Step i is a two-stage pipeline:
+               first half   O^T += V^T(i-1) P^T(i-1)   beside  K(i+1) reads, exponentials of tile i, row sum of block A
+               second half  S^T(i+1) = K(i+1) Q^T      beside  V^T(i) reads, row sum of block B, bf16 packing, DMA
+                                                               pieces, stream advance, ring-address rotation
+               then ONE reference check: a row sum above 0.94 * 2^16 is the only way a score can have outrun the
+               reference by 2^16; the out-of-line path applies online_softmax_shifted()'s own test and, where a
+               reference moves, rescales O / l, RECOMPUTES the next tile's scores against it (bit-exactness: the
+               reference kernel would have) and redoes the tile's exponentials.
   registers  : a[0:127] O^T (A, B), a[128:191] Q (A, B), a[192:223] K fragments, a[224:255] V^T fragments;
                v[0:63] two score tiles per query block (ping-pong), v[64:95] -reference vectors, then P, exps, staging.
 Hazards stated by hand (CDNA3/4 ISA, manually inserted wait states): an MFMA result is read by a VALU instruction no
-sooner than 8 MFMAs (or 3 x s_nop 7) later; a transcendental result is never consumed by the next instruction; 2 wait
-states before v_permlane32_swap reads a VALU result; s_nop 0 between an M0 write and the LDS-DMA that reads it.
+sooner than 2 MFMAs + 16 wait states (or 3 x s_nop 7) later; a transcendental result is never consumed by the next
+instruction; 2 wait states before v_permlane32_swap reads a VALU result; s_nop 0 between an M0 write and the LDS-DMA
+that reads it; s_nop 1 between a VALU write and the MFMA that reads it as C.
 """
 import sys
 from pathlib import Path
