@@ -134,17 +134,21 @@ struct Ring {
 
     __device__ __forceinline__ char* slot(int t) const { return base + (t & (NRING - 1)) * RING_BYTES; }
 
-    // One DMA instruction moves 1 KiB; instruction i = w + NW * k of the block's 32 reads KiB (i & 7) of segment i >> 3
-    // and lands at slot + i KiB.  Per instruction: s_add_u32 m0 (LDS address = per-wave base + immediate), the hazard
-    // nop, the load -- the segment base is wave-uniform (SGPR pair, + this wave's KiB), the rest of the source offset
-    // rides in the per-lane offset register.  M0 is not saved / restored: nothing else in these kernels uses it (gfx9 DS
-    // instructions do not need it; tests/test_abi_and_host.py checks the disassembly).
+    // One DMA instruction moves 1 KiB (64 lanes x 16 B); piece i of the block's 32 reads KiB (i & 7) of segment i >> 3 and
+    // lands at slot + i KiB.  A wave's pieces are CONSECUTIVE KiB of ONE segment, four per M0 write: the instruction's
+    // immediate offset moves the global source and the LDS destination together (measured: scripts/ubench/dma_issue.hip),
+    // so a group of four costs s_add_u32 m0 + the hazard nop + 4 loads (round 2 paid the M0 write and the nop per piece).
+    // M0 is not saved / restored: nothing else in these kernels uses it (gfx9 DS instructions do not need it;
+    // tests/test_abi_and_host.py checks the disassembly).
     template <int IMM>
-    static __device__ __forceinline__ void dma1k(const char* src, unsigned ldsb, unsigned voff) {
+    static __device__ __forceinline__ void dma4k(const char* src, unsigned ldsb, unsigned voff) {
         asm volatile(
             "s_add_u32 m0, %2, %3\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %0, %1"
+            "global_load_lds_dwordx4 %0, %1\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:3072"
             :
             : "v"(voff), "s"(src), "s"(ldsb), "n"(IMM)
             : "memory", "scc");
@@ -155,27 +159,16 @@ struct Ring {
         // LDS byte address = low 32 bits of the flat address (the LDS aperture is 4 GiB aligned).  An explicit
         // generic -> address_space(3) cast adds a null check that hipcc 7.2 mis-selects in one instantiation
         // ("V_CMP_NE_U32 0, $src_shared_base: operand has incorrect register class").
-        const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot(t)) + (unsigned)w * FRAG_BYTES;
-        const unsigned off = (unsigned)lane * 16u;
-        if (NW == 4) {  // i = w + 4k: segment k >> 1, KiB w + 4 (k & 1)
-            const unsigned off4 = off + 4u * FRAG_BYTES;
-            const char* s0 = seg_src(0) + (size_t)w * FRAG_BYTES;
-            dma1k<0 * 4096>(s0, ldsb, off);
-            dma1k<1 * 4096>(s0, ldsb, off4);
-            const char* s1 = seg_src(1) + (size_t)w * FRAG_BYTES;
-            dma1k<2 * 4096>(s1, ldsb, off);
-            dma1k<3 * 4096>(s1, ldsb, off4);
-            const char* s2 = seg_src(2) + (size_t)w * FRAG_BYTES;
-            dma1k<4 * 4096>(s2, ldsb, off);
-            dma1k<5 * 4096>(s2, ldsb, off4);
-            const char* s3 = seg_src(3) + (size_t)w * FRAG_BYTES;
-            dma1k<6 * 4096>(s3, ldsb, off);
-            dma1k<7 * 4096>(s3, ldsb, off4);
-        } else {  // NW == 8: i = w + 8k: segment k, KiB w
-            dma1k<0 * 8192>(seg_src(0) + (size_t)w * FRAG_BYTES, ldsb, off);
-            dma1k<1 * 8192>(seg_src(1) + (size_t)w * FRAG_BYTES, ldsb, off);
-            dma1k<2 * 8192>(seg_src(2) + (size_t)w * FRAG_BYTES, ldsb, off);
-            dma1k<3 * 8192>(seg_src(3) + (size_t)w * FRAG_BYTES, ldsb, off);
+        const unsigned slot0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot(t));
+        const unsigned off = (unsigned)lane * 16u, off4 = off + 4u * FRAG_BYTES;
+        if (NW == 4) {  // wave w moves segment w: KiB 8w .. 8w+7 of the block
+            const char* s0 = seg_src(w);
+            const unsigned ldsb = slot0 + (unsigned)w * BLK_BYTES;
+            dma4k<0>(s0, ldsb, off);
+            dma4k<4096>(s0, ldsb, off4);
+        } else {  // NW == 8: wave w moves half a segment: KiB 4w .. 4w+3
+            const char* s0 = seg_src(w >> 1) + (size_t)(w & 1) * 4 * FRAG_BYTES;
+            dma4k<0>(s0, slot0 + (unsigned)w * 4 * FRAG_BYTES, off);
         }
     }
     // wait until block t has landed for every wave; `newer` = DMA blocks issued after block t (wave-uniform)
