@@ -169,7 +169,7 @@ def rocprof_averages():
 ROCPROF_NAMES = {  # bench launch label -> kernel short name in the rocprofv3 stats (fp32 M-split / fused regime, bf16 4-wave kernels)
     "attention_row": "attention_row_kernel<false>", "attention_row_last": "attention_row_kernel<true>",
     "input_qkv": "input_qkv_kernel_m", "packed_forward": "packed_forward_kernel",
-    "attention_bf16": "attention_kernel_bf16<4>", "row_bf16": "row_kernel_bf16<false, 4>", "row_last_bf16": "row_kernel_bf16<true, 4>",
+    "attention_bf16": ("attention_pw_kernel_bf16", "attention_kernel_bf16<4>"), "row_bf16": "row_kernel_bf16<false, 4>", "row_last_bf16": "row_kernel_bf16<true, 4>",
     "input_qkv_bf16": "input_qkv_kernel_bf16<__bf16, 4>",
 }
 
@@ -353,7 +353,8 @@ def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False):
         per_kernel[n] = {"launches": len(ts), "ms": round(ms_k, 4), "tflops": round(fl / (ms_k * 1e-3) / 1e12, 2),
                          "frac": round(fl / (ms_k * 1e-3) / 1e12 / peak, 4),
                          "hbm_frac": round(by / (ms_k * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4)}
-        ref_ns = prof_avg.get(ROCPROF_NAMES.get(n, ""))
+        cands = ROCPROF_NAMES.get(n, ())
+        ref_ns = next((prof_avg[c] for c in ((cands,) if isinstance(cands, str) else cands) if c in prof_avg), None)
         if ref_ns:  # this run's HIP-event duration over the committed rocprofv3 average of the same kernel on the same sources
             per_kernel[n]["rocprof_ms"] = round(ref_ns * 1e-6, 4)
             per_kernel[n]["event_over_rocprof"] = round(ms_k / (ref_ns * 1e-6), 3)
