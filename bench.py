@@ -152,11 +152,19 @@ def gpu_state():
     return keep or None
 
 
-def rocprof_averages():
-    """{kernel short name: average ns} of the committed rocprofv3 --kernel-trace --stats run of this bench
+def rocprof_averages(precision, B, T):
+    """{kernel short name: average ns} of the committed rocprofv3 --kernel-trace --stats run of this workload
     (profiles/*_kernel_avg.json, written by scripts/summarize_profile.py), only when taken on the running kernel sources."""
+    if (precision, B, T) == ("fp32", 32, 800):
+        files = [f for f in sorted((REPO / "profiles").glob("*_kernel_avg.json")) if not any(t in f.name for t in ("bf16", "_t7_", "_t50_"))]
+    elif (precision, B, T) == ("bf16", 256, 800):
+        files = sorted((REPO / "profiles").glob("*bf16_kernel_avg.json"))
+    elif (precision, B, T) == ("fp32", 1000, 7):
+        files = sorted((REPO / "profiles").glob("*t7_kernel_avg.json"))
+    else:
+        return {}, None
     want = kernel_source_hash()
-    for f in sorted((REPO / "profiles").glob("*_kernel_avg.json"), reverse=True):
+    for f in reversed(files):
         try:
             data = json.loads(f.read_text())
         except Exception:
@@ -346,7 +354,7 @@ def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False):
     dom_flops, dom_bytes = launch_work(dom, B, T, e)
     ach = dom_flops / (dom_ms * 1e-3) / 1e12
     per_kernel = {}
-    prof_avg, prof_file = rocprof_averages() if profiled_shape else ({}, None)
+    prof_avg, prof_file = rocprof_averages(precision, B, T) if profiled_shape else ({}, None)
     for n, ts in by_name.items():
         fl, by = launch_work(n, B, T, e)
         ms_k = sum(ts) / len(ts)
