@@ -760,8 +760,10 @@ def emit_cold_mid(a, cur, has_next, nblocks):
 def emit_item_prologue(a):
     """Q of this item from staging into a[128:191]; S^T(0) with C = 0 beside the zeroing of O; reference of tile 0"""
     a.i("s_waitcnt vmcnt(8)")   # the staged Q is older than the newest stage of DMA pieces
+    stamp(a, 26)
     for r in range(64):
         a.i(f"v_accvgpr_write_b32 {ar(A_Q['A'] + r)}, {vr(V_QS + r)}")
+    stamp(a, 27)
     for f in range(8):
         a.i(kread(f, V_ADDR_V, 0))
     for blk in ("A", "B"):
@@ -771,6 +773,7 @@ def emit_item_prologue(a):
     a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11")
     a.i(f"v_add_u32 {vr(V_ADDR_VT)}, {sr(S_T0)}, {vr(V_ADDR_V)}")
     a.i("s_waitcnt lgkmcnt(0)")
+    stamp(a, 28)
     n = 0
     for ks in range(8):
         for blk in ("A", "B"):
@@ -778,6 +781,7 @@ def emit_item_prologue(a):
             for _ in range(8):
                 a.i(f"v_accvgpr_write_b32 {ar(n)}, 0")
                 n += 1
+    stamp(a, 29)
     # tile 0 is the last tile only when QB == 1, which this kernel never sees (T > 32)
     a.i(f"s_call_b64 {sr(S_RET, 2)}, .Lpw_coldfirst_0")
     a.i(f"s_sub_u32 {sr(S_CNT)}, {sr(S_QB)}, 3")          # 'mid' stages between the first and the last: (QB - 3) / 2
@@ -970,7 +974,9 @@ def emit_all():
     a.i(f"s_sub_i32 {sr(S_VALID['A'])}, {sr(S_T)}, {sr(S_T0)}")
     a.i(f"s_sub_i32 {sr(S_VALID['B'])}, {sr(S_VALID['A'])}, 32")
     # advance the compute cursor and describe the next item (its Q is requested behind this item's first barrier)
+    stamp(a, 0)
     emit_cursor_next(a, S_CC, "c")
+    stamp(a, 24)
     a.i(f"s_mov_b32 {sr(S_NFLAGS)}, 0")
     l_nonext = a.uniq("nonext")
     a.i(f"s_cmp_eq_u32 {sr(S_CC + 3)}, 0")
@@ -978,16 +984,17 @@ def emit_all():
     emit_item_params(a, S_CC, S_NFLAGS, S_NQA, S_NSEQBLK)
     a.label(l_nonext)
     a.i(f"s_mov_b32 {sr(S_QPEND)}, 1")
+    stamp(a, 25)
     a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 0")
     a.i("s_cbranch_scc0 .Lpw_idle_item")
-    stamp(a, 0)
     emit_item_prologue(a)
     stamp(a, 1)
     a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 2")
     a.i("s_cbranch_scc0 .Lpw_normal_item")
-    a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 1")
-    a.i("s_cbranch_scc0 .Lpw_tail1_item")
-    emit_item_body(a, 2, "t2")
+    if SPLIT_MAX >= 2:
+        a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 1")
+        a.i("s_cbranch_scc0 .Lpw_tail1_item")
+        emit_item_body(a, 2, "t2")
     a.label(".Lpw_tail1_item")
     emit_item_body(a, 1, "t1")
     a.label(".Lpw_normal_item")

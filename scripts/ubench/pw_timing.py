@@ -18,7 +18,7 @@ buf = (ctypes.c_longlong * 16)()
 lib.savad_debug_stamps(buf, 16)
 w = []
 for v in buf: w += [v & 0xffffffff, (v >> 32) & 0xffffffff]
-names = {0: "kernel prologue / between items", 1: "item prologue (Q copy, S(0), first reference)", 2: "barrier", 3: "vmcnt(8) wait",
+names = {0: "epilogue end -> item start (incl. kernel prologue)", 24: "  cursor advance", 25: "  next item's parameters", 26: "  wait for the staged Q", 27: "  Q -> AGPRs", 28: "  K(0) reads, init, LDS wait", 29: "  S(0) MFMAs + O zeroing", 1: "  first reference (out-of-line call)", 2: "barrier", 3: "vmcnt(8) wait",
          4: "even step", 5: "odd step", 23: "DMA advance", 6: "last step of an item", 20: "tail item: even step", 21: "tail item: odd step", 22: "tail item: last step", 8: "item epilogue", 9: "idle stages", 10: "tail", 11: "stage dispatch"}
 tot = sum(w[c] for c in names)
 cyc, rt = (w[17] - w[16]) & 0xffffffff, (w[19] - w[18]) & 0xffffffff
