@@ -19,11 +19,12 @@ Structure
                ragged tail groups); sequences with b % 8 == xcd stay on one XCD, so the groups of a sequence share
                its K / V^T in that XCD's L2.  A tail group of one or two query blocks is a FEATURE-SPLIT item: all
                four waves take the same block(s) and each owns one 32-feature block of the context.
-  K / V^T    : 64 keys (K 2 blocks | V^T 2 blocks = 32 KiB) per LDS stage, ring of 4 stages (+ a fifth slot nobody
-               reads, where the DMA lands once the stream is exhausted: the cadence of 8 pieces per stage, and with it
-               the meaning of every vmcnt(8), never changes), filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
-               instruction, one M0 write per half stage: the immediate offset moves source AND destination) three
-               stages ahead of the compute; the stream runs continuously ACROSS items (a second item cursor feeds it).
+  K / V^T    : 64 keys (K 2 blocks | V^T 2 blocks = 32 KiB) per LDS stage, ring of 5 stages (the whole LDS), filled by
+               LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, one M0 write per half stage: the immediate
+               offset moves source AND destination) FOUR stages ahead of the compute; the stream runs continuously
+               ACROSS items (a second item cursor feeds it), and once it is exhausted the DMA keeps its cadence of 8
+               pieces per stage with the last valid sources (they land in slots no later stage reads), so that every
+               counted vmcnt keeps its meaning without a second code path.
   per stage  : ONE barrier; two steps (key blocks).  Step i is a two-stage pipeline:
                first half   O^T += V^T(i-1) P^T(i-1)   beside  K(i+1) reads, exponentials of tile i, row sum of block A
                second half  S^T(i+1) = K(i+1) Q^T      beside  V^T(i) reads, row sum of block B, bf16 packing, DMA
@@ -113,9 +114,10 @@ CHECK_BITS = "0x47700000"      # 61440.0 = 0.9375 * 2^16: a row whose maximum ex
                                # exponential >= 2^16 (1 - ulp) in its sum, whatever v_exp_f32 rounds to: the check is a strict
                                # superset of online_softmax_shifted()'s own test, which the out-of-line path then applies exactly
 NEG_BIG_BITS = 0xF149F2CA      # -1.0e30f
-BLK, FRAG, STAGE, NRING = 8192, 1024, 32768, 4
-DUMP = NRING * STAGE           # LDS offset of the stage nobody reads: once the stream is exhausted the DMA keeps its
-                               # cadence (8 pieces per stage, so every vmcnt(8) keeps its meaning) and lands there
+BLK, FRAG, STAGE, NRING = 8192, 1024, 32768, 5     # 5 stages of 32 KiB: the whole LDS of a CU
+AHEAD = NRING - 1              # the DMA runs this many stages ahead of the compute; once the stream is exhausted it keeps its
+                               # cadence (8 pieces per stage, so every counted vmcnt keeps its meaning) with the last valid
+                               # sources: those pieces land in ring slots no later stage reads
 
 
 class Asm:
@@ -327,9 +329,9 @@ def emit_dma_item_setup(a):
 
 
 def dma_slot_ops():
-    """the next stage of the stream goes to the next ring slot"""
-    return [f"s_add_u32 {sr(S_DSTREAM)}, {sr(S_DSTREAM)}, 1", f"s_and_b32 {sr(S_TD)}, {sr(S_DSTREAM)}, {NRING - 1}",
-            f"s_lshl_b32 {sr(S_TD)}, {sr(S_TD)}, 15", f"s_add_u32 {sr(S_DLDS)}, {sr(S_DBASE)}, {sr(S_TD)}"]
+    """the next stage of the stream goes to the next ring slot (S_DSTREAM = slot index 0 .. NRING - 1)"""
+    return [f"s_add_u32 {sr(S_DSTREAM)}, {sr(S_DSTREAM)}, 1\n\ts_cmp_eq_u32 {sr(S_DSTREAM)}, {NRING}\n\ts_cselect_b32 {sr(S_DSTREAM)}, 0, {sr(S_DSTREAM)}",
+            f"s_lshl_b32 {sr(S_TD)}, {sr(S_DSTREAM)}, 15", f"s_add_u32 {sr(S_DLDS)}, {sr(S_DBASE)}, {sr(S_TD)}"]
 
 
 def dma_advance_ops(a):
@@ -367,13 +369,8 @@ def emit_dma_next_item_sub(a):
     emit_dma_item_setup(a)
     emit_back_one_stage(a)
     a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
-    a.label(l_dump)   # stream exhausted: same cadence, harmless destination, the last valid sources again
+    a.label(l_dump)   # stream exhausted: same cadence, the last valid sources again, ring slots nobody reads any more
     emit_back_one_stage(a)
-    a.i(f"s_add_u32 {sr(S_TD)}, {sr(S_DSTREAM)}, 1")
-    a.i(f"s_and_b32 {sr(S_TD)}, {sr(S_TD)}, {NRING - 1}")
-    a.i(f"s_lshl_b32 {sr(S_TD)}, {sr(S_TD)}, 15")
-    a.i(f"s_add_u32 {sr(S_DBASE)}, {sr(S_LDSW)}, {DUMP}")
-    a.i(f"s_sub_u32 {sr(S_DBASE)}, {sr(S_DBASE)}, {sr(S_TD)}")
     a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
 
 
@@ -463,17 +460,18 @@ def emit_post_barrier_sub(a):
 
 def rotate_ops(tail):
     """the stage behind the compute stage becomes the compute stage"""
-    ops = [f"v_mov_b32 {vr(V_ADDR_V)}, {vr(V_ADDR_K)}", f"s_add_u32 {sr(S_KS)}, {sr(S_KS)}, {STAGE}",
-           f"s_and_b32 {sr(S_KS)}, {sr(S_KS)}, {NRING * STAGE - 1}", f"v_add_u32 {vr(V_ADDR_K)}, {sr(S_KS)}, {vr(V_LDSL)}"]
+    ops = [f"v_mov_b32 {vr(V_ADDR_V)}, {vr(V_ADDR_K)}",
+           f"s_add_u32 {sr(S_KS)}, {sr(S_KS)}, {STAGE}\n\ts_cmp_eq_u32 {sr(S_KS)}, {NRING * STAGE}\n\ts_cselect_b32 {sr(S_KS)}, 0, {sr(S_KS)}",
+           f"v_add_u32 {vr(V_ADDR_K)}, {sr(S_KS)}, {vr(V_LDSL)}"]
     if tail:
         ops += [f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11\n\tv_add_u32 {vr(V_ADDR_VT)}, {sr(S_T0)}, {vr(V_ADDR_V)}"]
     return ops
 
 
 def emit_stage_top(a):
-    """own share of the stage behind the compute stage landed (the 8 newest requests are the stage after that), then
-    everybody's; afterwards the slot of the stage before the compute stage may be refilled"""
-    a.i("s_waitcnt vmcnt(8)")
+    """own share of the stage behind the compute stage landed (the newest 8 (AHEAD - 2) requests are the stages after it),
+    then everybody's; afterwards the slot of the stage before the compute stage may be refilled"""
+    a.i(f"s_waitcnt vmcnt({8 * (AHEAD - 2)})")
     stamp(a, 3)
     if not ABLATE & 2:
         a.i("s_barrier")
@@ -957,12 +955,12 @@ def emit_all():
     emit_item_params(a, S_CC, S_NFLAGS, S_NQA, S_NSEQBLK)
     emit_q_request(a)
     emit_dma_item_setup(a)
-    for _ in range(3):
+    for _ in range(AHEAD):
         emit_dma_half(a, 0)
         emit_dma_half(a, 1)
         emit_dma_advance(a)
-    # stage 0 has landed for everybody before the first item's prologue reads K(0), K(1) from it
-    a.i("s_waitcnt vmcnt(16)")
+    # stage 0 has landed for everybody before the first item's prologue reads K(0) from it
+    a.i(f"s_waitcnt vmcnt({8 * (AHEAD - 1)})")
     a.i("s_barrier")
 
     # ================================================================================ item loop
