@@ -80,7 +80,7 @@ def kernel_source_hash() -> str:
     measured on (scripts/summarize_profile.py stamps the same hash into *_traffic.json)."""
     h = hashlib.sha256()
     for f in sorted((REPO / "voice_activity_detection_amd" / "csrc").glob("*")):
-        if f.suffix in (".h", ".hip"):
+        if f.suffix in (".h", ".hip", ".inc"):
             h.update(f.name.encode())
             h.update(f.read_bytes())
     return h.hexdigest()[:16]

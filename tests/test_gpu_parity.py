@@ -654,7 +654,8 @@ def test_bf16_launch_shapes_identical(torch_cuda, model, shape):
 
 
 @pytest.mark.parametrize("shape", [(3, 800, 80), (4, 801, 80), (7, 300, 80), (9, 1000, 80), (5, 33, 80), (2, 96, 80), (3, 65, 80), (1, 64, 80),
-                                   (2, 264, 80), (40, 200, 80), (3, 128, 80), (2, 600, 80), (3, 320, 80), (70, 800, 80)])
+                                   (2, 264, 80), (40, 200, 80), (3, 128, 80), (2, 600, 80), (3, 320, 80), (70, 800, 80), (2, 3200, 80),
+                                   (700, 100, 80), (530, 40, 80)])
 def test_bf16_persistent_attention_same_bits(torch_cuda, model, shape):
     """row_mode 5: the attention stage as ONE persistent launch of 4 x 64-row workgroups (savad_attn_pw_bf16.h, instruction
     stream generated by scripts/gen_attn_pw.py) performs the arithmetic of attention_kernel_bf16 operation for operation:
