@@ -131,7 +131,7 @@ def gpu_state():
     import subprocess
 
     exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(exe):
+    if not os.path.exists(exe) or os.environ.get("RANK", "0") != "0":  # (rank 0 reports; eight ranks polling would only add noise)
         return None
     try:
         out = subprocess.run([exe, "--showclocks", "--showpower", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=8).stdout

@@ -275,6 +275,8 @@ class SelfAttentiveVAD(nn.Module):
         with T <= max_frames (and B <= max_batch) then neither allocate nor synchronise nor launch anything but their own
         kernels, so even the FIRST forward can be captured into a HIP graph."""
         device = torch.device(device) if device is not None else self.classifier.weight.device
+        if device.type == "cuda" and device.index is None:  # "cuda" -> the indexed device tensors report
+            device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(device):
             lib = self._prepare_call(device)
             stream = torch.cuda.current_stream(device).cuda_stream
