@@ -4,9 +4,6 @@
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
 #include "savad_attn_pw_bf16.h"
-#ifdef SAVAD_ATTN2  // experiment builds only (scripts/ubench/attention2): -DSAVAD_ATTN2='"<header>"' adds bf16 row_mode 6
-#include SAVAD_ATTN2
-#endif
 #include <type_traits>
 #include "savad_logmel.h"
 #include "savad_post.h"
@@ -526,12 +523,6 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
-#ifdef SAVAD_ATTN2
-    if (m && mode == 6) {
-        m->row_mode = 6;
-        return SAVAD_OK;
-    }
-#endif
     if (!m || mode < 0 || mode > 5) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
@@ -718,20 +709,6 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
             if (T <= 32) {
                 hipLaunchKernelGGL(bf::attention_packed_kernel_bf16, dim3((bp.nblk + 3) / 4), dim3(256), 0, st, qf, kf, vtf, ctxf,
                                    B, T, bp.nblk);
-#ifdef SAVAD_ATTN2
-            } else if (m->row_mode == 6) {
-                const int QB = (T + 31) / 32, NP = (QB + 1) / 2;
-                int NG = B >= 256 ? 1 : (256 + B - 1) / B;
-                if (NG > (NP + 3) / 4) NG = (NP + 3) / 4;
-                if (NG < 1) NG = 1;
-                static bool attr_done = false;
-                if (!attr_done) {
-                    if ((rc = allow_lds(bf::attention2_kernel_bf16, bf::A2_NRING * bf::A2_STAGE_BYTES))) return;
-                    attr_done = true;
-                }
-                hipLaunchKernelGGL(bf::attention2_kernel_bf16, dim3(8 * (((long)B * NG + 7) / 8)), dim3(256), bf::A2_NRING * bf::A2_STAGE_BYTES, st,
-                                   qf, kf, vtf, ctxf, B, T, NG);
-#endif
             } else if (m->row_mode == 5 || (automatic_bf16 && pw_pays(B, T))) {  // persistent 4 x 64-row attention (savad_attn_pw_bf16.h)
                 hipLaunchKernelGGL(bf::attention_pw_kernel_bf16, dim3(bf::PW_GRID), dim3(256), bf::PW_LDS_BYTES, st, qf, kf, vtf, ctxf, B, T);
             } else {
