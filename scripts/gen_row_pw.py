@@ -57,10 +57,10 @@ V_RING = [236, 237]              # LDS base + lane * 16 (+ 65536): ring slots 0-
 V_BIAS = 238                     # LDS address of the bias area + 16 h
 V_BIASN = 239                    # LDS address of the V bias + 4 (lane & 31)
 # LayerNorm / store scalars (alias BT0 / BT1: no MFMA chain is being started while they live)
-V_S, V_TMP, V_MEAN, V_SS, V_M2, V_R0, V_R1, V_R2, V_R3, V_AMAX, V_C65, V_R4, V_R5 = 192, 193, 194, 196, 197, 198, 199, 200, 201, 202, 203, 204, 205
+V_C65 = 207                      # 65504.0 (store_hblock's clamp); the per-block LayerNorm / store scalars: ln_scalars()
+V_R4, V_R5 = 220, 221            # saturation path scratch
 
-S_RET = 24
-S_WS, S_FR = 26, 28   # prologue only: workspace / fragment bases
+S_WS, S_FR = 26, 28   # prologue only: workspace / fragment bases.  s[24:29] and s[82:83]: VALU compare results of the LayerNorms
 S_BCTX, S_BH, S_BQ, S_BK, S_BV = 36, 38, 40, 42, 44
 S_WO, S_W1, S_W2, S_WN = 46, 48, 50, 52
 S_SAT = 54
@@ -70,7 +70,6 @@ S_NBLK, S_NITEMS, S_STRIDE, S_PAIR, S_NPAIR = 59, 60, 61, 62, 63
 S_HC, S_Q, S_K, S_V, S_CTXN, S_HN = 64, 66, 68, 70, 72, 74
 S_SRC = 76
 S_T0, S_T1, S_T2, S_T3 = 78, 79, 80, 81
-S_CMP = 82            # s[82:83], s[84:85]: VALU compare results
 S_CMP2 = 30          # s[30:31]: exec save of the saturation path
 S_PREV, S_TMPD = 84, 85   # timing builds
 S_TM = 86
@@ -158,8 +157,8 @@ def ring_addr(slot, frag):
     return V_RING[slot >> 1], (slot & 1) * RINGBLK + frag * FRAG
 
 
-def mfma(d, a, b, c, need=()):
-    return Ins(f"v_mfma_f32_32x32x16_bf16 {d}, {a}, {b}, {c}", "mfma", need_lds=need)
+def mfma(d, a, b, c, need=(), need_vm=()):
+    return Ins(f"v_mfma_f32_32x32x16_bf16 {d}, {a}, {b}, {c}", "mfma", need_lds=need, need_vm=need_vm)
 
 
 # ------------------------------------------------------------------------------------------------ DMA / acquire
@@ -214,20 +213,26 @@ def bias_tags(tag):
     return tuple(f"{tag}_{g}" for g in range(4))
 
 
-def h_prep_ops(r, nb, bias_reg, btag):
-    """BT[r] = (f32(h rows of block r, feature block nb) + 0) + bo block  (load_hblock on zeros, then the bias: the
-    compiled order); the packed h sits in a[A_H + 32 r + 8 nb ..+7], register k = values 2k, 2k+1"""
-    bt = V_BT[r]
-    ops = [X(f"v_accvgpr_read_b32 {vr(bt + k)}, {ar(A_H + 32 * r + 8 * nb + k)}", need_vm=(f"h{r}",) if k == 0 else ()) for k in range(8)]
-    for k in range(7, -1, -1):
-        ops.append(X(f"v_cvt_f32_f16_sdwa {vr(bt + 2 * k + 1)}, {vr(bt + k)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"))
-        ops.append(X(f"v_cvt_f32_f16_e32 {vr(bt + 2 * k)}, {vr(bt + k)}"))
-    for j in range(8):
-        ops.append(X(f"v_pk_add_f32 {vr(bt + 2 * j, 2)}, {vr(bt + 2 * j, 2)}, 0 op_sel_hi:[1,0]"))
-    for j in range(8):
-        ops.append(X(f"v_pk_add_f32 {vr(bt + 2 * j, 2)}, {vr(bt + 2 * j, 2)}, {vr(bias_reg + 2 * j, 2)}",
-                     need_lds=(f"{btag}_{j // 2}",) if j % 2 == 0 else ()))
-    return ops  # 8 + 16 + 8 + 8 = 40
+V_BSTAGE = 112   # = O(1, 3): free while the out-projection's last chain has not started, and at the item seam
+
+
+def h_prep_ops(nb, blocks=(0, 1)):
+    """BT[r] = (f32(h rows of block r, feature block nb) + 0) + bo block, r = 0, 1  (load_hblock on zeros, then the bias: the
+    compiled order); the fp16 rows sit in v[V_AC + 32 r + 8 nb ..+7] as loaded, register k = values 2k, 2k+1; the bias block is
+    requested first (LDS latency behind the conversions) into v[V_BSTAGE..+15]"""
+    ops = bias_reads(V_BSTAGE, LBO + 128 * nb, f"bo{nb}")
+    for r in blocks:
+        bt, src = V_BT[r], V_AC + 32 * r + 8 * nb
+        for k in range(8):
+            ops.append(X(f"v_cvt_f32_f16_e32 {vr(bt + 2 * k)}, {vr(src + k)}", need_vm=(f"h{r}",) if k == 0 else ()))
+            ops.append(X(f"v_cvt_f32_f16_sdwa {vr(bt + 2 * k + 1)}, {vr(src + k)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"))
+        for j in range(8):
+            ops.append(X(f"v_pk_add_f32 {vr(bt + 2 * j, 2)}, {vr(bt + 2 * j, 2)}, 0 op_sel_hi:[1,0]"))
+    for r in blocks:
+        for j in range(8):
+            ops.append(X(f"v_pk_add_f32 {vr(V_BT[r] + 2 * j, 2)}, {vr(V_BT[r] + 2 * j, 2)}, {vr(V_BSTAGE + 2 * j, 2)}",
+                         need_lds=(f"bo{nb}_{j // 2}",) if (r == blocks[0] and j % 2 == 0) else ()))
+    return ops  # 4 + 2 x 24 + 16 = 68
 
 
 def frag_read(slot, frag, wf, tag):
@@ -235,100 +240,147 @@ def frag_read(slot, frag, wf, tag):
     return L(f"ds_read_b128 {ar(A_WF + 4 * wf, 4)}, {vr(addr)} offset:{off}", tag=tag)
 
 
-def place_frag_reads(gaps, reads, la):
-    """reads[f] feeds MFMAs 2f, 2f+1: issue it `la` fragments ahead (the first `la` before the first MFMA)"""
-    for f, op in enumerate(reads):
-        gaps[max(0, 2 * (f - la))].append(op)
-
-
 LA = 6
 
 
-def layernorm_ops(r, first_tag):
-    """LayerNorm (no affine part) of block r: x = O[r] -> deviations in v[V_AC..+63] -> scaled -> XP[r] (bf16 B-operand
-    fragments: xp[ks] = values 8 ks .. 8 ks + 7).  Operation order of layernorm_regs() as compiled."""
-    x0 = O(r, 0)
-    d0 = V_AC
-    ops = [X(f"v_add_f32 {vr(V_S)}, 0, {vr(x0)}")]
-    for e in range(1, 64):
-        ops.append(X(f"v_add_f32 {vr(V_S)}, {vr(x0 + e)}, {vr(V_S)}"))
-    ops.append([Ins(f"v_mov_b32 {vr(V_TMP)}, {vr(V_S)}"), Ins("s_nop 1"), Ins(f"v_permlane32_swap_b32 {vr(V_S)}, {vr(V_TMP)}")])
-    ops.append(X(f"v_add_f32 {vr(V_S)}, {vr(V_S)}, {vr(V_TMP)}"))
-    ops.append(X(f"v_mul_f32 {vr(V_MEAN)}, 0x3c000000, {vr(V_S)}"))
-    for p in range(32):
-        ops.append(X(f"v_pk_add_f32 {vr(d0 + 2 * p, 2)}, {vr(x0 + 2 * p, 2)}, {vr(V_MEAN, 2)} op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]"))
-    # ss = fma(d0, d0, d1 * d1); then per pair: ss = fma(d_even, d_even, ss); ss = d_odd * d_odd + ss
-    ops.append(X(f"v_mul_f32 {vr(V_M2)}, {vr(d0 + 1)}, {vr(d0 + 1)}"))
-    ops.append(X(f"v_fma_f32 {vr(V_SS)}, {vr(d0)}, {vr(d0)}, {vr(V_M2)}"))
-    for p in range(1, 32):
-        ops.append(X(f"v_mul_f32 {vr(V_M2)}, {vr(d0 + 2 * p + 1)}, {vr(d0 + 2 * p + 1)}"))
-        ops.append(X(f"v_fmac_f32 {vr(V_SS)}, {vr(d0 + 2 * p)}, {vr(d0 + 2 * p)}"))
-        ops.append(X(f"v_add_f32 {vr(V_SS)}, {vr(V_M2)}, {vr(V_SS)}"))
-    ops.append([Ins(f"v_mov_b32 {vr(V_TMP)}, {vr(V_SS)}"), Ins("s_nop 1"), Ins(f"v_permlane32_swap_b32 {vr(V_SS)}, {vr(V_TMP)}")])
-    ops.append(X(f"v_add_f32 {vr(V_SS)}, {vr(V_SS)}, {vr(V_TMP)}"))
-    # var + eps (contracted), IEEE sqrt, IEEE 1 / x: the compiled sequences
-    seq = [
-        f"v_mov_b32 {vr(V_R0)}, 0x3727c5ac",
-        f"v_fmac_f32 {vr(V_R0)}, 0x3c000000, {vr(V_SS)}",                       # x = ss / 128 + eps
-        f"v_mul_f32 {vr(V_R1)}, 0x4f800000, {vr(V_R0)}",
-        f"v_mov_b32 {vr(V_R2)}, 0xf800000",
-        f"v_cmp_gt_f32 vcc, {vr(V_R2)}, {vr(V_R0)}",
-        f"v_cndmask_b32 {vr(V_R0)}, {vr(V_R0)}, {vr(V_R1)}, vcc",                # scaled x
-        f"v_sqrt_f32 {vr(V_R1)}, {vr(V_R0)}",
-        "s_nop 0",
-        f"v_add_u32 {vr(V_R2)}, -1, {vr(V_R1)}",
-        f"v_fma_f32 {vr(V_R3)}, -{vr(V_R2)}, {vr(V_R1)}, {vr(V_R0)}",
-        f"v_cmp_ge_f32 {sr(S_CMP, 2)}, 0, {vr(V_R3)}",
-        f"v_add_u32 {vr(V_R3)}, 1, {vr(V_R1)}",
-        f"v_cndmask_b32 {vr(V_R2)}, {vr(V_R1)}, {vr(V_R2)}, {sr(S_CMP, 2)}",
-        f"v_fma_f32 {vr(V_R1)}, -{vr(V_R3)}, {vr(V_R1)}, {vr(V_R0)}",
-        f"v_cmp_lt_f32 {sr(S_CMP, 2)}, 0, {vr(V_R1)}",
-        "s_nop 1",
-        f"v_cndmask_b32 {vr(V_R1)}, {vr(V_R2)}, {vr(V_R3)}, {sr(S_CMP, 2)}",
-        f"v_mul_f32 {vr(V_R2)}, 0x37800000, {vr(V_R1)}",
-        f"v_cndmask_b32 {vr(V_R1)}, {vr(V_R1)}, {vr(V_R2)}, vcc",
-        f"v_mov_b32 {vr(V_R2)}, 0x260",
-        f"v_cmp_class_f32 vcc, {vr(V_R0)}, {vr(V_R2)}",
-        "s_nop 1",
-        f"v_cndmask_b32 {vr(V_R0)}, {vr(V_R1)}, {vr(V_R0)}, vcc",                # sd = sqrt(x)
-        f"v_div_scale_f32 {vr(V_R1)}, {sr(S_CMP, 2)}, {vr(V_R0)}, {vr(V_R0)}, 1.0",
-        f"v_rcp_f32 {vr(V_R2)}, {vr(V_R1)}",
-        "s_nop 0",
-        f"v_fma_f32 {vr(V_R3)}, -{vr(V_R1)}, {vr(V_R2)}, 1.0",
-        f"v_fmac_f32 {vr(V_R2)}, {vr(V_R3)}, {vr(V_R2)}",
-        f"v_div_scale_f32 {vr(V_R3)}, vcc, 1.0, {vr(V_R0)}, 1.0",
-        f"v_mul_f32 {vr(V_R4)}, {vr(V_R3)}, {vr(V_R2)}",
-        f"v_fma_f32 {vr(V_R5)}, -{vr(V_R1)}, {vr(V_R4)}, {vr(V_R3)}",
-        f"v_fmac_f32 {vr(V_R4)}, {vr(V_R5)}, {vr(V_R2)}",
-        f"v_fma_f32 {vr(V_R1)}, -{vr(V_R1)}, {vr(V_R4)}, {vr(V_R3)}",
-        "s_nop 3",
-        f"v_div_fmas_f32 {vr(V_R1)}, {vr(V_R1)}, {vr(V_R2)}, {vr(V_R4)}",
-        f"v_div_fixup_f32 {vr(V_MEAN)}, {vr(V_R1)}, {vr(V_R0)}, 1.0",          # rstd (V_MEAN is free now; an aligned pair's low half)
+class Seg:
+    """MFMAs mf[0..n) with fillers gaps[k] in front of mf[k] (gaps[n] behind the last); reads[f] feeds mf[2f], mf[2f+1] and is
+    issued LA fragments ahead -- the first LA (`head`) by whatever runs before this segment"""
+
+    def __init__(self, t, mf, reads):
+        self.t, self.mf, self.reads = t, mf, reads
+        self.gaps = [[] for _ in range(len(mf) + 1)]
+        for f, op in enumerate(reads[LA:]):
+            self.gaps[2 * f].append(op)
+        self.head = reads[:LA]
+
+    def put(self, ops, lo, hi):
+        spread(self.gaps, ops, lo, hi)
+
+    def emit(self, body):
+        emit_seg(body, self.mf, self.gaps)
+
+
+def interleave(a, b):
+    out = []
+    for k in range(max(len(a), len(b))):
+        if k < len(a):
+            out.append(a[k])
+        if k < len(b):
+            out.append(b[k])
+    return out
+
+
+def rstd_seq(sc):
+    """x = ss / 128 + eps (contracted) -> IEEE sqrt -> IEEE 1 / x, the compiled sequences; scalars sc = dict of registers;
+    result in sc['RS'] (the low half of an aligned pair).  A VALU-written SGPR mask is read two wait states later at the
+    earliest; the division's v_div_scale / v_div_fmas pair communicates through VCC and stays one group."""
+    R0, R1, R2, R3, R4, R5, SS, RS, CA, CB = (sc[k] for k in ("R0", "R1", "R2", "R3", "R4", "R5", "SS", "RS", "CMPA", "CMPB"))
+    groups = [
+        [f"v_mov_b32 {vr(R0)}, 0x3727c5ac"],
+        [f"v_fmac_f32 {vr(R0)}, 0x3c000000, {vr(SS)}"],
+        [f"v_mul_f32 {vr(R1)}, 0x4f800000, {vr(R0)}"],
+        [f"v_mov_b32 {vr(R2)}, 0xf800000"],
+        [f"v_cmp_gt_f32 {sr(CB, 2)}, {vr(R2)}, {vr(R0)}", "s_nop 1", f"v_cndmask_b32 {vr(R0)}, {vr(R0)}, {vr(R1)}, {sr(CB, 2)}"],
+        [f"v_sqrt_f32 {vr(R1)}, {vr(R0)}", "s_nop 0"],
+        [f"v_add_u32 {vr(R2)}, -1, {vr(R1)}"],
+        [f"v_fma_f32 {vr(R3)}, -{vr(R2)}, {vr(R1)}, {vr(R0)}"],
+        [f"v_cmp_ge_f32 {sr(CA, 2)}, 0, {vr(R3)}", f"v_add_u32 {vr(R3)}, 1, {vr(R1)}", "s_nop 0",
+         f"v_cndmask_b32 {vr(R2)}, {vr(R1)}, {vr(R2)}, {sr(CA, 2)}"],
+        [f"v_fma_f32 {vr(R1)}, -{vr(R3)}, {vr(R1)}, {vr(R0)}"],
+        [f"v_cmp_lt_f32 {sr(CA, 2)}, 0, {vr(R1)}", "s_nop 1", f"v_cndmask_b32 {vr(R1)}, {vr(R2)}, {vr(R3)}, {sr(CA, 2)}"],
+        [f"v_mul_f32 {vr(R2)}, 0x37800000, {vr(R1)}"],
+        [f"v_cndmask_b32 {vr(R1)}, {vr(R1)}, {vr(R2)}, {sr(CB, 2)}"],
+        [f"v_mov_b32 {vr(R2)}, 0x260"],
+        [f"v_cmp_class_f32 {sr(CA, 2)}, {vr(R0)}, {vr(R2)}", "s_nop 1", f"v_cndmask_b32 {vr(R0)}, {vr(R1)}, {vr(R0)}, {sr(CA, 2)}"],
+        [f"v_div_scale_f32 {vr(R1)}, {sr(CA, 2)}, {vr(R0)}, {vr(R0)}, 1.0",
+         f"v_rcp_f32 {vr(R2)}, {vr(R1)}",
+         "s_nop 0",
+         f"v_fma_f32 {vr(R3)}, -{vr(R1)}, {vr(R2)}, 1.0",
+         f"v_fmac_f32 {vr(R2)}, {vr(R3)}, {vr(R2)}",
+         f"v_div_scale_f32 {vr(R3)}, vcc, 1.0, {vr(R0)}, 1.0",
+         f"v_mul_f32 {vr(R4)}, {vr(R3)}, {vr(R2)}",
+         f"v_fma_f32 {vr(R5)}, -{vr(R1)}, {vr(R4)}, {vr(R3)}",
+         f"v_fmac_f32 {vr(R4)}, {vr(R5)}, {vr(R2)}",
+         f"v_fma_f32 {vr(R1)}, -{vr(R1)}, {vr(R4)}, {vr(R3)}",
+         "s_nop 1",
+         f"v_div_fmas_f32 {vr(R1)}, {vr(R1)}, {vr(R2)}, {vr(R4)}",
+         f"v_div_fixup_f32 {vr(RS)}, {vr(R1)}, {vr(R0)}, 1.0"],
     ]
-    ops.append([Ins(t) for t in seq])
+    return [[Ins(t) for t in g] for g in groups]
+
+
+def ln_scalars(r):
+    b = V_BT[r]
+    return {"S": b, "TMP": b + 1, "MEAN": b + 2, "SS": b + 4, "M2": b + 5, "R0": b + 6, "R1": b + 7, "R2": b + 8, "R3": b + 9, "R4": b + 10,
+            "R5": b + 11, "DT": b + 12, "AMAX": b + 14, "CMPA": (24, 28)[r], "CMPB": (26, 82)[r]}
+
+
+def layernorm_ops(r, keep):
+    """LayerNorm (no affine part) of block r: x = O[r] -> XP[r] (bf16 B-operand fragments: xp[ks] = values 8 ks .. 8 ks + 7),
+    operation order of layernorm_regs() as compiled.  keep: the deviations are kept in v[V_AC..+63]; else they are
+    recomputed for the scaling pass (same operation, same bits) so that both blocks' chains can be interleaved."""
+    sc = ln_scalars(r)
+    S, TMP, MEAN, SS, M2, DT = (sc[k] for k in ("S", "TMP", "MEAN", "SS", "M2", "DT"))
+    x0 = O(r, 0)
+    ops = [X(f"v_add_f32 {vr(S)}, 0, {vr(x0)}")]
+    for e in range(1, 64):
+        ops.append(X(f"v_add_f32 {vr(S)}, {vr(x0 + e)}, {vr(S)}"))
+    ops.append([Ins(f"v_mov_b32 {vr(TMP)}, {vr(S)}"), Ins("s_nop 1"), Ins(f"v_permlane32_swap_b32 {vr(S)}, {vr(TMP)}")])
+    ops.append(X(f"v_add_f32 {vr(S)}, {vr(S)}, {vr(TMP)}"))
+    ops.append(X(f"v_mul_f32 {vr(MEAN)}, 0x3c000000, {vr(S)}"))
+
+    def dev(p):
+        d = V_AC + 2 * p if keep else DT
+        return d, X(f"v_pk_add_f32 {vr(d, 2)}, {vr(x0 + 2 * p, 2)}, {vr(MEAN, 2)} op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")
+
+    # ss = fma(d0, d0, d1 * d1); then per pair: ss = fma(d_even, d_even, ss); ss = d_odd * d_odd + ss
     for p in range(32):
-        ops.append(X(f"v_pk_mul_f32 {vr(d0 + 2 * p, 2)}, {vr(d0 + 2 * p, 2)}, {vr(V_MEAN, 2)} op_sel_hi:[1,0]"))
+        d, op = dev(p)
+        ops.append(op)
+        ops.append(X(f"v_mul_f32 {vr(M2)}, {vr(d + 1)}, {vr(d + 1)}"))
+        if p == 0:
+            ops.append(X(f"v_fma_f32 {vr(SS)}, {vr(d)}, {vr(d)}, {vr(M2)}"))
+        else:
+            ops.append(X(f"v_fmac_f32 {vr(SS)}, {vr(d)}, {vr(d)}"))
+            ops.append(X(f"v_add_f32 {vr(SS)}, {vr(M2)}, {vr(SS)}"))
+    ops.append([Ins(f"v_mov_b32 {vr(TMP)}, {vr(SS)}"), Ins("s_nop 1"), Ins(f"v_permlane32_swap_b32 {vr(SS)}, {vr(TMP)}")])
+    ops.append(X(f"v_add_f32 {vr(SS)}, {vr(SS)}, {vr(TMP)}"))
+    RS = MEAN if keep else sc["R2"]     # rstd: low half of an aligned pair (the mean is needed again when the deviations are recomputed)
+    ops += rstd_seq(dict(sc, RS=RS))
     for p in range(32):
-        t = V_T + (p & 7)
-        ops.append([Ins(f"v_cvt_pk_bf16_f32 {vr(t)}, {vr(d0 + 2 * p)}, {vr(d0 + 2 * p + 1)}"),
-                    Ins(f"v_accvgpr_write_b32 {ar(A_XP + 32 * r + p)}, {vr(t)}")])
+        t = V_T + 4 * r + (p & 3)
+        if keep:
+            d = V_AC + 2 * p
+            grp = []
+        else:
+            d, op = dev(p)
+            grp = list(op)
+        grp += [Ins(f"v_pk_mul_f32 {vr(d, 2)}, {vr(d, 2)}, {vr(RS, 2)} op_sel_hi:[1,0]"),
+                Ins(f"v_cvt_pk_bf16_f32 {vr(t)}, {vr(d)}, {vr(d + 1)}"), Ins(f"v_accvgpr_write_b32 {ar(A_XP + 32 * r + p)}, {vr(t)}")]
+        ops.append(grp)
     return ops
 
 
+def layernorm_pair():
+    return interleave(layernorm_ops(0, True), layernorm_ops(1, False))
+
+
 def store_h_ops(r):
-    """store_hblock(O[r]): |x| maximum (v_max3 chain), clamp to +-65504 (v_med3), fp16 pairs, 8 stores; then the rare
-    saturation count (out of line)"""
+    """store_hblock(O[r]): |x| maximum (v_max3 chain), clamp to +-65504 (v_med3), fp16 pairs, 8 stores"""
+    sc = ln_scalars(r)
+    AMAX, R4, R5 = sc["AMAX"], sc["R4"], sc["R5"]
     x0 = O(r, 0)
-    ops = [X(f"v_max3_f32 {vr(V_AMAX)}, |{vr(x0)}|, 0, |{vr(x0 + 1)}|")]
+    ops = [X(f"v_max3_f32 {vr(AMAX)}, |{vr(x0)}|, 0, |{vr(x0 + 1)}|")]
     for p in range(1, 32):
-        ops.append(X(f"v_max3_f32 {vr(V_AMAX)}, {vr(V_AMAX)}, |{vr(x0 + 2 * p)}|, |{vr(x0 + 2 * p + 1)}|"))
+        ops.append(X(f"v_max3_f32 {vr(AMAX)}, {vr(AMAX)}, |{vr(x0 + 2 * p)}|, |{vr(x0 + 2 * p + 1)}|"))
     for k in range(8):      # fragment k = values 8k .. 8k+7 of the block
-        t = V_T + 4 * (k & 1)
+        t = V_T + 4 * r
         grp = []
         for q in range(4):
             a, b = x0 + 8 * k + 2 * q, x0 + 8 * k + 2 * q + 1
-            grp += [Ins(f"v_med3_f32 {vr(V_R4)}, {vr(a)}, {sr(S_T3)}, {vr(V_C65)}"), Ins(f"v_med3_f32 {vr(V_R5)}, {vr(b)}, {sr(S_T3)}, {vr(V_C65)}"),
-                    Ins(f"v_cvt_pk_f16_f32 {vr(t + q)}, {vr(V_R4)}, {vr(V_R5)}")]
+            grp += [Ins(f"v_med3_f32 {vr(R4)}, {vr(a)}, {sr(S_T3)}, {vr(V_C65)}"), Ins(f"v_med3_f32 {vr(R5)}, {vr(b)}, {sr(S_T3)}, {vr(V_C65)}"),
+                    Ins(f"v_cvt_pk_f16_f32 {vr(t + q)}, {vr(R4)}, {vr(R5)}")]
         off, imm = goff(r, k)
         grp.append(Ins(f"global_store_dwordx4 {vr(off)}, {vr(t, 4)}, {sr(S_HC, 2)} offset:{imm}", "vmem"))
         ops.append(grp)
@@ -364,12 +416,26 @@ def qkv_epilogue_ops(rb, r, nbl):
     return ops
 
 
+def next_loads(kind, ks_range):
+    """the NEXT item's context fragments (-> AP, the B operands of its out-projection) / residual rows (-> v[V_AC..], fp16)"""
+    ops = []
+    for r in range(2):
+        for k in ks_range:
+            off, imm = goff(r, k)
+            if kind == "ctx":
+                ops.append(M(f"global_load_dwordx4 {ar(AP(r, k), 4)}, {vr(off)}, {sr(S_CTXN, 2)} offset:{imm}", tag=f"ctx{r}_{k}"))
+            else:
+                ops.append(M(f"global_load_dwordx4 {vr(V_AC + 32 * r + 4 * k, 4)}, {vr(off)}, {sr(S_HN, 2)} offset:{imm}", tag=f"h{r}" if k == ks_range[-1] else None))
+    return ops
+
+
+CTX_TAGS = {r: tuple(f"ctx{r}_{k}" for k in range(8)) for r in range(2)}
+
+
 # ------------------------------------------------------------------------------------------------ segments
-def seg_out(body):
+def seg_out():
     """ring block 0: o[r] = (h[r] + bo) + ctx[r] Wo^T; the C operands of nb = 0 were prepared at the end of the previous
     item (or by the prologue)"""
-    body += acquire(0)
-    stamp(body, 11)
     mf, reads = [], []
     for nb in range(4):
         for ks in range(8):
@@ -378,48 +444,37 @@ def seg_out(body):
             reads.append(frag_read(0, f, f % 16, tag))
             for r in range(2):
                 c = vr(V_BT[r], 16) if ks == 0 else vr(O(r, nb), 16)
-                mf.append(mfma(vr(O(r, nb), 16), ar(A_WF + 4 * (f % 16), 4), ar(AP(r, ks), 4), c, need=(tag,) if r == 0 else ()))
-    gaps = [[] for _ in range(len(mf) + 1)]
-    place_frag_reads(gaps, reads, LA)
-    spread(gaps, dma_ops(2), 1, 15)
+                mf.append(mfma(vr(O(r, nb), 16), ar(A_WF + 4 * (f % 16), 4), ar(AP(r, ks), 4), c, need=(tag,) if r == 0 else (),
+                               need_vm=(f"ctx{r}_{ks}",) if nb == 0 else ()))
+    s = Seg(0, mf, reads)
     for nb in range(1, 4):   # C operands of the next feature block while this one's chain runs
-        breg = V_AC + 16 * (nb & 1)
-        ops = bias_reads(breg, LBO + 128 * nb, f"bo{nb}") + h_prep_ops(0, nb, breg, f"bo{nb}") + h_prep_ops(1, nb, breg, f"bo{nb}")
-        spread(gaps, ops, 16 * (nb - 1) + 3, 16 * nb - 1)
-    emit_seg(body, mf, gaps)
-    stamp(body, 1)
+        s.put(h_prep_ops(nb), 16 * (nb - 1) + 3, 16 * nb - 1)
+    return s
 
 
-def seg_ln1(body):
+def ln1_phase(body):
     body.append(Ins("s_nop 7"))
     body.append(Ins("s_nop 7"))
-    for r in range(2):
-        for op in layernorm_ops(r, None):
-            body.extend(op)
-    # o = h1 + b2: the residual stream enters the FFN2 accumulators (bias quads through BT1: the LayerNorm scalars live in BT0)
+    for op in layernorm_pair():
+        body.extend(op)
+    # o = h1 + b2: the residual stream enters the FFN2 accumulators (the 128 bias values of a lane through v[V_AC..+63], free again)
     for nb in range(4):
-        for g in range(4):
-            tag = f"b2_{nb}_{g}"
-            treg = V_BT[1] + 4 * (g & 3)
-            body.extend(L(f"ds_read_b128 {vr(treg, 4)}, {vr(V_BIAS)} offset:{LB2 + 128 * nb + 32 * g}", tag=tag))
-        for g in range(4):
-            treg = V_BT[1] + 4 * (g & 3)
-            for r in range(2):
-                for j in range(2):
-                    body.extend(X(f"v_pk_add_f32 {vr(O(r, nb) + 4 * g + 2 * j, 2)}, {vr(O(r, nb) + 4 * g + 2 * j, 2)}, {vr(treg + 2 * j, 2)}",
-                                  need_lds=(f"b2_{nb}_{g}",) if (r, j) == (0, 0) else ()))
+        for op in bias_reads(V_AC + 16 * nb, LB2 + 128 * nb, f"b2_{nb}"):
+            body.extend(op)
+    for nb in range(4):
+        for r in range(2):
+            for j in range(8):
+                body.extend(X(f"v_pk_add_f32 {vr(O(r, nb) + 2 * j, 2)}, {vr(O(r, nb) + 2 * j, 2)}, {vr(V_AC + 16 * nb + 2 * j, 2)}",
+                              need_lds=(f"b2_{nb}_{j // 2}",) if (r == 0 and j % 2 == 0) else ()))
     for op in bias_reads(V_BT[0], LB1 + 0, "b1_0_0") + bias_reads(V_BT[1], LB1 + 128, "b1_0_1"):
         body.extend(op)
     stamp(body, 2)
 
 
-def seg_ffn(body, c):
-    """chunk c (128 hidden units) in two halves of 64: FFN1 half -> relu / pack -> FFN2 half, W1 block 1 + 2c and W2 block 2 + 2c"""
-    t1, t2 = 1 + 2 * c, 2 + 2 * c
-    s1, s2 = t1 % NRING, t2 % NRING
-    # ---- segment A: FFN1 of half 0 (n-blocks 0, 1 of the chunk)
-    body += acquire(t1)
-    stamp(body, 11)
+def seg_ffn_a(c):
+    """chunk c, segment A (ring block 1 + 2c = W1 chunk): FFN1 of half 0 (hidden units 0..63 of the chunk)"""
+    t1 = 1 + 2 * c
+    s1 = t1 % NRING
     mf, reads = [], []
     for q in range(2):
         for ks in range(8):
@@ -430,22 +485,15 @@ def seg_ffn(body, c):
                 cc = vr(V_BT[q], 16) if ks == 0 else vr(AC(r, q), 16)
                 need = ((tag,) if r == 0 else ()) + (bias_tags(f"b1_{c}_{q}") if ks == 0 and r == 0 else ())
                 mf.append(mfma(vr(AC(r, q), 16), ar(A_WF + 4 * (f % 16), 4), ar(XP(r, ks), 4), cc, need=need))
-    gaps = [[] for _ in range(len(mf) + 1)]
-    place_frag_reads(gaps, reads, LA)
-    spread(gaps, dma_ops(t1 + AHEAD), 1, 15)
-    if c == 0:  # the next item's residual rows
-        hl = []
-        for r in range(2):
-            for k in range(8):
-                off, imm = goff(r, k)
-                hl.append(M(f"global_load_dwordx4 {ar(A_H + 32 * r + 4 * k, 4)}, {vr(off)}, {sr(S_HN, 2)} offset:{imm}", tag=f"h{r}" if k == 7 else None))
-        spread(gaps, hl, 2, 18)
-    spread(gaps, relu_pack_ops(0, 0, 0) + relu_pack_ops(1, 0, 0), 19, 32)
-    emit_seg(body, mf, gaps)
-    # ---- segment B: FFN2 half 0, FFN1 half 1, FFN2 half 1
-    stamp(body, 3 + c)
-    body += acquire(t2)
-    stamp(body, 11)
+    s = Seg(t1, mf, reads)
+    s.put(relu_pack_ops(0, 0, 0) + relu_pack_ops(1, 0, 0), 19, 32)
+    return s
+
+
+def seg_ffn_b(c):
+    """chunk c, segment B (ring block 2 + 2c = W2 chunk; the W1 chunk stays resident): FFN2 half 0, FFN1 half 1, FFN2 half 1"""
+    t1, t2 = 1 + 2 * c, 2 + 2 * c
+    s1, s2 = t1 % NRING, t2 % NRING
     mf, reads = [], []
     fcount = 0
 
@@ -473,52 +521,58 @@ def seg_ffn(body, c):
                 need = ((tag,) if r == 0 else ()) + (bias_tags(f"b1_{c}_{2 + q}") if ks == 0 and r == 0 else ())
                 mf.append(mfma(vr(AC(r, q), 16), ar(A_WF + 4 * wf, 4), ar(XP(r, ks), 4), cc, need=need))
     ffn2(1)
-    gaps = [[] for _ in range(len(mf) + 1)]
-    place_frag_reads(gaps, reads, LA)
-    spread(gaps, dma_ops(t2 + AHEAD), 1, 15)
-    spread(gaps, relu_pack_ops(0, 1, 1) + relu_pack_ops(1, 1, 1), 3, 15)
+    s = Seg(t2, mf, reads)
+    s.put(relu_pack_ops(0, 1, 1) + relu_pack_ops(1, 1, 1), 3, 15)
     # bias of half 1's chains (BT0 / BT1 were consumed by the first MFMAs of segment A's chains)
-    spread(gaps, bias_reads(V_BT[0], LB1 + 512 * c + 256, f"b1_{c}_2") + bias_reads(V_BT[1], LB1 + 512 * c + 384, f"b1_{c}_3"), 4, 20)
-    spread(gaps, relu_pack_ops(0, 0, 2) + relu_pack_ops(1, 0, 2), 51, 63)
-    spread(gaps, relu_pack_ops(0, 1, 3) + relu_pack_ops(1, 1, 3), 67, 79)
+    s.put(bias_reads(V_BT[0], LB1 + 512 * c + 256, f"b1_{c}_2") + bias_reads(V_BT[1], LB1 + 512 * c + 384, f"b1_{c}_3"), 4, 20)
+    s.put(relu_pack_ops(0, 0, 2) + relu_pack_ops(1, 0, 2), 51, 63)
+    s.put(relu_pack_ops(0, 1, 3) + relu_pack_ops(1, 1, 3), 67, 79)
     if c < 3:   # bias of the next chunk's first half
-        spread(gaps, bias_reads(V_BT[0], LB1 + 512 * (c + 1), f"b1_{c + 1}_0") + bias_reads(V_BT[1], LB1 + 512 * (c + 1) + 128, f"b1_{c + 1}_1"), 66, 90)
-    emit_seg(body, mf, gaps)
-    stamp(body, 3 + c)
+        s.put(bias_reads(V_BT[0], LB1 + 512 * (c + 1), f"b1_{c + 1}_0") + bias_reads(V_BT[1], LB1 + 512 * (c + 1) + 128, f"b1_{c + 1}_1"), 66, 90)
+    else:       # the next item's context, K-steps 0..3 (AP[r][0..3] were last read by MFMA 31)
+        s.put(next_loads("ctx", range(0, 4)), 36, 92)
+    return s
 
 
-def seg_end(body):
-    """the finished residual rows go back to HBM (fp16), LayerNorm of the next layer, the next item's context"""
+def end_phase(body):
+    """the finished residual rows go back to HBM (fp16), LayerNorm of the next layer"""
     for _ in range(3):
         body.append(Ins("s_nop 7"))
-    for r in range(2):
-        for k in range(8):
-            off, imm = goff(r, k)
-            body.extend(M(f"global_load_dwordx4 {ar(AP(r, k), 4)}, {vr(off)}, {sr(S_CTXN, 2)} offset:{imm}", tag=f"ctx{r}" if k == 7 else None))
+    for op in next_loads("ctx", range(4, 8)):
+        body.extend(op)
     body.append(Ins(f"s_mov_b32 {sr(S_T3)}, 0xc77fe000"))
     body.append(Ins(f"v_mov_b32 {vr(V_C65)}, 0x477fe000"))
+    for op in interleave(store_h_ops(0), store_h_ops(1)):
+        body.extend(op)
     for r in range(2):
-        for op in store_h_ops(r):
-            body.extend(op)
         sat, back = f".Lrp_sat{r}", f".Lrp_satback{r}"
-        body.append(Ins(f"v_cmp_nle_f32 vcc, {vr(V_AMAX)}, {vr(V_C65)}"))
+        body.append(Ins(f"v_cmp_nle_f32 vcc, {vr(ln_scalars(r)['AMAX'])}, {vr(V_C65)}"))
         body.append(Ins("s_nop 0"))
         body.append(Ins("s_cmp_lg_u64 vcc, 0"))
         body.append(Ins(f"s_cbranch_scc1 {sat}"))
         body.append(Ins(f"{back}:", "label"))
-        for op in layernorm_ops(r, None):
-            body.extend(op)
+    for op in layernorm_pair():
+        body.extend(op)
     for op in bias_reads(V_BT[0], LBN + 0, "bq0_0") + bias_reads(V_BT[1], LBN + 128, "bq0_1"):
         body.extend(op)
     stamp(body, 7)
 
 
-def seg_qkv(body, rb):
+def qkv_c_ops(rb, nbl):
+    bt = V_BT[nbl & 1]
+    if rb < 2:
+        return bias_reads(bt, LBN + 512 * rb + 128 * nbl, f"bq{rb}_{nbl}")
+    ops = [L(f"ds_read_b32 {vr(bt)}, {vr(V_BIASN)} offset:{128 * nbl}", tag=f"bv_{nbl}")]
+    ops.append([Ins(f"v_mov_b32 {vr(bt + 1)}, {vr(bt)}", need_lds=(f"bv_{nbl}",))])
+    for e in range(2, 16):
+        ops.append(X(f"v_mov_b32 {vr(bt + e)}, {vr(bt)}"))
+    return ops
+
+
+def seg_qkv(rb):
     """ring block 9 + rb: Q (pre-scaled), K in the transposed form, V^T in the swapped form; accumulators = O's registers"""
     t = 9 + rb
     slot = t % NRING
-    body += acquire(t)
-    stamp(body, 11)
     mf, reads = [], []
     for nbl in range(4):
         for ks in range(8):
@@ -534,41 +588,28 @@ def seg_qkv(body, rb):
                 wfr, xpr = ar(A_WF + 4 * (f % 16), 4), ar(XP(r, ks), 4)
                 a_op, b_op = (wfr, xpr) if rb < 2 else (xpr, wfr)
                 mf.append(mfma(vr(O(r, nbl), 16), a_op, b_op, c, need=need))
-    gaps = [[] for _ in range(len(mf) + 1)]
-    place_frag_reads(gaps, reads, LA)
-    spread(gaps, dma_ops(t + AHEAD), 1, 15)
-
-    def c_ops(rb_, nbl):
-        bt = V_BT[nbl & 1]
-        if rb_ < 2:
-            return bias_reads(bt, LBN + 512 * rb_ + 128 * nbl, f"bq{rb_}_{nbl}")
-        ops = [L(f"ds_read_b32 {vr(bt)}, {vr(V_BIASN)} offset:{128 * nbl}", tag=f"bv_{nbl}")]
-        ops.append([Ins(f"v_mov_b32 {vr(bt + 1)}, {vr(bt)}", need_lds=(f"bv_{nbl}",))] )
-        for e in range(2, 16):
-            ops.append(X(f"v_mov_b32 {vr(bt + e)}, {vr(bt)}"))
-        return ops
-
+    s = Seg(t, mf, reads)
     # C operands: n-blocks 0 / 1 were prepared by the previous segment; 2 / 3 here once BT0 / BT1 have been consumed
-    spread(gaps, c_ops(rb, 2), 3, 20)
-    spread(gaps, c_ops(rb, 3), 19, 36)
-    for nbl in range(4):   # epilogue of chain nbl under the MFMAs of chain nbl + 1 (the last one behind the segment)
-        ops = qkv_epilogue_ops(rb, 0, nbl) + qkv_epilogue_ops(rb, 1, nbl)
-        if nbl < 3:
-            spread(gaps, ops, 16 * (nbl + 1) + 3, 16 * (nbl + 2) - 1)
-        else:
-            tail = ops
+    def put_c(rb_, nbl, lo, hi):
+        ops = qkv_c_ops(rb_, nbl)
+        if rb_ < 2:
+            s.put(ops, lo, hi)
+        else:   # the broadcast waits for its one LDS read: request it a few MFMAs earlier
+            s.put(ops[:1], lo, lo + 1)
+            s.put(ops[1:], lo + 5, hi)
+
+    put_c(rb, 2, 3, 20)
+    put_c(rb, 3, 19, 36)
     if rb < 2:
-        spread(gaps, c_ops(rb + 1, 0), 36, 50)
-        spread(gaps, c_ops(rb + 1, 1), 50, 63)
-    emit_seg(body, mf, gaps)
-    for _ in range(3):
-        body.append(Ins("s_nop 7"))
-    for op in tail:
-        body.extend(op)
-    if rb == 2:   # C operands of the next item's first out-projection chains
-        for op in bias_reads(V_AC, LBO, "bo0") + h_prep_ops(0, 0, V_AC, "bo0") + h_prep_ops(1, 0, V_AC, "bo0"):
-            body.extend(op)
-    stamp(body, 8 + rb)
+        put_c(rb + 1, 0, 36, 50)
+        put_c(rb + 1, 1, 50, 63)
+    for nbl in range(3):   # epilogue of chain nbl under the MFMAs of chain nbl + 1
+        s.put(qkv_epilogue_ops(rb, 0, nbl) + qkv_epilogue_ops(rb, 1, nbl), 16 * (nbl + 1) + 3, 16 * (nbl + 2) - 1)
+    if rb > 0:             # the previous block's last chain: its registers are rewritten by this block's MFMA 48
+        s.put(qkv_epilogue_ops(rb - 1, 0, 3) + qkv_epilogue_ops(rb - 1, 1, 3), 4, 16)
+    if rb == 0:            # the next item's residual rows (the FFN1 accumulators are dead until the next item's chunk 0)
+        s.put(next_loads("h", range(0, 8)), 6, 60)
+    return s
 
 
 def item_params():
@@ -594,27 +635,60 @@ def zero_pad_ctx():
         skip = f".Lrp_nz{r}"
         out += [Ins(f"s_lshl_b32 {sr(S_T1)}, {sr(S_PAIR)}, 1"), Ins(f"s_add_u32 {sr(S_T1)}, {sr(S_T1)}, {r}"),
                 Ins(f"s_cmp_lt_u32 {sr(S_T1)}, {sr(S_NBLK)}"), Ins(f"s_cbranch_scc1 {skip}")]
-        out += [Ins(f"v_accvgpr_write_b32 {ar(AP(r, 0) + k)}, 0", need_vm=(f"ctx{r}",) if k == 0 else ()) for k in range(32)]
+        out += [Ins(f"v_accvgpr_write_b32 {ar(AP(r, 0) + k)}, 0", need_vm=CTX_TAGS[r] if k == 0 else ()) for k in range(32)]
         out.append(Ins(f"{skip}:", "label"))
     return out
 
 
+def wire(segs, k, e_gap, dma_lo, dma_hi, head_lo):
+    """inside segment k: acquire the NEXT segment's ring block early, issue the block three ahead behind that barrier, and
+    request the next segment's first weight fragments"""
+    cur, nxt = segs[k], segs[(k + 1) % len(segs)]
+    cur.put([acquire(nxt.t)], e_gap, e_gap + 1)
+    cur.put(dma_ops(nxt.t + AHEAD), dma_lo, dma_hi)
+    for j, op in enumerate(nxt.head):
+        cur.gaps[min(head_lo + j, len(cur.gaps) - 1)].append(op)
+
+
 def build_item():
+    out = seg_out()
+    fa = [seg_ffn_a(c) for c in range(4)]
+    fb = [seg_ffn_b(c) for c in range(4)]
+    qkv = [seg_qkv(rb) for rb in range(3)]
+    segs = [out] + [x for c in range(4) for x in (fa[c], fb[c])] + qkv
+    for k, sg in enumerate(segs):
+        n = len(sg.mf)
+        if n == 64:
+            wire(segs, k, 38, 39, 56, 56)
+        elif n == 32:   # W1 segments
+            wire(segs, k, 18, 19, 30, 26)
+        else:           # W2 segments: the W1 chunk is read until MFMA 63; the slot the new block lands in is the W1 chunk's
+            wire(segs, k, 66, 67, 88, 88)
     body = []
+    stamp(body, 11)
     body += item_params()
     body += zero_pad_ctx()
     stamp(body, 0)
-    seg_out(body)
-    seg_ln1(body)
+    out.emit(body)
+    stamp(body, 1)
+    ln1_phase(body)
     for c in range(4):
-        seg_ffn(body, c)
-    seg_end(body)
+        fa[c].emit(body)
+        fb[c].emit(body)
+        stamp(body, 3 + c)
+    end_phase(body)
     for rb in range(3):
-        seg_qkv(body, rb)
-    return body
+        qkv[rb].emit(body)
+        if rb == 2:
+            for _ in range(3):
+                body.append(Ins("s_nop 7"))
+            for op in qkv_epilogue_ops(2, 0, 3) + qkv_epilogue_ops(2, 1, 3) + h_prep_ops(0):
+                body.extend(op)
+        stamp(body, 8 + rb)
+    return body, out
 
 
-def build_prologue():
+def build_prologue(first_head):
     """operands -> fixed homes, constants, the first two ring blocks, the first item's context and residual rows"""
     p = []
 
@@ -670,7 +744,7 @@ def build_prologue():
         i(f"s_mov_b32 {sr(S_PREV)}, {sr(S_TM)}")
     i(f"s_cmp_lt_u32 {sr(S_PAIR)}, {sr(S_NITEMS)}")
     i("s_cbranch_scc0 .Lrp_exit")
-    for t in (0, 1):
+    for t in (0, 1, 2):
         for op in dma_ops(t):
             p.extend(op)
     # first item: S_CTXN / S_HN = this pair
@@ -679,19 +753,15 @@ def build_prologue():
         i(f"s_lshl_b32 {sr(S_T1)}, {sr(S_PAIR)}, 14")
         i(f"s_add_u32 {sr(dst)}, {sr(base)}, {sr(S_T1)}")
         i(f"s_addc_u32 {sr(dst + 1)}, {sr(base + 1)}, {sr(S_T2)}")
-    for r in range(2):
-        for k in range(8):
-            off, imm = goff(r, k)
-            i(f"global_load_dwordx4 {ar(AP(r, k), 4)}, {vr(off)}, {sr(S_CTXN, 2)} offset:{imm}", "vmem", tag=f"ctx{r}" if k == 7 else None)
-    for r in range(2):
-        for k in range(8):
-            off, imm = goff(r, k)
-            i(f"global_load_dwordx4 {ar(A_H + 32 * r + 4 * k, 4)}, {vr(off)}, {sr(S_HN, 2)} offset:{imm}", "vmem", tag=f"h{r}" if k == 7 else None)
+    for op in next_loads("ctx", range(0, 8)) + next_loads("h", range(0, 8)):
+        p.extend(op)
     i("s_waitcnt vmcnt(0)", "drainvm")
-    for op in bias_reads(V_AC, LBO, "bo0") + h_prep_ops(0, 0, V_AC, "bo0") + h_prep_ops(1, 0, V_AC, "bo0"):
+    for op in h_prep_ops(0):
         p.extend(op)
     i("s_waitcnt lgkmcnt(0)", "drain")
     i("s_barrier")
+    for op in first_head:
+        p.extend(op)
     return p
 
 
@@ -753,7 +823,8 @@ def resolve(prologue, item):
 
 
 def emit_all():
-    pl, il = resolve(build_prologue(), build_item())
+    item, out = build_item()
+    pl, il = resolve(build_prologue(out.head), item)
     lines = ["\t// generated by scripts/gen_row_pw.py -- do not edit"] + pl
     lines.append(".Lrp_item:")
     lines += il

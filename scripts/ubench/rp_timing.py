@@ -20,7 +20,7 @@ lib.savad_debug_stamps(buf, 16)
 w = []
 for v in buf: w += [v & 0xffffffff, (v >> 32) & 0xffffffff]
 names = ["item parameters", "out-projection (64 MFMAs)", "LayerNorm 1 + b2", "FFN chunk 0 (128 MFMAs)", "FFN chunk 1", "FFN chunk 2", "FFN chunk 3",
-         "residual store + LayerNorm 2", "Q block (64 MFMAs + tail)", "K block", "V block + next item's C operands", "ring acquires (12 per item)"]
+         "residual store + LayerNorm 2", "Q block (64 MFMAs + tail)", "K block", "V block + next item's C operands", "prologue / loop edge (up to the item top)"]
 tot = sum(w[:12])
 nblk = B * ((T + 31) // 32) if T > 32 else (B + 32 // T - 1) // (32 // T)
 npairs = (nblk + 7) // 8 * 8 // 2
