@@ -1,13 +1,11 @@
 #!/usr/bin/env python3
 """Generator of the hand-scheduled gfx950 instruction stream of `row_pw_kernel_bf16`
-(voice_activity_detection_amd/csrc/savad_row_pw_bf16.inc): the bf16 ROW stage of one encoder layer
+(an EXPERIMENT: scripts/ubench/row_pw/README.md has the measurements and why it is not in the product): the bf16 ROW stage of one encoder layer
 (vad/modeling/transformer.py:160-215 of the reference: attention out-projection + residual, LayerNorm, feed-forward +
 residual, then the NEXT layer's LayerNorm + QKV projection) as a PERSISTENT workgroup of 4 waves, one per SIMD, each
 wave owning a PAIR of 32-row blocks (64 rows), with the whole register file owned by the stream below.
 
-    python scripts/gen_row_pw.py            # rewrites the .inc files
-    python scripts/gen_row_pw.py --check    # exit 1 when a committed .inc is stale (tests/test_abi_and_host.py)
-    python scripts/gen_row_pw.py --out F [--timing]
+    bash scripts/ubench/row_pw/build.sh     # generates gen/*.inc, patches a copy of savad.hip (row_mode 7), builds libsavad_rowpw*.so
 
 Why: row_kernel_bf16 (32 rows per wave, two workgroups per CU, 2-slot weight ring one block ahead) needs 1 KiB of LDS
 reads per 32-cycle MFMA on every SIMD -- the CU's whole 128 B/clk -- streams the layer's 384 KiB of weights once per FOUR
@@ -39,10 +37,9 @@ counts hold across the loop edge.
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
-CSRC = ROOT / "voice_activity_detection_amd" / "csrc"
-OUT = CSRC / "savad_row_pw_bf16.inc"
-OUT_TIMING = CSRC / "savad_row_pw_bf16_timing.inc"
+HERE = Path(__file__).resolve().parent
+OUT = HERE / "gen" / "savad_row_pw_bf16.inc"          # written by build.sh, not tracked
+OUT_TIMING = HERE / "gen" / "savad_row_pw_bf16_timing.inc"
 
 FRAG, BLK, RINGBLK = 1024, 8192, 32768
 D, DFF = 128, 512
@@ -825,7 +822,7 @@ def resolve(prologue, item):
 def emit_all():
     item, out = build_item()
     pl, il = resolve(build_prologue(out.head), item)
-    lines = ["\t// generated by scripts/gen_row_pw.py -- do not edit"] + pl
+    lines = ["\t// generated by scripts/ubench/row_pw/gen_row_pw.py -- do not edit"] + pl
     lines.append(".Lrp_item:")
     lines += il
     lines.append(f"\ts_mov_b32 {sr(S_PAIR)}, {sr(S_NPAIR)}")
@@ -847,7 +844,7 @@ def emit_all():
 
 
 def render(lines):
-    return ("// generated by scripts/gen_row_pw.py -- do not edit (python scripts/gen_row_pw.py rewrites it)\n"
+    return ("// generated by scripts/ubench/row_pw/gen_row_pw.py -- do not edit (python scripts/ubench/row_pw/gen_row_pw.py rewrites it)\n"
             "R\"ASMRP(\n" + "\n".join(lines) + "\n)ASMRP\"\n")
 
 
@@ -865,9 +862,10 @@ def main():
     if "--check" in sys.argv:
         stale = [f for f, t in ((OUT, text), (OUT_TIMING, timing_text)) if not f.exists() or f.read_text() != t]
         if stale:
-            print(f"stale: {[str(f) for f in stale]}: run python scripts/gen_row_pw.py", file=sys.stderr)
+            print(f"stale: {[str(f) for f in stale]}: run python scripts/ubench/row_pw/gen_row_pw.py", file=sys.stderr)
             sys.exit(1)
         return
+    OUT.parent.mkdir(exist_ok=True)
     OUT.write_text(text)
     OUT_TIMING.write_text(timing_text)
     print(f"{OUT}: {len(lines)} lines", file=sys.stderr)

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""64-row bf16 row stage (row_mode 7 = persistent hand-scheduled kernel; --mode 6 = the hipcc-scheduled experiment) against the 32-row one (row_mode 5 = same attention kernel when forced): bits + kernel times.
+"""persistent 64-row bf16 row stage (experiment library, row_mode 7) against the 32-row one (row_mode 5 = same attention kernel when forced): bits + kernel times.
 usage: row64_check.py B T [B T ...]"""
+import os
 import sys
 from pathlib import Path
 
+os.environ.setdefault("SAVAD_LIB", str(Path(__file__).resolve().parent / "libsavad_rowpw.so"))   # bash scripts/ubench/row_pw/build.sh
+
 import torch
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 from voice_activity_detection_amd import SelfAttentiveVAD, seeded_features, seeded_state_dict  # noqa: E402
 
 m = SelfAttentiveVAD(80, 3, 128, 0.5)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """phase stamps of the persistent bf16 row kernel (first wave of workgroup 0): rp_timing.py B T [iters] [lib]
-build the library first: hipcc ... -DSAVAD_TIMING ... -o scripts/ubench/libsavad_timing.so (scripts/ubench/build_timing.sh)"""
+build first: bash scripts/ubench/row_pw/build.sh"""
 import ctypes, os, sys
 sys.path.insert(0, os.getcwd())
-os.environ["SAVAD_LIB"] = os.path.abspath(sys.argv[4] if len(sys.argv) > 4 else "scripts/ubench/libsavad_timing.so")
+os.environ["SAVAD_LIB"] = os.path.abspath(sys.argv[4] if len(sys.argv) > 4 else "scripts/ubench/row_pw/libsavad_rowpw_timing.so")
 import torch
 from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, seeded_features, _lib
 B, T = int(sys.argv[1]), int(sys.argv[2])

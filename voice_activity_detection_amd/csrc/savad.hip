@@ -4,7 +4,6 @@
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
 #include "savad_attn_pw_bf16.h"
-#include "savad_row_pw_bf16.h"
 #include <type_traits>
 #include "savad_logmel.h"
 #include "savad_post.h"
@@ -524,7 +523,7 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
-    if (!m || mode < 0 || mode > 7) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 5) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -605,9 +604,6 @@ int prepare_bf16_launch(savad_model* m) {
     if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::attention_pw_kernel_bf16, bf::PW_LDS_BYTES))) return rc;
-    if ((rc = allow_lds(bf::row_kernel64_bf16<false>, bf::Ring64::NRING * bf::RING_BYTES + 9 * D * 4))) return rc;
-    if ((rc = allow_lds(bf::row_pw_kernel_bf16, bf::RP_LDS_BYTES))) return rc;
-    if ((rc = allow_lds(bf::row_kernel64_bf16<true>, bf::Ring64::NRING * bf::RING_BYTES + 9 * D * 4))) return rc;
     m->lds_attrs_set = true;
     return SAVAD_OK;
 }
@@ -649,7 +645,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     const bool wide = m->row_mode == 2;
     if ((rc = prepare_bf16_launch(m))) return rc;
     Prof prof(m, st);
-    const bool automatic_bf16 = m->row_mode == 0 || m->row_mode == 4 || m->row_mode == 6 || m->row_mode == 7;
+    const bool automatic_bf16 = m->row_mode == 0 || m->row_mode == 4;
     // The persistent attention kernel (one 4 x 64-row workgroup per CU walking (sequence, 8 query blocks) items) wins once
     // every workgroup gets at least three full items of a long key walk; below that its coarse items leave CUs idle
     // while others work.  Measured, attention stage per layer, first-generation / persistent kernel (same bits):
@@ -721,37 +717,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
                                    T, NG);
             }
             prof.mark("attention_bf16");
-            if (m->row_mode == 7 && !last) {  // persistent 4 x 64-row row stage (savad_row_pw_bf16.h)
-                bf::RowPwArgs P7;
-                auto kib = [&](const char* p, const char* base) { return (unsigned)((size_t)(p - base) >> 10); };
-                P7.ws = W;
-                P7.o_ctx = kib(ctxf, W);
-                P7.o_h = kib((const char*)hb, W);
-                P7.o_q = kib(A.qf, W);
-                P7.o_k = kib(A.kf, W);
-                P7.o_vt = kib(A.vtf, W);
-                P7.frag = Fr;
-                P7.o_wo = kib(A.wo_frag, Fr);
-                P7.o_w1 = kib(A.w1_frag, Fr);
-                P7.o_w2 = kib(A.w2_frag, Fr);
-                P7.o_wn = kib(A.wn_frag, Fr);
-                P7.bo = A.bo;
-                P7.b1 = A.b1;
-                P7.b2 = A.b2;
-                P7.bn = A.bn;
-                P7.qscale = c;
-                P7.satcnt = m->d_sat;
-                P7.nblk = bp.nblk;
-                P7.npairs = bp.nblk_pad / 2;
-                const int g7 = P7.npairs / 4 < bf::RP_GRID ? P7.npairs / 4 : bf::RP_GRID;
-                hipLaunchKernelGGL(bf::row_pw_kernel_bf16, dim3(g7), dim3(256), bf::RP_LDS_BYTES, st, P7);
-            } else if (m->row_mode == 6 || m->row_mode == 7) {
-                constexpr int lds64 = bf::Ring64::NRING * bf::RING_BYTES + 9 * D * 4;
-                if (last)
-                    hipLaunchKernelGGL((bf::row_kernel64_bf16<true>), dim3(bp.nblk_pad / 8), dim3(256), lds64, st, ctxf, A);
-                else
-                    hipLaunchKernelGGL((bf::row_kernel64_bf16<false>), dim3(bp.nblk_pad / 8), dim3(256), lds64, st, ctxf, A);
-            } else if (last)
+            if (last)
                 hipLaunchKernelGGL((bf::row_kernel_bf16<true, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, A);
             else
                 hipLaunchKernelGGL((bf::row_kernel_bf16<false, NW>), dim3(grid_rows), wg, ring + 9 * D * 4, st, ctxf, A);

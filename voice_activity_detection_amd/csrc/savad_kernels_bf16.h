@@ -526,9 +526,8 @@ struct RowArgsBf16 {
 // by other waves when this is entered (the first ring barrier inside publishes ring block 0 and the biases).
 // live (wave-uniform) = this wave's block exists: a wave without a block still issues its share of the DMA and takes
 // part in every barrier, but stores nothing.
-template <bool LAST, int NW>
+template <bool LAST, int NW, class R = Ring<NW>>
 __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem, bf16x8 (&xp)[8], int blk, bool live, int lane, int w) {
-    using R = Ring<NW>;
     float* lbo = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
     float* lb1 = lbo + D;
     float* lb2 = lb1 + DFF;
@@ -637,192 +636,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(cons
         if (blk >= A.nblk) xp[ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});  // pad blocks: attention never wrote them
     }
     row_stage_bf16<LAST, NW>(A, smem, xp, blk, true, lane, w);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Row stage, 64 rows per wave (experiment, row_mode 6): a wave owns a PAIR of 32-row blocks, so every weight fragment
-// read from LDS feeds two MFMAs (the 32-row kernel needs 1 KiB of LDS read per 32-cycle MFMA on each of the four SIMDs:
-// exactly the CU's 128 B/clk).  One 4-wave workgroup per CU, one wave per SIMD, 4-slot ring two blocks ahead.  Same
-// operations in the same order per block as row_stage_bf16 (same bits).
-// ---------------------------------------------------------------------------------------------
-using Ring64 = Ring<4, 4, 2>;
-
-template <bool SWAPPED, int NB0, int NBN, int KS0, int KSN>
-__device__ __forceinline__ void gemm_ring2(f32x16 (&acc)[2][4], const char* ringblk, const bf16x8 (&x0)[8], const bf16x8 (&x1)[8], int lane) {
-#pragma unroll
-    for (int nbl = NB0; nbl < NB0 + NBN; ++nbl)
-#pragma unroll
-        for (int ks = KS0; ks < KS0 + KSN; ++ks) {
-            const bf16x8 wf = ldfrag(ringblk + ((nbl * 8 + ks) * 64 + lane) * 16);
-            if (SWAPPED) {
-                acc[0][nbl] = SAVAD_MFMA_BF16(x0[ks], wf, acc[0][nbl]);
-                acc[1][nbl] = SAVAD_MFMA_BF16(x1[ks], wf, acc[1][nbl]);
-            } else {
-                acc[0][nbl] = SAVAD_MFMA_BF16(wf, x0[ks], acc[0][nbl]);
-                acc[1][nbl] = SAVAD_MFMA_BF16(wf, x1[ks], acc[1][nbl]);
-            }
-        }
-}
-
-template <bool LAST>
-__global__ __launch_bounds__(256, 1) void row_kernel64_bf16(const char* __restrict__ ctxf, RowArgsBf16 A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using R = Ring64;
-    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk0 = 2 * (blockIdx.x * 4 + w);
-    float* lbo = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
-    float* lb1 = lbo + D;
-    float* lb2 = lb1 + DFF;
-    float* lbn = lb2 + D;
-    const R ring{smem, w, lane};
-    constexpr int NBLK = LAST ? 9 : 12;
-    auto issue = [&](int t) {
-        ring.issue(t, [&](int sgm) -> const char* {
-            if (t == 0) return A.wo_frag + sgm * BLK_BYTES;
-            if (t < 9) {
-                const int c = (t - 1) >> 1;
-                return ((t - 1) & 1) ? A.w2_frag + (size_t)(sgm * 32 + 8 * c) * FRAG_BYTES : A.w1_frag + (size_t)c * RING_BYTES + sgm * BLK_BYTES;
-            }
-            return A.wn_frag + (size_t)(t - 9) * RING_BYTES + sgm * BLK_BYTES;
-        });
-    };
-    auto advance = [&](int t) {
-        ring.acquire(NBLK - 1 - t < R::DEPTH - 1 ? NBLK - 1 - t : R::DEPTH - 1);
-        if (t + R::DEPTH < NBLK) issue(t + R::DEPTH);
-    };
-#pragma unroll
-    for (int t = 0; t < R::DEPTH; ++t) issue(t);
-    stage_bias(lbo, A.bo, D);
-    stage_bias(lb1, A.b1, DFF);
-    stage_bias(lb2, A.b2, D);
-    if (!LAST) stage_bias(lbn, A.bn, 3 * D);
-    bf16x8 xp[2][8];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            xp[r][ks] = ldfrag(ctxf + ((size_t)(blk0 + r) * 8 + ks) * FRAG_BYTES + lane * 16);
-            if (blk0 + r >= A.nblk) xp[r][ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-        }
-    hres_t* hb = A.hbuf + (size_t)blk0 * HBLK_FLOATS;
-    f32x16 o[2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) o[r][nb] = zero16();
-        load_hblock(o[r], hb + (size_t)r * HBLK_FLOATS, lane);
-    }
-    advance(0);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) o[r][nb] += bias_block(lbo + 32 * nb, h);
-    gemm_ring2<false, 0, 4, 0, 8>(o, ring.slot(0), xp[0], xp[1], lane);
-    f32x4 xg[16];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        layernorm_regs(o[r], xg);
-        pack_row(xg, xp[r]);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) o[r][nb] += bias_block(lb2 + 32 * nb, h);
-    }
-#pragma unroll 1
-    for (int ch = 0; ch < 4; ++ch) {
-        advance(1 + 2 * ch);  // W1 chunk
-        const char* w1 = ring.slot(1 + 2 * ch);
-        const char* w2 = ring.slot(2 + 2 * ch);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x16 a[2][4];
-            bf16x8 ap[2][8];
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int nbl = 2 * half; nbl < 2 * half + 2; ++nbl) a[r][nbl] = bias_block(lb1 + 128 * ch + 32 * nbl, h);
-            if (half == 0)
-                gemm_ring2<false, 0, 2, 0, 8>(a, w1, xp[0], xp[1], lane);
-            else
-                gemm_ring2<false, 2, 2, 0, 8>(a, w1, xp[0], xp[1], lane);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int nbl = 2 * half; nbl < 2 * half + 2; ++nbl) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) a[r][nbl][e] = fmaxf(a[r][nbl][e], 0.0f);
-                    ap[r][2 * nbl] = pack_half(a[r][nbl], 0);
-                    ap[r][2 * nbl + 1] = pack_half(a[r][nbl], 1);
-                }
-            if (half == 0) {
-                advance(2 + 2 * ch);  // W2 chunk
-                gemm_ring2<false, 0, 4, 0, 4>(o, w2, ap[0], ap[1], lane);
-            } else {
-                gemm_ring2<false, 0, 4, 4, 4>(o, w2, ap[0], ap[1], lane);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (!LAST) store_hblock(hb + (size_t)r * HBLK_FLOATS, o[r], lane, A.satcnt);
-        layernorm_regs(o[r], xg);
-        if (!LAST) {
-            pack_row(xg, xp[r]);
-        } else {
-            float z0 = 0.0f, z1 = 0.0f;
-#pragma unroll
-            for (int G = 0; G < 16; ++G) {
-                const f32x4 c0 = ld4(A.wc + 8 * G + 4 * h), c1 = ld4(A.wc + D + 8 * G + 4 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    z0 = __builtin_fmaf(xg[G][e], c0[e], z0);
-                    z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
-                }
-            }
-            z0 = half_sum(z0) + A.bn[0];
-            z1 = half_sum(z1) + A.bn[1];
-            const float mx = fmaxf(z0, z1);
-            const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
-            size_t row;
-            int t_frame;
-            const bool valid = (blk0 + r < A.nblk) && slot_row(A.B, A.T, blk0 + r, m, row, t_frame);
-            if (h == 0 && valid) *reinterpret_cast<f32x2*>(A.out + row * 2) = f32x2{z0 - lse, z1 - lse};
-        }
-    }
-    if (!LAST) {
-        const int n = lane & 31;
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            advance(9 + rb);
-            const char* rbk = ring.slot(9 + rb);
-            f32x16 acc[2][4];
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int nbl = 0; nbl < 4; ++nbl) {
-                    if (rb < 2) {
-                        acc[r][nbl] = bias_block(lbn + D * rb + 32 * nbl, h);
-                    } else {
-                        const float bv = lbn[2 * D + 32 * nbl + n];
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[r][nbl][e] = bv;
-                    }
-                }
-            if (rb < 2)
-                gemm_ring2<false, 0, 4, 0, 8>(acc, rbk, xp[0], xp[1], lane);
-            else
-                gemm_ring2<true, 0, 4, 0, 8>(acc, rbk, xp[0], xp[1], lane);
-            char* dst = rb == 0 ? A.qf : (rb == 1 ? A.kf : A.vtf);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int nbl = 0; nbl < 4; ++nbl) {
-                    if (rb == 0) acc[r][nbl] *= A.qscale;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        stfrag(dst + ((size_t)(blk0 + r) * 8 + 2 * nbl + j) * FRAG_BYTES + lane * 16, pack_half(acc[r][nbl], j));
-                }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
