@@ -44,9 +44,12 @@ typedef struct savad_model* savad_handle;
 
 /* Mirrors SelfAttentiveVAD.__init__(feature_size, num_layers, d_model, dropout)
  * (vad/models/self_attention.py:7-21; d_ff = 4*d_model :10, n_heads = 1 :18).  dropout is an
- * inference no-op and is not part of the ABI.  Kernels implement d_model = 128 (the only value
- * the reference ships: tests/configs/vad/train_config.yaml:7-10) and any feature_size (rows are zero-padded to a
- * multiple of 16 internally when needed). */
+ * inference no-op and is not part of the ABI.  Any even d_model in [2, 4096] (the reference's positional encoding pairs
+ * sin / cos columns) and any feature_size (rows are zero-padded to a multiple of 16 internally when needed).
+ * d_model = 128 -- the only value the reference ships (tests/configs/vad/train_config.yaml:7-10) -- runs the tuned MFMA
+ * kernels in fp32 or bf16; every other width runs plain fp32 kernels (csrc/savad_generic.h: same results to the fp32
+ * tolerance, several times slower per FLOP, savad_set_precision(h, 1) is refused with SAVAD_E_UNSUPPORTED, and
+ * savad_set_attention_splits(h, n > 1) there means "n query tiles per sequence"). */
 typedef struct savad_config {
     int32_t feature_size;
     int32_t num_layers;

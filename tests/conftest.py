@@ -53,3 +53,9 @@ def write_reference_checkpoint(path, state, config=None):
     }
     torch.save(ckpt, path)
     return path
+
+
+@pytest.fixture(scope="session")
+def golden_dmodel():
+    """reference outputs for model widths other than 128 (tests/golden/make_golden_dmodel.py)"""
+    return np.load(Path(__file__).resolve().parent / "golden" / "golden_dmodel.npz")

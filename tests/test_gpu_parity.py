@@ -524,7 +524,10 @@ def test_c_abi_error_behaviour(torch_cuda):
     torch = torch_cuda
     lib = _lib.load()
     h = ctypes.c_void_p()
-    assert lib.savad_create(ctypes.byref(_lib.savad_config(80, 3, 64)), ctypes.byref(h)) == -2  # unsupported d_model
+    assert lib.savad_create(ctypes.byref(_lib.savad_config(80, 3, 65)), ctypes.byref(h)) == -1  # odd d_model: the reference's PE cannot build it either
+    _lib.check(lib.savad_create(ctypes.byref(_lib.savad_config(80, 3, 64)), ctypes.byref(h)))  # any even width: savad_generic.h
+    assert lib.savad_num_params(h) == 54 and lib.savad_set_precision(h, 1) == -2 and b"d_model=128" in lib.savad_last_error()
+    lib.savad_destroy(h)
     assert lib.savad_create(ctypes.byref(_lib.savad_config(0, 3, 128)), ctypes.byref(h)) == -1
     _lib.check(lib.savad_create(ctypes.byref(_lib.savad_config(80, 3, 128)), ctypes.byref(h)))
     assert lib.savad_num_params(h) == 54
@@ -1014,3 +1017,73 @@ def test_config4_one_hour_stream_full_size(torch_cuda, model, state1234, precisi
     a = 896 * hop
     ref, _ = oracle.predict_streaming(state1234, feat[a:], T, hop)
     assert ref.shape == (N - a,) and np.abs(ph[a + 400:] - ref[400:]).max() < tol
+
+
+def _dmodel_cases():
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    from dmodel_cases import CASES
+
+    return CASES
+
+
+@pytest.mark.parametrize("case", _dmodel_cases(), ids=lambda c: c[0])
+def test_golden_other_model_widths(torch_cuda, golden_dmodel, case):
+    """d_model != 128 (vad/models/self_attention.py:7-21 takes any width; savad_generic.h): the reference's own outputs"""
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    name, d_model, F, L, wseed, xseed, shape = case
+    m = make_model(torch_cuda, seeded_state_dict(wseed, feature_size=F, num_layers=L, d_model=d_model), F, L, d_model)
+    y = run(torch_cuda, m, feats(xseed, shape))
+    assert y.shape == golden_dmodel[name].shape and y.dtype == np.float32
+    err = np.abs(y - golden_dmodel[name]).max()
+    assert err < TIGHT, err
+
+
+def test_other_model_width_paths(torch_cuda):
+    """d_model = 64 through every caller of the forward: against the oracle on a ragged shape, query-tiled attention (the
+    form long sequences take) equal to the untiled one, the reference's window batches, the predictor (window gather +
+    chunked forwards + boost) against the oracle's, graph capture after reserve(), and a clear refusal of bf16 operands."""
+    from oracle import oracle
+    from voice_activity_detection_amd import VADFromScratchPredictor
+    from voice_activity_detection_amd._lib import SavadError
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    torch = torch_cuda
+    st = seeded_state_dict(6401, feature_size=80, num_layers=3, d_model=64)
+    m = make_model(torch, st, 80, 3, 64)
+    x = feats(641, (3, 301, 80))
+    y = run(torch, m, x)
+    assert np.abs(y - oracle.forward(st, x)).max() < TIGHT
+    for tiles in (2, 3, 7):
+        assert np.abs(run(torch, m, x, splits=tiles) - y).max() < 1e-6
+    xw = feats(642, (1100, 7, 80))
+    assert np.abs(run(torch, m, xw) - oracle.forward(st, xw)).max() < TIGHT
+    assert run(torch, m, np.zeros((0, 7, 80), np.float32)).shape == (0, 7, 2)
+    feat = feats(643, (777, 80))
+    pred = VADFromScratchPredictor(m, "cuda", chunk_size=250)
+    want, want_mean = oracle.predict_probabilities(st, feat, chunk=250)
+    assert np.abs(pred.predict_probabilities(feat) - want).max() < TIGHT
+    assert np.abs(pred.predict_boosted(feat) - want_mean).max() < TIGHT
+    # captured into a HIP graph once reserve() has sized the positional-encoding table
+    m2 = make_model(torch, st, 80, 3, 64)
+    m2.reserve(64)
+    xs = torch.from_numpy(feats(644, (4, 40, 80))).cuda()
+    out = torch.empty(4, 40, 2, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.no_grad(), torch.cuda.stream(s):
+        m2(features=xs, out=out)  # allocates the workspace outside the capture
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            m2(features=xs, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - oracle.forward(st, xs.cpu().numpy())).max() < TIGHT
+    m.precision = "bf16"
+    with pytest.raises(SavadError, match="d_model=128"):
+        run(torch, m, x)
+    m.precision = "fp32"

@@ -215,3 +215,27 @@ def test_logmel_stft_matches_scipy_on_the_reference_clip():
     win[56:456] = logmel.hann_periodic(400)
     mine = np.abs(np.fft.rfft(yp[16000:16000 + 512].astype(np.float64) * win)) ** 2
     assert np.abs(mine - p100).max() < 1e-6 * p100.max()
+
+
+def _dmodel_cases():
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    from dmodel_cases import CASES
+
+    return CASES
+
+
+@pytest.mark.parametrize("case", _dmodel_cases(), ids=lambda c: c[0])
+def test_other_model_widths(golden_dmodel, case):
+    """d_model != 128 (vad/models/model_factory.py:42-48 passes any width through): the oracle against the reference's outputs"""
+    name, d_model, F, L, wseed, xseed, shape = case
+    st = seeded_state_dict(wseed, feature_size=F, num_layers=L, d_model=d_model)
+    y = oracle.forward(st, seeded_features(xseed, shape))
+    assert y.shape == golden_dmodel[name].shape
+    assert np.abs(y - golden_dmodel[name]).max() < TOL
+
+
+def test_pe_table_other_width(golden_dmodel):
+    assert np.abs(oracle.pe(60, 64) - golden_dmodel["d64_pe"]).max() < 5e-6

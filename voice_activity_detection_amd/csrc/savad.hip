@@ -4,6 +4,7 @@
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
 #include "savad_attn_pw_bf16.h"
+#include "savad_generic.h"
 #include <type_traits>
 #include "savad_logmel.h"
 #include "savad_post.h"
@@ -54,6 +55,7 @@ constexpr int MAX_EVENTS = 64;
 
 struct savad_model {
     savad_config cfg;
+    bool generic = false;  // d_model != 128: the plain fp32 kernels of savad_generic.h on the raw parameters
     std::vector<Param> params;
     float* d_raw = nullptr;     // parameters exactly as handed over (state_dict layout)
     float* d_packed = nullptr;  // LayerNorm-folded weights
@@ -221,9 +223,15 @@ int ensure_pe(savad_model* m, int T, hipStream_t st) {
         m->d_pe = nullptr;
         m->pe_len = 0;
     }
-    HIP_TRY(hipMalloc(&m->d_pe, sizeof(float) * (size_t)cap * D));
-    build_pe(m->h_pe, cap);
-    HIP_TRY(hipMemcpyAsync(m->d_pe, m->h_pe.data(), sizeof(float) * (size_t)cap * D, hipMemcpyHostToDevice, st));
+    const size_t Dm = m->cfg.d_model;
+    HIP_TRY(hipMalloc(&m->d_pe, sizeof(float) * (size_t)cap * Dm));
+    if (m->generic) {
+        m->h_pe.resize((size_t)cap * Dm);
+        gen::build_pe_host(m->h_pe.data(), cap, (int)Dm);
+    } else {
+        build_pe(m->h_pe, cap);
+    }
+    HIP_TRY(hipMemcpyAsync(m->d_pe, m->h_pe.data(), sizeof(float) * (size_t)cap * Dm, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));  // h_pe is pageable and reused
     m->pe_len = cap;
     return SAVAD_OK;
@@ -389,6 +397,169 @@ struct Prof {
     }
 };
 
+
+// ---- d_model != 128: same parameter inventory with the runtime width, no folded / fragment copies
+int create_generic(const savad_config* cfg, savad_handle* out) {
+    if (cfg->feature_size <= 0 || cfg->feature_size > 4096) return fail(SAVAD_E_INVALID, "feature_size=%d", cfg->feature_size);
+    if (cfg->num_layers < 1 || cfg->num_layers > 64) return fail(SAVAD_E_INVALID, "num_layers=%d", cfg->num_layers);
+    savad_model* m = new savad_model();
+    m->cfg = *cfg;
+    m->generic = true;
+    const size_t Dm = cfg->d_model, Fm = cfg->feature_size, Hm = 4 * Dm;  // d_ff = 4 d_model: vad/models/self_attention.py:10
+    const int L = cfg->num_layers;
+    m->r_win = add_param(m, "input_layer.0.weight", Dm * Fm);
+    m->r_bin = add_param(m, "input_layer.0.bias", Dm);
+    m->lr.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "encoder.layers." + std::to_string(l) + ".";
+        auto& r = m->lr[l];
+        r.wq = add_param(m, p + "self_attention.query_projection.weight", Dm * Dm);
+        r.bq = add_param(m, p + "self_attention.query_projection.bias", Dm);
+        r.wk = add_param(m, p + "self_attention.key_projection.weight", Dm * Dm);
+        r.bk = add_param(m, p + "self_attention.key_projection.bias", Dm);
+        r.wv = add_param(m, p + "self_attention.value_projection.weight", Dm * Dm);
+        r.bv = add_param(m, p + "self_attention.value_projection.bias", Dm);
+        r.wo = add_param(m, p + "self_attention.final_projection.weight", Dm * Dm);
+        r.bo = add_param(m, p + "self_attention.final_projection.bias", Dm);
+        r.ln1w = add_param(m, p + "self_attention_sublayer.layer_norm.weight", Dm);
+        r.ln1b = add_param(m, p + "self_attention_sublayer.layer_norm.bias", Dm);
+        r.w1 = add_param(m, p + "feed_forward.feed_forward.0.weight", Hm * Dm);
+        r.b1 = add_param(m, p + "feed_forward.feed_forward.0.bias", Hm);
+        r.w2 = add_param(m, p + "feed_forward.feed_forward.3.weight", Dm * Hm);
+        r.b2 = add_param(m, p + "feed_forward.feed_forward.3.bias", Dm);
+        r.ln2w = add_param(m, p + "feed_forward_sublayer.layer_norm.weight", Dm);
+        r.ln2b = add_param(m, p + "feed_forward_sublayer.layer_norm.bias", Dm);
+    }
+    m->r_lnf_w = add_param(m, "encoder.layer_norm.weight", Dm);
+    m->r_lnf_b = add_param(m, "encoder.layer_norm.bias", Dm);
+    m->r_wc = add_param(m, "classifier.weight", 2 * Dm);
+    m->r_bc = add_param(m, "classifier.bias", 2);
+    m->FP = cfg->feature_size;
+    hipError_t e = hipMalloc(&m->d_raw, sizeof(float) * m->raw_floats);
+    if (e != hipSuccess) {
+        delete m;
+        return fail(SAVAD_E_HIP, "hipMalloc(weights): %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return SAVAD_OK;
+}
+
+void launch_gemm(hipStream_t st, const gen::GemmArgs& g, int batch) {
+    hipLaunchKernelGGL(gen::gemm_kernel, dim3((g.N + gen::GT - 1) / gen::GT, (g.M + gen::GT - 1) / gen::GT, batch), dim3(256), 0, st, g);
+}
+
+// nn.Linear on `rows` rows: y = act(x W^T + b [+ pe]) [+ res]
+void launch_linear(hipStream_t st, const float* x, long rows, int K, const float* W, const float* b, int N, float* y, const float* res,
+                   bool relu, const float* pe, int T) {
+    // rows per launch: a multiple of T (the positional-encoding row of output row m is m % T) that keeps grid.y inside its limit
+    const long step = T >= (1L << 21) ? T : (1L << 21) / T * T;
+    for (long r0 = 0; r0 < rows; r0 += step) {
+        gen::GemmArgs g{};
+        g.M = (int)(rows - r0 < step ? rows - r0 : step);
+        g.N = N;
+        g.K = K;
+        g.A = x + r0 * K;
+        g.lda = K;
+        g.Bm = W;
+        g.ldk = 1;
+        g.ldn = K;
+        g.C = y + r0 * N;
+        g.ldc = N;
+        g.alpha = 1.0f;
+        g.bias = b;
+        g.add = pe;
+        g.add_rows = pe ? T : 1;
+        g.res = res ? res + r0 * N : nullptr;
+        g.relu = relu ? 1 : 0;
+        launch_gemm(st, g, 1);
+    }
+}
+
+// SelfAttentiveVAD.forward for any d_model, the reference's operation sequence (vad/models/self_attention.py:23-28) kernel by kernel
+int forward_generic(savad_model* m, const float* x, int B, int T, float* out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const int Dm = m->cfg.d_model, F = m->cfg.feature_size, L = m->cfg.num_layers;
+    const gen::Plan p = gen::plan(B, T, Dm, m->splits);
+    if (workspace_bytes < p.total * sizeof(float))
+        return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, p.total * sizeof(float));
+    for (const Param& q : m->params)
+        if (!q.set) return fail(SAVAD_E_NOKEY, "missing key '%s' in state_dict", q.key.c_str());
+    int rc;
+    if ((rc = ensure_pe(m, T, st))) return rc;
+    float* W = (float*)workspace;
+    float *h = W + p.h, *n = W + p.n, *q = W + p.q, *k = W + p.k, *v = W + p.v, *ctx = W + p.ctx, *ff = W + p.ff, *sc = W + p.scores;
+    const float* R = m->d_raw;
+    const long rows = (long)B * T;
+    const int ln_grid = (int)((rows + 3) / 4);
+    Prof prof(m, st);
+    // input Linear + positional encoding / sqrt(d_model) (self_attention.py:13-15, transformer.py:401); dropout = identity
+    launch_linear(st, x, rows, F, R + m->r_win, R + m->r_bin, Dm, h, nullptr, false, m->d_pe, T);
+    prof.mark("input_generic");
+    const float alpha = (float)(1.0 / sqrt((double)Dm));  // / sqrt(d_head), one head (transformer.py:362)
+    for (int l = 0; l < L; ++l) {
+        const auto& r = m->lr[l];
+        hipLaunchKernelGGL(gen::layernorm_kernel, dim3(ln_grid), dim3(256), 0, st, h, R + r.ln1w, R + r.ln1b, n, rows, Dm);
+        launch_linear(st, n, rows, Dm, R + r.wq, R + r.bq, Dm, q, nullptr, false, nullptr, T);
+        launch_linear(st, n, rows, Dm, R + r.wk, R + r.bk, Dm, k, nullptr, false, nullptr, T);
+        launch_linear(st, n, rows, Dm, R + r.wv, R + r.bv, Dm, v, nullptr, false, nullptr, T);
+        prof.mark("qkv_generic");
+        for (int b0 = 0; b0 < B; b0 += p.cb) {
+            const int nb = B - b0 < p.cb ? B - b0 : p.cb;
+            for (int t0 = 0; t0 < T; t0 += p.tq) {
+                const int nq = T - t0 < p.tq ? T - t0 : p.tq;
+                gen::GemmArgs g{};
+                g.A = q + ((size_t)b0 * T + t0) * Dm;  // scores = q k^T / sqrt(d) (transformer.py:351-363)
+                g.lda = Dm;
+                g.sA = (long)T * Dm;
+                g.Bm = k + (size_t)b0 * T * Dm;
+                g.ldk = 1;
+                g.ldn = Dm;
+                g.sB = (long)T * Dm;
+                g.C = sc;
+                g.ldc = T;
+                g.sC = (long)nq * T;
+                g.M = nq;
+                g.N = T;
+                g.K = Dm;
+                g.alpha = alpha;
+                g.add_rows = 1;
+                launch_gemm(st, g, nb);
+                const long srows = (long)nb * nq;
+                hipLaunchKernelGGL(gen::softmax_kernel, dim3((unsigned)((srows + 3) / 4)), dim3(256), 0, st, sc, srows, T);
+                gen::GemmArgs c{};
+                c.A = sc;  // context = A V (transformer.py:338-346)
+                c.lda = T;
+                c.sA = (long)nq * T;
+                c.Bm = v + (size_t)b0 * T * Dm;
+                c.ldk = Dm;
+                c.ldn = 1;
+                c.sB = (long)T * Dm;
+                c.C = ctx + ((size_t)b0 * T + t0) * Dm;
+                c.ldc = Dm;
+                c.sC = (long)T * Dm;
+                c.M = nq;
+                c.N = Dm;
+                c.K = T;
+                c.alpha = 1.0f;
+                c.add_rows = 1;
+                launch_gemm(st, c, nb);
+            }
+        }
+        prof.mark("attention_generic");
+        // final_projection + residual onto the un-normalised x (transformer.py:347,237); FFN sublayer (:366-382)
+        launch_linear(st, ctx, rows, Dm, R + r.wo, R + r.bo, Dm, h, h, false, nullptr, T);
+        hipLaunchKernelGGL(gen::layernorm_kernel, dim3(ln_grid), dim3(256), 0, st, h, R + r.ln2w, R + r.ln2b, n, rows, Dm);
+        launch_linear(st, n, rows, Dm, R + r.w1, R + r.b1, 4 * Dm, ff, nullptr, true, nullptr, T);
+        launch_linear(st, ff, rows, 4 * Dm, R + r.w2, R + r.b2, Dm, h, h, false, nullptr, T);
+        prof.mark("row_generic");
+    }
+    hipLaunchKernelGGL(gen::layernorm_kernel, dim3(ln_grid), dim3(256), 0, st, h, R + m->r_lnf_w, R + m->r_lnf_b, n, rows, Dm);
+    hipLaunchKernelGGL(gen::classifier_kernel, dim3(ln_grid), dim3(256), 0, st, n, R + m->r_wc, R + m->r_bc, out, rows, Dm);
+    prof.mark("classifier_generic");
+    prof.done();
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
 }  // namespace
 
 SAVAD_EXPORT const char* savad_last_error(void) { return g_err; }
@@ -396,9 +567,9 @@ SAVAD_EXPORT const char* savad_version(void) { return "savad 0.1 (gfx950, fp32 M
 
 SAVAD_EXPORT int savad_create(const savad_config* cfg, savad_handle* out) {
     if (!cfg || !out) return fail(SAVAD_E_INVALID, "null argument");
-    if (cfg->d_model != D)
-        return fail(SAVAD_E_UNSUPPORTED, "d_model=%d: the gfx950 kernels implement d_model=128 (the reference's only config)",
-                    cfg->d_model);
+    if (cfg->d_model < 2 || cfg->d_model > 4096 || cfg->d_model % 2)  // the reference's positional encoding pairs sin / cos columns
+        return fail(SAVAD_E_INVALID, "d_model=%d (an even value in [2, 4096])", cfg->d_model);
+    if (cfg->d_model != D) return create_generic(cfg, out);
     if (cfg->feature_size <= 0 || cfg->feature_size > 4096)
         return fail(SAVAD_E_INVALID, "feature_size=%d", cfg->feature_size);
     if (cfg->num_layers < 1 || cfg->num_layers > 64) return fail(SAVAD_E_INVALID, "num_layers=%d", cfg->num_layers);
@@ -533,6 +704,8 @@ SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* byt
     if ((double)B * T * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "B*T=%ld rows exceed the 32-bit tile index range", (long)B * T);
     if (B == 0 || T == 0)
         *bytes = 0;
+    else if (m->generic)
+        *bytes = gen::plan(B, T, m->cfg.d_model, m->splits).total * sizeof(float);
     else if (m->precision == 1)
         *bytes = plan_blocks(m, B, T).total;
     else
@@ -554,6 +727,7 @@ SAVAD_EXPORT int savad_reserve(savad_handle m, int T_max, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = ensure_pe(m, T_max, st))) return rc;
+    if (m->generic) return SAVAD_OK;  // nothing to fold or pack: the generic kernels read the raw parameters
     bool all_set = true;
     for (const Param& p : m->params) all_set = all_set && p.set;
     if (!all_set) return SAVAD_OK;
@@ -569,6 +743,10 @@ SAVAD_EXPORT int savad_reserve(savad_handle m, int T_max, void* stream) {
 // counted.  Reads the count accumulated since the last call and clears it; synchronises `stream`.
 SAVAD_EXPORT int savad_residual_saturations(savad_handle m, unsigned long long* count, void* stream) {
     if (!m || !count) return fail(SAVAD_E_INVALID, "null argument");
+    if (!m->d_sat) {  // fp32-only handle (d_model != 128): no fp16-stored residual stream, nothing can saturate
+        *count = 0;
+        return SAVAD_OK;
+    }
     unsigned c = 0;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(&c, m->d_sat, sizeof(c), hipMemcpyDeviceToHost, st));
@@ -580,6 +758,8 @@ SAVAD_EXPORT int savad_residual_saturations(savad_handle m, unsigned long long* 
 
 SAVAD_EXPORT int savad_set_precision(savad_handle m, int precision) {
     if (!m || precision < 0 || precision > 1) return fail(SAVAD_E_INVALID, "precision %d (0 = fp32, 1 = bf16)", precision);
+    if (m->generic && precision == 1)
+        return fail(SAVAD_E_UNSUPPORTED, "bf16 operands are implemented for d_model=128 only (this handle: d_model=%d, fp32)", m->cfg.d_model);
     m->precision = precision;
     return SAVAD_OK;
 }
@@ -764,6 +944,7 @@ SAVAD_EXPORT int savad_forward_ex(savad_handle m, const void* x, int x_dtype, in
     if (!m) return fail(SAVAD_E_INVALID, "null handle");
     if (x_dtype == 0 && m->precision == 0) return savad_forward(m, (const float*)x, B, T, out, workspace, workspace_bytes, stream);
     if (x_dtype < 0 || x_dtype > 1) return fail(SAVAD_E_INVALID, "x_dtype %d", x_dtype);
+    if (m->generic) return fail(SAVAD_E_UNSUPPORTED, "bf16 features need the d_model=128 kernels (this handle: d_model=%d, fp32)", m->cfg.d_model);
     if (m->precision != 1) return fail(SAVAD_E_UNSUPPORTED, "bf16 features need savad_set_precision(h, 1)");
     if (B < 0 || T < 0) return fail(SAVAD_E_INVALID, "negative shape B=%d T=%d", B, T);
     if (B == 0 || T == 0) return SAVAD_OK;
@@ -784,6 +965,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)workspace) & 15)
         return fail(SAVAD_E_INVALID, "x, out and workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (m->generic) return forward_generic(m, x, B, T, out, workspace, workspace_bytes, st);
     if (m->precision == 1) return forward_bf16(m, x, 0, B, T, out, workspace, workspace_bytes, st);
     const Workspace ws = plan(m, B, T);
     if (workspace_bytes < ws.total * sizeof(float))
@@ -1012,7 +1194,7 @@ int plan_predict(savad_model* m, int N, int half, int jump, int chunk, PredictPl
     // windowed: the whole clip in ONE single-launch forward (up to 1024 packed tiles = 4096 windows of 7 frames, ~41 s of
     // audio: savad_forward's own limit for that kernel); longer inputs go through `chunk`-sized M-split forwards, which
     // are ~9 % faster per window than 4096-window launches (5.27 vs 5.36 ms for 10 min of audio)
-    p->windowed = m->precision == 0 && p->W <= 32 && m->cfg.num_layers <= PACKED_MAX_LAYERS && m->FP == F &&
+    p->windowed = !m->generic && m->precision == 0 && p->W <= 32 && m->cfg.num_layers <= PACKED_MAX_LAYERS && m->FP == F &&
                   (m->row_mode == 4 || (m->row_mode == 0 && p->n_items <= 1024 * (32 / p->W)));
     // chunk-sized forwards write their log-probs at logp + first*W*2 floats and savad_forward wants 16-byte aligned
     // pointers: an even chunk keeps every offset a multiple of 16 bytes whatever W is (windows are independent, so the
