@@ -1,10 +1,10 @@
 // savad_generic.h -- SelfAttentiveVAD.forward for ANY d_model (vad/models/self_attention.py:7-21 and
 // vad/models/model_factory.py:42-48 accept every value; the reference ships 128, which has the tuned MFMA kernels of
 // savad_kernels.h).  A handle created with d_model != 128 runs this path: plain fp32 kernels that follow the reference
-// operation by operation on row-major [rows][features] buffers -- one tiled GEMM with a fused epilogue (bias, positional
-// encoding, ReLU, residual), LayerNorm with its affine part, softmax over the keys of a materialised score tile, classifier +
+// operation by operation on row-major [rows][features] buffers -- one LDS-tiled GEMM on the fp32 matrix cores with a fused
+// epilogue (bias, positional encoding, ReLU, residual), LayerNorm with its affine part, softmax over the keys of a materialised score tile, classifier +
 // log-softmax.  Correctness and the full boundary first: it is several times slower per FLOP than the d_model = 128 path
-// (no MFMA, the [T,T] scores make a round trip through HBM) and fp32 only.
+// (runtime shapes with bounds checks, no operand reuse beyond one 64 x 64 tile, the [T,T] scores make a round trip through HBM) and fp32 only.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -35,21 +35,24 @@ constexpr int GK = 16;   // K step
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __shared__ float As[GK][GT + 1];
     __shared__ float Bs[GK][GT + 1];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    // 64 x 64 output tile per workgroup, one 32 x 32 quadrant per wave on the fp32 matrix cores (v_mfma_f32_32x32x2f32):
+    // A operand = weight values (lane & 31 = output feature, lane >> 5 = k), B operand = data values (lane & 31 = data row),
+    // so a lane ends up with 16 output features of ONE data row: register r = feature 8 (r / 4) + 4 (lane >> 5) + (r & 3).
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
     const long b = blockIdx.z;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
     const float* A = g.A + b * g.sA;
     const float* Bm = g.Bm + b * g.sB;
-    float acc[4][4];
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     // tile loads: 64 x 16 elements each, 4 per thread.  A: row = tid / 4, k = 4 (tid % 4) + e (contiguous in k).
     // B: whichever of k / n is contiguous in memory runs fastest across the threads.
     const int ar = tid >> 2, ak = (tid & 3) * 4;
     const bool b_k_contig = g.ldk == 1;
     const int bn = b_k_contig ? (tid >> 2) : (tid & 63), bk = b_k_contig ? (tid & 3) * 4 : (tid >> 6) * 4;
+    const int kh = lane >> 5, l31 = lane & 31;
     for (int k0 = 0; k0 < g.K; k0 += GK) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -60,36 +63,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < GK; ++k) {
-            float a[4], w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = Bs[k][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(a[i], w[j], acc[i][j]);
-        }
+        for (int k = 0; k < GK; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Bs[k + kh][wn * 32 + l31], As[k + kh][wm * 32 + l31], acc, 0, 0, 0);
         __syncthreads();
     }
-    float* C = g.C + b * g.sC;
-    const float* R = g.res ? g.res + b * g.sC : nullptr;
+    const int m = m0 + wm * 32 + l31;
+    if (m >= g.M) return;
+    float* C = g.C + b * g.sC + (long)m * g.ldc;
+    const float* R = g.res ? g.res + b * g.sC + (long)m * g.ldc : nullptr;
+    const float* addr = g.add ? g.add + (long)(m % g.add_rows) * g.N : nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n >= g.N) continue;
-            float v = acc[i][j] * g.alpha;
-            if (g.bias) v += g.bias[n];
-            if (g.add) v += g.add[(long)(m % g.add_rows) * g.N + n];
-            if (g.relu) v = v > 0.0f ? v : 0.0f;
-            if (R) v += R[(long)m * g.ldc + n];
-            C[(long)m * g.ldc + n] = v;
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+        if (n >= g.N) continue;
+        float v = acc[r] * g.alpha;
+        if (g.bias) v += g.bias[n];
+        if (addr) v += addr[n];
+        if (g.relu) v = v > 0.0f ? v : 0.0f;
+        if (R) v += R[n];
+        C[n] = v;
     }
 }
 
