@@ -6,7 +6,7 @@ m = SelfAttentiveVAD(80, 3, 128, 0.5)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()})
 m = m.cuda().eval(); m.precision = "bf16"
 x = torch.from_numpy(seeded_features(1, (256, 800, 80))).cuda().to(torch.bfloat16)
-for mode in (0, 2, 1, 5):
+for mode in [int(a) for a in sys.argv[1:]] or (0, 2, 1, 5):
     m.row_mode = mode
     with torch.no_grad():
         for _ in range(20): m(x)
