@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep (GPU box): random (B, T, mode, splits, precision) against the C oracle."""
+"""Randomised parity sweep (GPU box): random (B, T, mode, splits, precision) -- and, every fourth case, a random model
+(d_model, feature_size, num_layers) on the plain fp32 path -- against the C oracle."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -18,13 +19,27 @@ for it in range(n):
     maxB = max(1, min(48, 40000 // T)) if T > 32 else int(rng.choice([3, 40, 300, 1200, 5000]))
     B = int(rng.integers(1, maxB + 1))
     prec = "bf16" if rng.random() < 0.35 else "fp32"
-    mode = int(rng.integers(0, 5))  # 0 .. 4 (include/savad.h)
+    mode = int(rng.integers(0, 6))  # 0 .. 5 (include/savad.h)
     splits = int(rng.choice([0, 0, 1, 1, 2, 3, 5]))
-    x = seeded_features(int(rng.integers(1 << 30)), (B, T, 80))
-    m.precision, m.row_mode, m.attention_splits = prec, mode, splits
-    with torch.no_grad():
-        y = m(features=torch.from_numpy(x).cuda()).cpu().numpy()
-    ref = oracle.forward(st, x, threads=32)
+    if it % 4 == 3:   # another model width: csrc/savad_generic.h (fp32 only; splits = query tiles)
+        D, F, L = int(rng.choice([2, 8, 30, 64, 96, 130, 256, 384])), int(rng.choice([13, 40, 80, 257])), int(rng.integers(1, 4))
+        B, prec = min(B, 64), "fp32"
+        st2 = seeded_state_dict(int(rng.integers(1 << 20)), feature_size=F, num_layers=L, d_model=D)
+        m2 = SelfAttentiveVAD(F, L, D, 0.5)
+        m2.load_state_dict({k: torch.from_numpy(v) for k, v in st2.items()})
+        m2 = m2.cuda().eval()
+        m2.attention_splits = splits
+        x = seeded_features(int(rng.integers(1 << 30)), (B, T, F))
+        with torch.no_grad():
+            y = m2(features=torch.from_numpy(x).cuda()).cpu().numpy()
+        ref = oracle.forward(st2, x, threads=32)
+        mode = f"generic d_model={D} F={F} L={L}"
+    else:
+        x = seeded_features(int(rng.integers(1 << 30)), (B, T, 80))
+        m.precision, m.row_mode, m.attention_splits = prec, mode, splits
+        with torch.no_grad():
+            y = m(features=torch.from_numpy(x).cuda()).cpu().numpy()
+        ref = oracle.forward(st, x, threads=32)
     err = float(np.abs(y - ref).max())
     tol = 2e-2 if prec == "bf16" else 3e-5
     worst[prec] = max(worst[prec], err)

@@ -64,15 +64,6 @@ __device__ __forceinline__ float half_max(float v) {
     return fmaxf(lo, hi);
 }
 
-// relu as ONE v_max_f32: fmaxf(x, 0) costs two (hipcc first canonicalises x with v_max_f32 x, x, x -- a no-op on
-// everything an MFMA can produce); per 32-row block that was 256 of the bf16 row chain's 2 300 VALU instructions
-// (same-run A/B at [256,800,80] bf16: row stage unchanged within noise, classifier-ending row launch 82.9 -> 79.9 us)
-__device__ __forceinline__ float relu1(float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
-}
-
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -754,7 +745,7 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
         wwait<16>(wa);
         wmma_k128(a, wa, xg);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = relu1(a[r]);
+        for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
         // the next W1 slice, or the next layer's query block; the LAST launch re-reads a block it will not use (keeps
         // the wait count uniform)
         wload_frag(wa, (ch + 1 < 4 || LAST) ? frag : nfrag, ch + 1 < 4 ? 16 + 4 * w + ch + 1 : w, voff);
@@ -1027,7 +1018,7 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
             wmma_k128(a, wa, xg);
             SAVAD_STAMP(42);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = relu1(a[r]);
+            for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
             // the next W1 slice, or the next layer's query block; behind the last layer the stream simply re-reads a
             // block it will not use (keeps the wait count uniform)
             wload_frag(wa, ch + 1 < 4 ? frag : nfrag, ch + 1 < 4 ? 16 + 4 * w + ch + 1 : w, voff);
@@ -1267,7 +1258,7 @@ __device__ __forceinline__ void row_chain_m(f32x4 (&xg)[16], f32x16 (&h1)[4], si
         if (act) {
             gemm_lds_a(a, ring, n, h, xg);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = relu1(a[r]);
+            for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
         }
         ring_acquire();
         if (ch + 1 < 16)

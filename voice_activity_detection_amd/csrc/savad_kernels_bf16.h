@@ -585,7 +585,7 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
 #pragma unroll
         for (int nbl = 0; nbl < 4; ++nbl) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[nbl][r] = relu1(a[nbl][r]);
+            for (int r = 0; r < 16; ++r) a[nbl][r] = fmaxf(a[nbl][r], 0.0f);
             ap[2 * nbl] = pack_half(a[nbl], 0);
             ap[2 * nbl + 1] = pack_half(a[nbl], 1);
         }
