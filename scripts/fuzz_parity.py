@@ -33,6 +33,9 @@ for it in range(n):
         with torch.no_grad():
             y = m2(features=torch.from_numpy(x).cuda()).cpu().numpy()
         ref = oracle.forward(st2, x, threads=32)
+        # tiny widths amplify fp32 summation-order noise (LayerNorm over 2 features is a cancellation): the yardstick is the
+        # oracle's own fp32-against-fp64 distance on the same input
+        noise = float(np.abs(ref - oracle.forward(st2, x, threads=32, acc64=True)).max())
         mode = f"generic d_model={D} F={F} L={L}"
     else:
         x = seeded_features(int(rng.integers(1 << 30)), (B, T, 80))
@@ -42,6 +45,8 @@ for it in range(n):
         ref = oracle.forward(st, x, threads=32)
     err = float(np.abs(y - ref).max())
     tol = 2e-2 if prec == "bf16" else 3e-5
+    if it % 4 == 3:
+        tol = max(tol, 4 * noise)
     worst[prec] = max(worst[prec], err)
     flag = "" if (np.isfinite(y).all() and err < tol) else "   <<<<<< FAIL"
     print(f"B={B:3d} T={T:4d} {prec} row_mode={mode} splits={splits}: max|dlogp|={err:.2e}{flag}", flush=True)

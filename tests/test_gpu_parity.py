@@ -1087,3 +1087,15 @@ def test_other_model_width_paths(torch_cuda):
     with pytest.raises(SavadError, match="d_model=128"):
         run(torch, m, x)
     m.precision = "fp32"
+
+
+def test_randomised_sweep(torch_cuda):
+    """scripts/fuzz_parity.py: random shapes x launch schedules x precisions x (every fourth case) model widths against the oracle;
+    a fixed seed here, any seed on the command line.  It is what caught a kernel edit that every fixed-shape test had not been run on."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(repo / "scripts" / "fuzz_parity.py"), "20260927", "40"], cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FAIL" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
