@@ -7,8 +7,9 @@
 
 One "step" = one pass of the hot path over one batch of synthetic mel frames: forward of
 SelfAttentiveVAD on a device-resident [B, T, F] tensor -> device-resident [B, T, 2] log-probs
-(N > 1: every rank runs its own B-sequence shard, then the RCCL all_gather of the log-probs that
-`voice_activity_detection_amd.distributed.forward_sharded` issues per call).
+(N > 1: every rank runs its own B-sequence shard; the log-probs of the K batches of a timed block are gathered over RCCL
+by ONE all_gather that closes the block -- north_star's "single RCCL gather at the end" -- or, with --gather step, by the
+per-call all_gather of `voice_activity_detection_amd.distributed.forward_sharded`; both are measured on every N > 1 run).
 Default workload = BASELINE.json configs[1]: [32, 800, 80] fp32 per GPU, seeded weights.
 
 Timing: W warm-up steps (at least 0.2 s of them, so the clocks have ramped), then BLOCKS
@@ -546,9 +547,10 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP-event pass (no roofline per kernel)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / T=7 / configs[0] / configs[3] / configs[4] legs")
     ap.add_argument("--legs", default="all", help="comma-separated secondary legs to run (default: all)")
-    ap.add_argument("--gather", default="step", choices=["step", "final"],
-                    help="multi-GPU: which gather mode `value` is quoted on (both are always measured): one all_gather per "
-                         "forward (forward_sharded, default) or one all_gather of all K batches at the end of a block")
+    ap.add_argument("--gather", default="final", choices=["step", "final"],
+                    help="multi-GPU: which gather mode `value` is quoted on (both are always measured and printed): 'final' (default) = "
+                         "every forward writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block -- north_star's "
+                         "'a single RCCL gather over xGMI at the end'; 'step' = one all_gather per forward (forward_sharded)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
