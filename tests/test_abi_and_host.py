@@ -227,3 +227,33 @@ def test_lds_dma_owns_m0(code_object):
                 seen += 1
                 assert "s_add_u32 m0" in line or "s_mov_b32 m0" in line, (name, line.strip())
     assert seen >= 100
+
+
+def build_c_client(out_dir):
+    """tests/abi_client.c: a plain C99 program written against include/savad.h only, linked against libsavad.so"""
+    import shutil
+    import subprocess
+
+    from voice_activity_detection_amd import build
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc here")
+    lib = build.build()
+    exe = Path(out_dir) / "abi_client"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", f"-I{REPO / 'include'}", str(REPO / "tests" / "abi_client.c"), "-o", str(exe),
+                    f"-L{lib.parent}", "-lsavad", "-ldl", "-lm", f"-Wl,-rpath,{lib.parent}"], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """the drop-in boundary is a C ABI: include/savad.h compiles as pedantic C99 and as C++11, and a C program that uses
+    nothing else links against the library (it runs on the GPU box: tests/test_gpu_parity.py::test_c_client_of_the_abi)"""
+    import shutil
+    import subprocess
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc here")
+    hdr = str(REPO / "include" / "savad.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    assert build_c_client(tmp_path).exists()

@@ -1099,3 +1099,17 @@ def test_randomised_sweep(torch_cuda):
     repo = Path(__file__).resolve().parents[1]
     r = subprocess.run([sys.executable, str(repo / "scripts" / "fuzz_parity.py"), "20260927", "40"], cwd=repo, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAIL" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_c_client_of_the_abi(torch_cuda, tmp_path):
+    """tests/abi_client.c (plain C99 against include/savad.h, device memory through libamdhip64 looked up at run time):
+    create, 54 set_param calls, workspace query, forward, error codes -- without Python or torch in the process."""
+    import subprocess
+    from pathlib import Path
+
+    from tests.test_abi_and_host import build_c_client
+
+    hip = next((p for p in (Path("/opt/rocm/lib/libamdhip64.so"), *Path(torch_cuda.__file__).parent.glob("lib/libamdhip64.so")) if p.exists()), None)
+    assert hip is not None, "libamdhip64.so not found"
+    r = subprocess.run([str(build_c_client(tmp_path)), str(hip)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), (r.returncode, r.stdout, r.stderr)
