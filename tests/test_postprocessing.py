@@ -237,6 +237,15 @@ def test_from_checkpoint_reads_reference_checkpoints_and_refuses_other_transform
     p = VADFromScratchPredictor.from_checkpoint(write_reference_checkpoint(tmp_path / "ok.checkpoint", state1234), "cpu")
     assert (p.hop_ms, p.window_ms, p.context_window_frames) == (10, 25, 7)
     assert sorted(p.model.state_dict()) == sorted(state1234)
+    # another model width / depth in the checkpoint's config (vad/models/model_factory.py:42-48 passes them through)
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    cfg64 = copy.deepcopy(REFERENCE_CONFIG)
+    cfg64["model"]["self_attention"].update(num_layers=2, d_model=64)
+    st64 = seeded_state_dict(64, num_layers=2, d_model=64)
+    p64 = VADFromScratchPredictor.from_checkpoint(write_reference_checkpoint(tmp_path / "d64.checkpoint", st64, cfg64), "cpu")
+    assert (p64.model.d_model, p64.model.num_layers) == (64, 2) and sorted(p64.model.state_dict()) == sorted(st64)
+    assert all(np.array_equal(p64.model.state_dict()[k].numpy(), v) for k, v in st64.items())
     for path, value in ((("transform", "hop_ms"), 20), (("transform", "n_fft"), 1024), (("transform", "name"), "mfcc"),
                         (("transform", "n_mels"), 40), (("temporal_differences",), True),
                         (("silence_remover",), {"silence_threshold": 0.1})):
