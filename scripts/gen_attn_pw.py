@@ -8,6 +8,7 @@ instruction stream below (no compiler-allocated register inside it).
     python scripts/gen_attn_pw.py            # rewrites the .inc files
     python scripts/gen_attn_pw.py --check    # exit 1 when a committed .inc is stale (tests/test_abi_and_host.py)
     python scripts/gen_attn_pw.py --out F [--ablate MASK] [--timing | --count] [--split-max N] [--pad N]   # experiments
+                                             # (scripts/ubench/build_timing.sh: the phase-stamp build, -DSAVAD_PW_INC)
 
 Data layout: savad_kernels_bf16.h (fragment-major q / k / v^T / ctx, 1 KiB per K-step fragment of 32 rows).
 Arithmetic: identical, operation for operation, to attention_kernel_bf16 (online softmax in the base-2 domain relative
@@ -45,7 +46,6 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / "voice_activity_detection_amd" / "csrc" / "savad_attn_pw_bf16.inc"
-OUT_TIMING = ROOT / "voice_activity_detection_amd" / "csrc" / "savad_attn_pw_bf16_timing.inc"
 OUT_CLOB = ROOT / "voice_activity_detection_amd" / "csrc" / "savad_attn_pw_bf16_clobbers.inc"
 
 # ---------------------------------------------------------------------------------------------- register map
@@ -1091,20 +1091,16 @@ def main():
             SPLIT_MAX = int(sys.argv[sys.argv.index("--split-max") + 1])
         Path(sys.argv[sys.argv.index("--out") + 1]).write_text(render(emit_all()))
         return
-    TIMING = True
-    timing_text = render(emit_all())
-    TIMING = False
     a = emit_all()
     text, clob = render(a), render_clobbers()
     if "--check" in sys.argv:
-        stale = [f for f, t in ((OUT, text), (OUT_CLOB, clob), (OUT_TIMING, timing_text)) if not f.exists() or f.read_text() != t]
+        stale = [f for f, t in ((OUT, text), (OUT_CLOB, clob)) if not f.exists() or f.read_text() != t]
         if stale:
             print(f"stale: {[str(f) for f in stale]}: run python scripts/gen_attn_pw.py", file=sys.stderr)
             sys.exit(1)
         return
     OUT.write_text(text)
     OUT_CLOB.write_text(clob)
-    OUT_TIMING.write_text(timing_text)
     print(f"{OUT}: {len(a.lines)} lines", file=sys.stderr)
 
 
