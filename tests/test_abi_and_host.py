@@ -257,3 +257,26 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
     subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
     assert build_c_client(tmp_path).exists()
+
+
+def test_pipelined_wrapper_host_logic(state1234):
+    """PipelinedVAD without a GPU: replicas share the parameters and never the runtime state; no CPU fallback either"""
+    import torch
+
+    from voice_activity_detection_amd import PipelinedVAD, SelfAttentiveVAD
+    from voice_activity_detection_amd._lib import SavadError
+
+    m = SelfAttentiveVAD(80, 3, 128, 0.5).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state1234.items()})
+    pipe = PipelinedVAD(m)
+    assert pipe.depth == 3 and len(pipe._replicas) == 3 and all(r is not m for r in pipe._replicas)
+    assert all(r.classifier.weight is m.classifier.weight and r._handle is None and r._workspace is None for r in pipe._replicas)
+    m.precision = "bf16"
+    assert PipelinedVAD(m).depth == 2 and PipelinedVAD(m, depth=1)._replicas == [m]
+    with pytest.raises(ValueError):
+        PipelinedVAD(m, depth=0)
+    with pytest.raises(ValueError):
+        pipe.set_active(4)
+    with pytest.raises(SavadError, match="no CPU fallback"):
+        pipe.submit(torch.zeros(1, 7, 80))
+    pipe.join()  # nothing in flight: a no-op

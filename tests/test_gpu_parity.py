@@ -1113,3 +1113,44 @@ def test_c_client_of_the_abi(torch_cuda, tmp_path):
     assert hip is not None, "libamdhip64.so not found"
     r = subprocess.run([str(build_c_client(tmp_path)), str(hip)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("ok "), (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("precision,depth", [("fp32", 3), ("fp32", 2), ("bf16", 2), ("fp32", 1)])
+def test_pipelined_forwards_are_the_modules_bits(torch_cuda, state1234, precision, depth):
+    """PipelinedVAD: `depth` independent forwards in flight (own stream / handle / workspace each, shared parameters) return what the
+    module returns, bit for bit -- different inputs and shapes interleaved, inputs produced on the caller's stream right before
+    submit, outputs consumed on it right after join, `out=` targets, knobs changed on the base module after construction."""
+    from voice_activity_detection_amd import PipelinedVAD
+
+    torch = torch_cuda
+    m = make_model(torch, state1234)
+    m.precision = precision
+    pipe = PipelinedVAD(m, depth=depth)
+    shapes = [(5, 96, 80), (32, 800, 80), (40, 7, 80), (3, 257, 80), (32, 800, 80), (1, 33, 80), (64, 50, 80), (5, 96, 80), (2, 801, 80)]
+    xs = []
+    for i, shape in enumerate(shapes):
+        base = torch.from_numpy(feats(7000 + i, shape)).cuda()
+        xs.append(base * 1.0 + 0.0)          # produced by a kernel on the current stream immediately before the submit
+    outs = pipe.forward_many(xs)
+    total = sum(o.double().sum() for o in outs)  # consumed on the current stream right after join(): no device-wide sync in between
+    with torch.no_grad():
+        want = [m(features=x) for x in xs]
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs, want))
+    assert torch.equal(total, sum(o.double().sum() for o in want))
+    # preallocated targets, many rounds through the same replicas (workspace / stream reuse)
+    keep = torch.zeros((12, 32, 800, 2), device="cuda")
+    x = xs[1]
+    for i in range(12):
+        pipe.submit(x, out=keep[i])
+    pipe.join()
+    torch.cuda.synchronize()
+    assert all(torch.equal(keep[i], want[1]) for i in range(12))
+    # a knob set on the base module reaches the replicas
+    m.row_mode = 1
+    got = pipe.forward_many([xs[0], xs[3]])
+    with torch.no_grad():
+        ref = [m(features=xs[0]), m(features=xs[3])]
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    m.row_mode = 0

@@ -3,7 +3,7 @@ voithru/voice-activity-detection: ``SelfAttentiveVAD.forward`` as driven by
 ``VADFromScratchPredictor.predict_probabilities``).  See DESIGN.md / INTEGRATION.md."""
 from .seeded import seeded_features, seeded_state_dict, state_dict_spec  # noqa: F401
 
-__all__ = ["SelfAttentiveVAD", "VADFromScratchPredictor", "ContextResolution", "StreamingPredictor", "seeded_state_dict",
+__all__ = ["SelfAttentiveVAD", "PipelinedVAD", "VADFromScratchPredictor", "ContextResolution", "StreamingPredictor", "seeded_state_dict",
            "seeded_features", "state_dict_spec"]
 
 
@@ -11,6 +11,9 @@ def __getattr__(name):  # torch / libsavad are imported lazily (seeded.py is num
     if name == "SelfAttentiveVAD":
         from .model import SelfAttentiveVAD
         return SelfAttentiveVAD
+    if name == "PipelinedVAD":
+        from .pipeline import PipelinedVAD
+        return PipelinedVAD
     if name in ("VADFromScratchPredictor", "ContextResolution", "window_offsets", "StreamingPredictor", "VADPredictParameters"):
         from . import predictor
         return getattr(predictor, name)

@@ -1,0 +1,106 @@
+"""Several independent forwards in flight on one GPU.
+
+One forward at a time leaves matrix-core time unused that no kernel change recovers: at BASELINE configs[1]
+(``[32, 800, 80]`` fp32) the fused launches put 800 wave-sized work items on 1 024 SIMDs, the input stage 200 workgroups on
+256 CUs, and every bf16 launch ends in a partial round.  Batches are independent (``vad/predictor.py:180-224`` walks them in a
+Python loop; north_star shards them), so the idle slots can run the NEXT batch: :class:`PipelinedVAD` keeps ``depth`` forwards
+in flight, each on its own HIP stream with its own library handle and workspace (the parameters are shared with the module
+it was built from; a handle's folded device copy of them is 2.4 MB).  Results are what the module itself returns, bit for bit;
+only the throughput changes (measured, one MI355X, forwards per second: ``[32,800,80]`` fp32 +25 % at depth 3, ``[256,800,80]``
+bf16 +5 % at depth 2; ``scripts/ubench/pipelined_streams.py``).  Latency of a single batch grows accordingly -- this is for
+loops over many batches (window chunks of a long recording, streaming windows, a serving queue).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Iterable, List, Optional
+
+import torch
+from torch import Tensor
+
+from .model import SelfAttentiveVAD
+
+_KNOBS = ("precision", "row_mode", "attention_splits", "training")
+
+
+class PipelinedVAD:
+    """``depth`` replicas of ``model`` (shared parameters, private native handle / workspace / HIP stream each).
+
+    ``submit(x)`` enqueues one forward on the next replica's stream and returns its output tensor immediately; the tensor's
+    contents are valid once ``join()`` (or a synchronisation of the device) has run.  Inputs are ordered after whatever the
+    CURRENT stream did before ``submit``; ``join()`` orders the current stream after every submitted forward."""
+
+    def __init__(self, model: SelfAttentiveVAD, depth: Optional[int] = None):
+        if depth is None:
+            depth = 2 if model.precision == "bf16" else 3
+        if depth < 1:
+            raise ValueError(f"depth must be >= 1, got {depth}")
+        self.model = model
+        self.depth = int(depth)
+        # the base module is never used by the pipeline itself (depth > 1): calling it directly stays safe while forwards are in flight
+        self._replicas: List[SelfAttentiveVAD] = [model] if self.depth == 1 else [copy.copy(model) for _ in range(self.depth)]
+        self._streams: Optional[List[torch.cuda.Stream]] = None
+        self._next = 0
+        self._busy: List[bool] = [False] * self.depth
+        self.active = self.depth   # forwards kept in flight (<= depth): set_active() lets a caller tune it for its shape
+
+    def set_active(self, n: int) -> None:
+        """use only the first n replicas from now on (1 <= n <= depth); call it with nothing in flight"""
+        if not 1 <= n <= self.depth:
+            raise ValueError(f"active must be in [1, {self.depth}], got {n}")
+        self.join()
+        self.active, self._next = int(n), 0
+
+    def _ensure_streams(self, device: torch.device) -> List[torch.cuda.Stream]:
+        if self._streams is None or self._streams[0].device != device:
+            self._streams = [torch.cuda.Stream(device) for _ in range(self.depth)]
+        return self._streams
+
+    @torch.no_grad()
+    def submit(self, features: Tensor, out: Optional[Tensor] = None) -> Tensor:
+        """enqueue ``model(features=features, out=out)`` on the next replica; returns the (not yet valid) output tensor"""
+        device = features.device
+        if device.type != "cuda":
+            return self.model(features=features, out=out)  # raises the module's own "no CPU fallback" error
+        if self.active == 1:   # nothing to overlap: the plain module on the caller's stream (after whatever is still in flight)
+            self.join()
+            return self.model(features=features, out=out)
+        streams = self._ensure_streams(device)
+        k = self._next
+        self._next = (k + 1) % self.active
+        rep, s = self._replicas[k], streams[k]
+        for name in _KNOBS:  # knobs set on the base module after construction apply to every replica
+            if getattr(rep, name) != getattr(self.model, name):
+                setattr(rep, name, getattr(self.model, name))
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            y = rep(features=features, out=out)
+        # the caching allocator must not hand these blocks to another stream while this forward still uses them
+        features.record_stream(s)
+        y.record_stream(s)
+        self._busy[k] = True
+        return y
+
+    def join(self) -> None:
+        """the current stream waits for every forward submitted so far"""
+        if self._streams is None:
+            return
+        cur = torch.cuda.current_stream(self._streams[0].device)
+        for k, s in enumerate(self._streams):
+            if self._busy[k]:
+                cur.wait_stream(s)
+                self._busy[k] = False
+
+    @torch.no_grad()
+    def forward_many(self, batches: Iterable[Tensor]) -> List[Tensor]:
+        """all batches through the pipeline; the returned outputs are ordered like the inputs and valid on the current stream"""
+        outs = [self.submit(x) for x in batches]
+        self.join()
+        return outs
+
+    def reserve(self, max_frames: int, device=None, max_batch: int = 0) -> None:
+        """``SelfAttentiveVAD.reserve`` on every replica (handles, folded weights, positional-encoding tables, workspaces)"""
+        for rep in self._replicas:
+            for name in _KNOBS:
+                setattr(rep, name, getattr(self.model, name))
+            rep.reserve(max_frames, device=device, max_batch=max_batch)

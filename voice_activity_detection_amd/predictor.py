@@ -261,8 +261,12 @@ class StreamingPredictor:
     With torch.distributed initialised, windows are sharded contiguously over the ranks and the
     log-probs are exchanged with ONE all_gather (voice_activity_detection_amd.distributed)."""
 
-    def __init__(self, model: SelfAttentiveVAD, device, T: int = 800, hop: int = 400, max_batch: int = 256):
+    def __init__(self, model: SelfAttentiveVAD, device, T: int = 800, hop: int = 400, max_batch: int = 256, in_flight: int = 2):
         self.model, self.device, self.T, self.hop, self.max_batch = model, torch.device(device), int(T), int(hop), int(max_batch)
+        # the window batches are independent: `in_flight` of them run concurrently (PipelinedVAD: own stream / handle / workspace
+        # each, same bits); 1 = one after the other on the caller's stream
+        self.in_flight = int(in_flight)
+        self._pipe = None
 
     @torch.no_grad()
     def predict_device(self, feature):
@@ -279,6 +283,10 @@ class StreamingPredictor:
         with torch.cuda.device(self.device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+            if self._pipe is None or self._pipe.model is not self.model or self._pipe.depth != max(self.in_flight, 1):
+                from .pipeline import PipelinedVAD
+                self._pipe = PipelinedVAD(self.model, depth=max(self.in_flight, 1))
+
             def windows_logp(lo, hi):  # this rank's contiguous span of windows -> [hi - lo, T, 2] log-probs
                 local = torch.empty((hi - lo, T, 2), dtype=torch.float32, device=self.device)
                 for first in range(lo, hi, self.max_batch):
@@ -286,7 +294,8 @@ class StreamingPredictor:
                     win = torch.empty((count, T, F), dtype=torch.float32, device=self.device)
                     _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), N, F, T, hop, first, count,
                                                         ctypes.c_void_p(win.data_ptr()), stream))
-                    self.model(features=win, out=local[first - lo:first - lo + count])
+                    self._pipe.submit(win, out=local[first - lo:first - lo + count])
+                self._pipe.join()
                 return local
 
             logp = sharded_rows(W, windows_logp, (T, 2), torch.float32, self.device).contiguous()
