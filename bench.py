@@ -12,6 +12,12 @@ by ONE all_gather that closes the block -- north_star's "single RCCL gather at t
 per-call all_gather of `voice_activity_detection_amd.distributed.forward_sharded`; both are measured on every N > 1 run).
 Default workload = BASELINE.json configs[1]: [32, 800, 80] fp32 per GPU, seeded weights.
 
+The K batches of a block are independent, so up to three of them are kept IN FLIGHT (voice_activity_detection_amd.PipelinedVAD: one HIP
+stream, library handle and workspace per forward in flight; the same bits as one at a time): the warm-up times 1, 2 and 3 in flight and
+the timed blocks use the fastest (--in-flight N fixes it).  Every step's work is complete inside its block (join + synchronize before the
+clock stops).  The one-at-a-time figure is printed beside `value` (ms_per_step_one_in_flight), and the per-kernel roofline block is
+measured with ONE forward in flight, so that a launch's duration is the kernel's own.
+
 Timing: W warm-up steps (at least 0.2 s of them, so the clocks have ramped), then BLOCKS
 of exactly K steps, each bracketed by barrier + torch.cuda.synchronize() on both sides and by a pair of HIP events
 on the launch stream, repeated until at least --min-seconds (0.5 s) of timed work has run (never fewer than 5
@@ -681,7 +687,7 @@ def main():
 
     def shape_leg(prec, b2, t2, gm):
         def run():
-            r = Runner(state, b2, t2, prec, dev, rank, world, dist, gm or "step")
+            r = Runner(state, b2, t2, prec, dev, rank, world, dist, gm or "step", in_flight=args.in_flight)
             r.set_gather(gm or "step", 20)
             k2 = 20 if t2 > 32 else 50
             w, e, y2 = r.timed_blocks(k2, 5, args.min_seconds)

@@ -7,12 +7,14 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 3 --min-seconds 0.02 --no-secondary --no-cpu-baseline $*"
+# --in-flight 1: one forward at a time, so that a launch's duration (trace) and its counters (PMC) are the kernel's own -- bench.py's
+# default keeps up to three batches in flight, whose launches overlap
+BENCH="python $REPO/bench.py --in-flight 1 --steps 10 --warmup 3 --min-seconds 0.02 --no-secondary --no-cpu-baseline $*"
 # the kernel-trace pass runs the SAME command as the default bench line (K = 50, W = 10, secondary legs included): its
 # per-kernel averages are the ones bench.py's HIP-event durations are checked against; the PMC passes serialise kernels,
 # so they run the primary workload only and stay short
 # (the legs that run the profiled kernels at ONE shape each: their averages feed bench.py's event_over_rocprof)
-TRACE_BENCH="python $REPO/bench.py --no-cpu-baseline --legs configs2_bf16_b256_t800,pipeline_fp32_b1000_t7,configs0_clip10s_audio_to_probabilities $*"
+TRACE_BENCH="python $REPO/bench.py --in-flight 1 --no-cpu-baseline --legs configs2_bf16_b256_t800,pipeline_fp32_b1000_t7,configs0_clip10s_audio_to_probabilities $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- $TRACE_BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
