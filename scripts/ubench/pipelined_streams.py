@@ -7,11 +7,12 @@ import torch
 from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, seeded_features
 
 B, T, PREC = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+MODE = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 sd = {k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()}
 def mk():
     m = SelfAttentiveVAD(80, 3, 128, 0.5)
     m.load_state_dict(sd)
-    m = m.cuda().eval(); m.precision = PREC
+    m = m.cuda().eval(); m.precision = PREC; m.row_mode = MODE
     return m
 NS = 4
 ms = [mk() for _ in range(NS)]
@@ -28,4 +29,4 @@ def run(nstreams, n):
 for ns in (1, 2, 3, 4, 1, 2):
     run(ns, 300)
     t = time.perf_counter(); run(ns, 400); dt = (time.perf_counter() - t) / 400
-    print(f"[{B},{T}] {PREC} {ns} stream(s): {dt*1e6:8.1f} us per forward", flush=True)
+    print(f"[{B},{T}] {PREC} row_mode {MODE} {ns} stream(s): {dt*1e6:8.1f} us per forward", flush=True)
