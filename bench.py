@@ -523,6 +523,21 @@ def config3_global_one_gpu(state, dev, min_seconds):
         return y
 
     med, mn, blocks, _ = _event_blocks(one_pass, 4, min_seconds)
+    # the same eight shards two in flight (PipelinedVAD: the shards are independent batches)
+    from voice_activity_detection_amd import PipelinedVAD
+    pipe = PipelinedVAD(model, depth=2)
+    pipe.reserve(T, max_batch=Bg // world)
+    y2 = torch.empty_like(y)
+
+    def one_pass_in_flight():
+        for r in range(world):
+            lo, hi = shard_bounds(Bg, r, world)
+            pipe.submit(x[lo:hi], out=y2[lo:hi])
+        pipe.join()
+        return y2
+
+    medp, mnp, _, _ = _event_blocks(one_pass_in_flight, 4, min_seconds / 2)
+    same_p = bool(torch.equal(y2, y))
     with torch.no_grad():
         whole = model(features=x)  # the global batch as ONE forward (2.1 GB workspace)
     same = bool(torch.equal(whole, y))
@@ -531,6 +546,8 @@ def config3_global_one_gpu(state, dev, min_seconds):
     return {"workload": "BASELINE configs[3] global batch on ONE GPU: synthetic [B=2048, T=800, F=80] bf16, eight 256-sequence shards back to back",
             "ms_per_pass": round(med, 4), "ms_per_pass_min": round(mn, 4), "frames_per_s": round(frames / (med * 1e-3), 1),
             "forward_frac_of_bf16_peak": round(flops_per_frame(T) * frames / (med * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            "two_shards_in_flight_ms_per_pass": round(medp, 4), "two_shards_in_flight_ms_min": round(mnp, 4),
+            "two_shards_in_flight_frames_per_s": round(frames / (medp * 1e-3), 1), "two_shards_in_flight_equals_sharded_bits": same_p,
             "single_forward_ms": round(med1, 4), "single_forward_ms_min": round(mn1, 4), "single_forward_equals_sharded_bits": same,
             "finite": bool(torch.isfinite(y).all().item()), "blocks": blocks, "unit": "frames/s"}
 
