@@ -14,7 +14,7 @@ def mk():
     m.load_state_dict(sd)
     m = m.cuda().eval(); m.precision = PREC; m.row_mode = MODE
     return m
-NS = 4
+NS = 6
 ms = [mk() for _ in range(NS)]
 x = torch.from_numpy(seeded_features(1, (B, T, 80))).cuda()
 if PREC == "bf16": x = x.to(torch.bfloat16)
@@ -26,7 +26,9 @@ def run(nstreams, n):
             with torch.cuda.stream(ss[k]):
                 ms[k](x)
     torch.cuda.synchronize()
-for ns in (1, 2, 3, 4, 1, 2):
+for ns in (1, 2, 3, 4, 6):
     run(ns, 300)
     t = time.perf_counter(); run(ns, 400); dt = (time.perf_counter() - t) / 400
-    print(f"[{B},{T}] {PREC} row_mode {MODE} {ns} stream(s): {dt*1e6:8.1f} us per forward", flush=True)
+    flop = B * T * (2 * 80 * 128 + 3 * (2 * 4 * 128 * 128 + 2 * 8 * 128 * 128 + 4 * T * 128))
+    peak = 2500.0 if PREC == "bf16" else 157.3
+    print(f"[{B},{T}] {PREC} row_mode {MODE} {ns} stream(s): {dt*1e6:8.1f} us per forward  {flop/dt/1e12:6.1f} TF = {flop/dt/1e12/peak:.2f} of the peak", flush=True)
