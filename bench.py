@@ -303,6 +303,8 @@ class Runner:
         fastest; a fixed --in-flight N skips it.  Every rank tunes on its own clock: nothing in a step is collective here."""
         if self.in_flight_request or (self.dist and self.gather == "step"):
             self.pipe.set_active(self.pipe.depth if not (self.dist and self.gather == "step") else 1)
+            if self.in_flight_request:
+                self.tuning = {"fixed": self.in_flight_request}
             return
         res = {}
         for d in range(1, self.pipe.depth + 1):
@@ -326,6 +328,10 @@ class Runner:
             res[d] = (time.perf_counter() - t0) / steps * 1e3
         self.done = 0
         best = min(res, key=res.get)
+        if self.dist:  # one decision for the job (rank 0's): later code paths that contain collectives depend on it
+            flag = torch.tensor([best], dtype=torch.int64, device=self.dev)
+            self.dist.broadcast(flag, 0)
+            best = int(flag.item())
         self.pipe.set_active(best)
         self.tuning = {str(k): round(v, 4) for k, v in res.items()}
 
