@@ -751,7 +751,7 @@ def main():
                        "parallelism": f"batch-shard x{world}" + ((" + 1 RCCL all_gather of the [B,T,2] log-probs per forward" if args.gather == "step"
                                                                    else " + 1 RCCL all_gather of all K batches' log-probs per block") if use_dist else "")},
             "finite": ok,
-            "in_flight": main_run.pipe.active,
+            "in_flight": 1 if (use_dist and args.gather == "step") else main_run.pipe.active,
             "in_flight_note": "consecutive batches are independent: `in_flight` forwards are kept in flight, each on its own HIP stream with its own "
                               "library handle and workspace (voice_activity_detection_amd.PipelinedVAD; same bits as one at a time); picked during "
                               "warm-up from the ms per step in in_flight_tuning; roofline.per_kernel and roofline.frac are measured with ONE in flight",
