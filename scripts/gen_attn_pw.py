@@ -10,16 +10,24 @@ instruction stream below (no compiler-allocated register inside it).
     python scripts/gen_attn_pw.py --out F [--ablate MASK] [--timing | --count] [--split-max N] [--pad N]   # experiments
                                              # (scripts/ubench/build_timing.sh: the phase-stamp build, -DSAVAD_PW_INC)
 
+    python scripts/pw_sim.py B T [...]       # runs the stream on the functional model of scripts/gfx950_sim.py (CPU)
+
 Data layout: savad_kernels_bf16.h (fragment-major q / k / v^T / ctx, 1 KiB per K-step fragment of 32 rows).
-Arithmetic: identical, operation for operation, to attention_kernel_bf16 (online softmax in the base-2 domain relative
-to a per-row reference that rides in as the C operand of the first S^T MFMA; the reference moves when a row maximum
-drifts 2^16 above it) -- the two kernels produce the same bits, which is how this one is tested.
+Arithmetic: ordinary items are identical, operation for operation, to attention_kernel_bf16 (online softmax in the
+base-2 domain relative to a per-row reference that rides in as the C operand of the first S^T MFMA; the reference moves
+when a row maximum drifts 2^16 above it) -- same bits; key-split tail items (below) sum a row's keys in four partial
+softmaxes that meet in LDS: their rows agree with attention_kernel_bf16 to the bf16 rounding of the context.
 
 Structure
-  work items : (sequence b, group g of 8 query blocks); a workgroup walks its items (all full groups first, then the
-               ragged tail groups); sequences with b % 8 == xcd stay on one XCD, so the groups of a sequence share
-               its K / V^T in that XCD's L2.  A tail group of one or two query blocks is a FEATURE-SPLIT item: all
-               four waves take the same block(s) and each owns one 32-feature block of the context.
+  work items : (sequence b, group g of 8 query blocks); a workgroup walks the full groups of its XCD with a stride;
+               sequences with b % 8 == xcd stay on one XCD, so the groups of a sequence share its K / V^T in that
+               XCD's L2.  A sequence's ragged TAIL group runs right in front of its first full group, on the same
+               workgroup (round 3 ran all tails last: every tail then streamed its sequence's 400 KiB of K / V^T from
+               the fabric a second time, all workgroups at once -- 87.5 us against 78.0 at [256,800], same box).
+               A tail group of one or two query blocks is a KEY-SPLIT item: all four waves take the same block(s)
+               and a quarter of the key blocks each, with all 128 features (round 3's feature split had every wave
+               repeat the scores and the exponentials); the partial (O, l, reference) meet through the LDS slot of
+               the item's last stage.  Larger tail groups run as ordinary items with idle waves.
   K / V^T    : 64 keys (K 2 blocks | V^T 2 blocks = 32 KiB) per LDS stage, ring of 5 stages (the whole LDS), filled by
                LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, one M0 write per half stage: the immediate
                offset moves source AND destination) FOUR stages ahead of the compute; the stream runs continuously
@@ -62,9 +70,10 @@ V_RS = {"A": 146, "B": 147}    # row sum of the current tile
 V_MX = {"A": 148, "B": 149}    # row maxima
 V_T0, V_T1, V_T2, V_T3, V_T4, V_T5 = 150, 151, 152, 153, 154, 155
 V_LDSL = 156                   # LDS base + lane * 16
-V_ADDR_VT = 157                # tail items: V_ADDR_V + w * 2048 (this wave's feature block of the V^T fragments)
+V_KSADDR = 157                 # key-split items: LDS address of this wave's key block (K image; V^T image 16 KiB behind it)
 V_OFF = [158, 159]             # lane * 16, lane * 16 + 4096 (global offsets of Q loads / ctx stores / DMA pieces)
 V_LANE16 = V_OFF[0]
+V_SCR16, V_SCR8 = 160, 161     # key-split items: combine scratch (the slot of the item's last stage) + lane * 16 / + lane * 8
 V_ADDR_V = 162                 # LDS address of the compute stage: slot base + lane * 16
 V_ADDR_K = 163                 # LDS address of the stage behind it
 V_H4 = 164                     # 4 * (lane >> 5)
@@ -102,11 +111,17 @@ S_PEND = 87                    # finished item waiting for its stores: bits as S
 S_QPEND = 88                   # 1: the once-per-item block (stores, Q request) still has to run behind a barrier
 S_T0, S_T1, S_T2, S_T3, S_T4, S_T5 = 89, 90, 91, 94, 92, 93   # s[S_T4:S_T5] is used as a 64-bit pair
 S_LDSW = 95                    # LDS base + w * 4096
+S_KB = 96                      # key-split items: the key block this wave takes from the current pair of stages
+S_KFIRST = 97                  # key-split items: 1 until this wave has seen its first key block
+S_SCRB = 98                    # key-split items: LDS byte address of the combine scratch
+S_KPEND = 99                   # key-split items: 1 while a tile's probabilities wait for their PV MFMAs
+FLT_MAX_BITS = "0x7f7fffff"
 S_TM = 58                      # timing builds: s[58:59]
 TIMING = False
 PAD = 0              # experiments: s_nop 0 instructions in front (shifts the stream by 4 bytes each)
 COUNT_ONLY = False   # timing builds: only the cold-path call counters, no stamps
-SPLIT_MAX = 2   # tail groups of up to this many query blocks are feature-split items (experiments: 0, 1)
+SPLIT_MAX = 2   # tail groups of up to this many query blocks are key-split items (experiments: 0, 1)
+ATTACH = True   # a sequence's tail item runs right in front of its first full item (False: all tail items last, round 3's order)
 ABLATE = 0   # experiments (results WRONG): 1 no DMA pieces, 2 no barrier, 4 no row maxima / reference check, 8 no exp / sum / pack,
              # 16 no LDS operand reads
 
@@ -231,10 +246,19 @@ def vread(f, off):
 
 # ------------------------------------------------------------------------------------------------ item cursors
 def emit_cursor_next(a, c, tag):
-    """advance cursor c = [phase, bi, g, valid]: full groups (phase 0) with stride S_STRIDE in (bi, g) order, then the
-    tail groups (phase 1), one per sequence"""
+    """advance cursor c = [ph, bi, g, valid].  ph 0: the item is the full group (bi, g), reached with stride S_STRIDE in
+    (bi, g) order; ph 2: the item is the TAIL group of sequence bi, running right in front of that sequence's first
+    full group (bi, 0), which follows it on this workgroup -- the tail streams the sequence's K / V^T through the L2 just
+    before (and while) the three full groups read it; ph 1: sequences without a full group (QB < 8): tail groups only,
+    one per sequence.  (ATTACH = False: round 3's order, all full groups, then all tail groups in phase 1.)"""
     ph, bi, g, valid = c, c + 1, c + 2, c + 3
-    l_tail, l_done, l_end, l_chk = (a.uniq(tag + x) for x in ("tail", "done", "end", "chk"))
+    l_tail, l_done, l_end, l_chk, l_full = (a.uniq(tag + x) for x in ("tail", "done", "end", "chk", "full"))
+    if ATTACH:
+        a.i(f"s_cmp_eq_u32 {sr(ph)}, 2")
+        a.i(f"s_cbranch_scc0 {l_full}")
+        a.i(f"s_mov_b32 {sr(ph)}, 0")       # the tail's own full group (bi, g) comes next
+        a.i(f"s_branch {l_end}")
+        a.label(l_full)
     a.i(f"s_cmp_eq_u32 {sr(ph)}, 0")
     a.i(f"s_cbranch_scc0 {l_tail}")
     a.i(f"s_add_u32 {sr(g)}, {sr(g)}, {sr(S_DR)}")
@@ -245,15 +269,20 @@ def emit_cursor_next(a, c, tag):
     a.i(f"s_add_u32 {sr(bi)}, {sr(bi)}, 1")
     a.label(l_chk)
     a.i(f"s_cmp_lt_u32 {sr(bi)}, {sr(S_BX)}")
-    a.i(f"s_cbranch_scc1 {l_end}")
-    a.i(f"s_mov_b32 {sr(ph)}, 1")       # full groups exhausted: first tail group
-    a.i(f"s_mov_b32 {sr(bi)}, {sr(S_J)}")
-    a.i(f"s_mov_b32 {sr(g)}, {sr(S_NGF)}")
-    a.i(f"s_cmp_eq_u32 {sr(S_TAILQ)}, 0")
-    a.i(f"s_cbranch_scc1 {l_done}")
-    a.i(f"s_cmp_lt_u32 {sr(bi)}, {sr(S_BX)}")
-    a.i(f"s_cbranch_scc1 {l_end}")
-    a.i(f"s_branch {l_done}")
+    if ATTACH:
+        a.i(f"s_cbranch_scc0 {l_done}")
+        emit_attach(a, c, l_end)
+        a.i(f"s_branch {l_end}")
+    else:
+        a.i(f"s_cbranch_scc1 {l_end}")
+        a.i(f"s_mov_b32 {sr(ph)}, 1")       # full groups exhausted: first tail group
+        a.i(f"s_mov_b32 {sr(bi)}, {sr(S_J)}")
+        a.i(f"s_mov_b32 {sr(g)}, {sr(S_NGF)}")
+        a.i(f"s_cmp_eq_u32 {sr(S_TAILQ)}, 0")
+        a.i(f"s_cbranch_scc1 {l_done}")
+        a.i(f"s_cmp_lt_u32 {sr(bi)}, {sr(S_BX)}")
+        a.i(f"s_cbranch_scc1 {l_end}")
+        a.i(f"s_branch {l_done}")
     a.label(l_tail)
     a.i(f"s_add_u32 {sr(bi)}, {sr(bi)}, {sr(S_STRIDE)}")
     a.i(f"s_cmp_lt_u32 {sr(bi)}, {sr(S_BX)}")
@@ -261,6 +290,17 @@ def emit_cursor_next(a, c, tag):
     a.label(l_done)
     a.i(f"s_mov_b32 {sr(valid)}, 0")
     a.label(l_end)
+
+
+def emit_attach(a, c, l_end):
+    """the cursor has just reached the full group (bi, g): when it is the sequence's first one and the sequence has a
+    tail group, the tail group runs first (ph 2)"""
+    ph, g = c, c + 2
+    a.i(f"s_cmp_lg_u32 {sr(g)}, 0")
+    a.i(f"s_cbranch_scc1 {l_end}")
+    a.i(f"s_cmp_eq_u32 {sr(S_TAILQ)}, 0")
+    a.i(f"s_cbranch_scc1 {l_end}")
+    a.i(f"s_mov_b32 {sr(ph)}, 2")
 
 
 def emit_cursor_init(a, c, tag):
@@ -272,7 +312,12 @@ def emit_cursor_init(a, c, tag):
     a.i(f"s_cmp_eq_u32 {sr(S_NGF)}, 0")
     a.i(f"s_cbranch_scc1 {l_tail}")
     a.i(f"s_cmp_lt_u32 {sr(bi)}, {sr(S_BX)}")
-    a.i(f"s_cbranch_scc1 {l_end}")
+    if ATTACH:
+        a.i(f"s_cbranch_scc0 {l_done}")     # no full group for this workgroup: no tail group either (they come attached)
+        emit_attach(a, c, l_end)
+        a.i(f"s_branch {l_end}")
+    else:
+        a.i(f"s_cbranch_scc1 {l_end}")
     a.label(l_tail)
     a.i(f"s_mov_b32 {sr(ph)}, 1")
     a.i(f"s_mov_b32 {sr(bi)}, {sr(S_J)}")
@@ -382,7 +427,9 @@ def emit_item_params(a, c, flags, qa, seqblk):
     scores and the softmax redundantly, and owns one of the four 32-feature blocks of the context."""
     l_split, l_end = a.uniq("ipsplit"), a.uniq("ipend")
     emit_seq_block(a, c, seqblk)
-    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(c + 2)}, 3")          # first query block of the group
+    a.i(f"s_cmp_eq_u32 {sr(c)}, 2")                         # an attached tail item: group NGF, whatever g says
+    a.i(f"s_cselect_b32 {sr(S_T0)}, {sr(S_NGF)}, {sr(c + 2)}")
+    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_T0)}, 3")            # first query block of the group
     a.i(f"s_sub_u32 {sr(S_T1)}, {sr(S_QB)}, {sr(S_T0)}")   # query blocks left in the sequence
     a.i(f"s_min_u32 {sr(S_T1)}, {sr(S_T1)}, 8")
     a.i(f"s_cmp_le_u32 {sr(S_T1)}, {SPLIT_MAX}")
@@ -458,14 +505,11 @@ def emit_post_barrier_sub(a):
     a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
 
 
-def rotate_ops(tail):
+def rotate_ops():
     """the stage behind the compute stage becomes the compute stage"""
-    ops = [f"v_mov_b32 {vr(V_ADDR_V)}, {vr(V_ADDR_K)}",
-           f"s_add_u32 {sr(S_KS)}, {sr(S_KS)}, {STAGE}\n\ts_cmp_eq_u32 {sr(S_KS)}, {NRING * STAGE}\n\ts_cselect_b32 {sr(S_KS)}, 0, {sr(S_KS)}",
-           f"v_add_u32 {vr(V_ADDR_K)}, {sr(S_KS)}, {vr(V_LDSL)}"]
-    if tail:
-        ops += [f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11\n\tv_add_u32 {vr(V_ADDR_VT)}, {sr(S_T0)}, {vr(V_ADDR_V)}"]
-    return ops
+    return [f"v_mov_b32 {vr(V_ADDR_V)}, {vr(V_ADDR_K)}",
+            f"s_add_u32 {sr(S_KS)}, {sr(S_KS)}, {STAGE}\n\ts_cmp_eq_u32 {sr(S_KS)}, {NRING * STAGE}\n\ts_cselect_b32 {sr(S_KS)}, 0, {sr(S_KS)}",
+            f"v_add_u32 {vr(V_ADDR_K)}, {sr(S_KS)}, {vr(V_LDSL)}"]
 
 
 def emit_stage_top(a):
@@ -500,31 +544,20 @@ def softmax_split(buf, blk):
     return head, pack, lsum
 
 
-def pv_mfmas(blocks, tail):
-    mf = []
-    for blk in blocks:
-        if tail:
-            for j in range(2):
-                O = A_O[blk]
-                mf.append(f"v_mfma_f32_32x32x16_bf16 {ar(O, 16)}, {ar(A_V + 4 * j, 4)}, {vr(V_P[blk] + 4 * j, 4)}, {ar(O, 16)}")
-        else:
-            for j in range(2):
-                for nbd in range(4):
-                    mf.append(mfma_pv(blk, nbd, j))
-    return mf
+def pv_mfmas(blocks):
+    return [mfma_pv(blk, nbd, j) for blk in blocks for j in range(2) for nbd in range(4)]
 
 
-def emit_step(a, i_par, has_prev, has_next, tail, dma, book):
+def emit_step(a, i_par, has_prev, has_next, dma, book):
     """Key block i (parity i_par: its scores sit in buffer i_par; the next tile's go to the other one).  Two-stage
     pipeline: the step issues  [O^T += V^T(i-1) P^T(i-1)]  (has_prev)  then  [S^T(i+1) = K(i+1) Q^T]  (has_next)  while the
     VALU works through tile i: exponentials, row sums, bf16 packing -- nothing the MFMAs of this step wait for.
       first half   beside the PV MFMAs : K(i+1) fragment reads, exponentials of both blocks, row sum of block A
       second half  beside the S^T MFMAs: V^T(i) fragment reads, row sum of block B, packing (P(i-1) has been consumed),
-                                         DMA pieces, stream advance, address rotation, the reference check
-    tail: 0 ordinary item; 1 / 2 feature-split item with block A / A and B (this wave's feature block only)."""
+                                         DMA pieces, stream advance, address rotation, the reference check"""
     cur, nxt = i_par, 1 - i_par
-    blocks = ("A",) if tail == 1 else ("A", "B")
-    mfP = pv_mfmas(blocks, tail) if has_prev else []
+    blocks = ("A", "B")
+    mfP = pv_mfmas(blocks) if has_prev else []
     mfS = []
     if has_next:
         for ks in range(8):
@@ -536,10 +569,7 @@ def emit_step(a, i_par, has_prev, has_next, tail, dma, book):
     # LDS reads: K(i+1) = second block of the compute stage (i even) or first block of the stage behind it (i odd)
     kr = [kread(f, V_ADDR_V, BLK) if i_par == 0 else kread(f, V_ADDR_K, 0) for f in range(8)] if has_next else []
     vblk = BLK * i_par
-    if tail:
-        vr_ops = [f"ds_read_b128 {ar(A_V + 4 * j, 4)}, {vr(V_ADDR_VT)} offset:{16384 + vblk + j * FRAG}" for j in range(2)]
-    else:
-        vr_ops = [vread(f, vblk) for f in (0, 2, 4, 6, 1, 3, 5, 7)]
+    vr_ops = [vread(f, vblk) for f in (0, 2, 4, 6, 1, 3, 5, 7)]
     if ABLATE & 16:
         kr, vr_ops = [], []
     head, pack, lsum = {}, {}, {}
@@ -576,10 +606,6 @@ def emit_step(a, i_par, has_prev, has_next, tail, dma, book):
         # the last MFMA of S^T(i) was issued at the very end of the previous step: its readers start 2 MFMAs in
         spread(gaps, kr, 0, max(1, nP // 2))
         spread(gaps, one, 2, nP)
-    elif nP > 0:   # feature-split items: 2 PV MFMAs
-        pre = ["s_nop 7", "s_nop 7"] if has_prev else []
-        spread(gaps, kr, 0, nP)
-        spread(gaps, one, 0, nP)
     else:
         pre = kr + one
     if N - nP > 0:
@@ -613,11 +639,10 @@ def emit_step(a, i_par, has_prev, has_next, tail, dma, book):
             a.i(op)
 
 
-def emit_drain(a, tail):
+def emit_drain(a):
     """O^T += V^T P^T of the item's last tile"""
-    blocks = ("A",) if tail == 1 else ("A", "B")
     a.i("s_waitcnt lgkmcnt(0)")
-    for op in pv_mfmas(blocks, tail):
+    for op in pv_mfmas(("A", "B")):
         a.i(op)
 
 
@@ -638,7 +663,7 @@ def emit_mask(a, buf, blocks):
     a.label(l_skip)
 
 
-def emit_stage(a, kind, tail):
+def emit_stage(a, kind):
     """kind: 'fmid' (the item's first stage, steps 0 and 1, tile 2 exists), 'mid' (two steps in the middle), 'last2' (the
     item's last two tiles), 'last1' (its last tile alone), 'flast2' (an item of two tiles).  Every stage: one barrier,
     8 DMA pieces, one stream advance, one rotation of the ring addresses."""
@@ -646,24 +671,24 @@ def emit_stage(a, kind, tail):
     emit_stage_top(a)
     stamp(a, 2)
     kh, vh = dma_half_ops(0), dma_half_ops(1)
-    c_even, c_odd, c_last = (4, 5, 6) if not tail else (20, 21, 22)
-    blocks = ("A",) if tail == 1 else ("A", "B")
-    odd_book = rotate_ops(tail)
+    c_even, c_odd, c_last = 4, 5, 6
+    blocks = ("A", "B")
+    odd_book = rotate_ops()
     if kind in ("mid", "fmid"):
-        emit_step(a, 0, kind == "mid", True, tail, kh, [])
+        emit_step(a, 0, kind == "mid", True, kh, [])
         stamp(a, c_even)
-        emit_step(a, 1, True, True, tail, vh + dma_advance_ops(a),
+        emit_step(a, 1, True, True, vh + dma_advance_ops(a),
                   odd_book + ([f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"] if kind == "mid" else []))
         stamp(a, c_odd)
     elif kind in ("last2", "flast2"):
-        emit_step(a, 0, kind == "last2", True, tail, kh, [])
+        emit_step(a, 0, kind == "last2", True, kh, [])
         stamp(a, c_even)
         emit_mask(a, 1, blocks)
-        emit_step(a, 1, True, False, tail, vh + dma_advance_ops(a), odd_book)
+        emit_step(a, 1, True, False, vh + dma_advance_ops(a), odd_book)
         stamp(a, c_last)
     else:
         emit_mask(a, 0, blocks)
-        emit_step(a, 0, True, False, tail, kh + vh + dma_advance_ops(a), odd_book)
+        emit_step(a, 0, True, False, kh + vh + dma_advance_ops(a), odd_book)
         stamp(a, c_last)
 
 
@@ -768,8 +793,6 @@ def emit_item_prologue(a):
         a.i(f"v_mov_b32 {vr(V_L[blk])}, 0")
         for r in range(16):
             a.i(f"v_mov_b32 {vr(V_NEGM[blk] + r)}, 0")
-    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11")
-    a.i(f"v_add_u32 {vr(V_ADDR_VT)}, {sr(S_T0)}, {vr(V_ADDR_V)}")
     a.i("s_waitcnt lgkmcnt(0)")
     stamp(a, 28)
     n = 0
@@ -787,16 +810,8 @@ def emit_item_prologue(a):
     a.i(f"s_lshr_b32 {sr(S_CNT)}, {sr(S_CNT)}, 1")
 
 
-def emit_normalise(a, blk, nregs, dst):
-    """context block(s) of query block blk: a[A_O[blk] .. + nregs) / row sum -> bf16 pairs in v[dst ..]; rows of a ragged
-    last query block that do not exist store exact zeros (as store_ctx of savad_kernels_bf16.h)"""
-    a.i(f"v_mov_b32 {vr(V_T0)}, {vr(V_L[blk])}")
-    a.i("s_nop 1")
-    a.i(f"v_permlane32_swap_b32 {vr(V_L[blk])}, {vr(V_T0)}")
-    a.i(f"v_add_f32 {vr(V_T0)}, {vr(V_L[blk])}, {vr(V_T0)}")
-    x, out = V_T0, V_INV[blk]
-    t0, t1, t2, t3 = V_T1, V_T2, V_T3, V_T4
-    # 1.0f / x as hipcc emits it (IEEE): v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup
+def emit_recip(a, x, out, t0, t1, t2, t3):
+    """out = 1.0f / x as hipcc emits it (IEEE): v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup (clobbers vcc, s[S_T4:S_T5])"""
     a.i(f"v_div_scale_f32 {vr(t0)}, {sr(S_T4, 2)}, {vr(x)}, {vr(x)}, 1.0")
     a.i(f"v_rcp_f32 {vr(t1)}, {vr(t0)}")
     a.i("s_nop 0")
@@ -810,6 +825,17 @@ def emit_normalise(a, blk, nregs, dst):
     a.i("s_nop 1")
     a.i(f"v_div_fmas_f32 {vr(t2)}, {vr(t2)}, {vr(t1)}, {vr(t3)}")
     a.i(f"v_div_fixup_f32 {vr(out)}, {vr(t2)}, {vr(x)}, 1.0")
+
+
+def emit_normalise(a, blk, nregs, dst):
+    """context block(s) of query block blk: a[A_O[blk] .. + nregs) / row sum -> bf16 pairs in v[dst ..]; rows of a ragged
+    last query block that do not exist store exact zeros (as store_ctx of savad_kernels_bf16.h)"""
+    a.i(f"v_mov_b32 {vr(V_T0)}, {vr(V_L[blk])}")
+    a.i("s_nop 1")
+    a.i(f"v_permlane32_swap_b32 {vr(V_L[blk])}, {vr(V_T0)}")
+    a.i(f"v_add_f32 {vr(V_T0)}, {vr(V_L[blk])}, {vr(V_T0)}")
+    out = V_INV[blk]
+    emit_recip(a, V_T0, out, V_T1, V_T2, V_T3, V_T4)
     a.i(f"v_cmp_gt_i32 vcc, {sr(S_VALID[blk])}, {vr(V_M)}")
     a.i("s_nop 1")
     a.i(f"v_cndmask_b32 {vr(out)}, 0, {vr(out)}, vcc")   # (rows that do not exist: factor 0, cleaned up below)
@@ -834,19 +860,13 @@ def emit_normalise(a, blk, nregs, dst):
     a.label(l_end)
 
 
-def emit_item_epilogue(a, tail):
-    """normalise O by the row sums, pack to bf16 fragments into the staging registers of the stores, describe them"""
-    a.i("s_nop 7")
-    a.i("s_nop 7")
-    a.i("s_nop 7")
-    blocks = ("A",) if tail == 1 else ("A", "B")
-    for blk in blocks:
-        emit_normalise(a, blk, 16 if tail else 64, V_CTX[blk])
+def emit_ctx_dest(a, split):
+    """where the finished item's context goes: blocks qa, qa + 1 of the sequence (split: this wave's fragments 2w, 2w + 1)"""
     a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_SEQBLK)}, {sr(S_QA)}")
     emit_block_addr(a, S_CDST, S_CTXF, S_T3, S_T2, S_T1)
     a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_T3)}, 1")
     emit_block_addr(a, S_CDSTB, S_CTXF, S_T3, S_T2, S_T1)
-    if tail:   # this wave's two fragments: 2w, 2w + 1
+    if split:
         a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 11")
         for d in (S_CDST, S_CDSTB):
             a.i(f"s_add_u32 {sr(d)}, {sr(d)}, {sr(S_T0)}")
@@ -854,34 +874,307 @@ def emit_item_epilogue(a, tail):
     a.i(f"s_mov_b32 {sr(S_PEND)}, {sr(S_FLAGS)}")
 
 
-def emit_item_body(a, tail, tag):
+def emit_item_epilogue(a):
+    """normalise O by the row sums, pack to bf16 fragments into the staging registers of the stores, describe them"""
+    a.i("s_nop 7")
+    a.i("s_nop 7")
+    a.i("s_nop 7")
+    for blk in ("A", "B"):
+        emit_normalise(a, blk, 64, V_CTX[blk])
+    emit_ctx_dest(a, False)
+
+
+def emit_item_body(a, tag):
     """the stages of an item whose prologue has run: QB == 2: 'flast2'; else 'fmid', (QB - 3) / 2 x 'mid', then 'last2' (QB
     even) or 'last1' (QB odd); the PV MFMAs of the last tile; the epilogue"""
     l_mid, l_last, l_l1, l_done, l_two = (f".Lpw_{tag}_{x}" for x in ("mid", "last", "last1", "done", "two"))
     a.i(f"s_cmp_eq_u32 {sr(S_QB)}, 2")
     a.i(f"s_cbranch_scc1 {l_two}")
-    emit_stage(a, "fmid", tail)
+    emit_stage(a, "fmid")
     a.i(f"s_cmp_eq_u32 {sr(S_CNT)}, 0")
     a.i(f"s_cbranch_scc1 {l_last}")
     a.label(l_mid)
-    emit_stage(a, "mid", tail)
+    emit_stage(a, "mid")
     a.i(f"s_cmp_lg_u32 {sr(S_CNT)}, 0")
     a.i(f"s_cbranch_scc1 {l_mid}")
     a.label(l_last)
     a.i(f"s_bitcmp1_b32 {sr(S_QB)}, 0")
     a.i(f"s_cbranch_scc1 {l_l1}")
-    emit_stage(a, "last2", tail)
+    emit_stage(a, "last2")
     a.i(f"s_branch {l_done}")
     a.label(l_l1)
-    emit_stage(a, "last1", tail)
+    emit_stage(a, "last1")
     a.i(f"s_branch {l_done}")
     a.label(l_two)
-    emit_stage(a, "flast2", tail)
+    emit_stage(a, "flast2")
     a.label(l_done)
-    emit_drain(a, tail)
+    emit_drain(a)
     stamp(a, 11)
-    emit_item_epilogue(a, tail)
+    emit_item_epilogue(a)
     stamp(a, 8)
+    a.i("s_branch .Lpw_next_item")
+
+
+# ------------------------------------------------------------------------------------------------ key-split tail items
+def emit_with_gaps(a, mfmas, fillers):
+    """the MFMAs with the filler instructions (kept in order) spread evenly over the gaps behind them"""
+    gaps = [[] for _ in mfmas]
+    spread(gaps, fillers, 0, len(mfmas))
+    for mf, g in zip(mfmas, gaps):
+        a.i(mf)
+        for op in g:
+            a.i(op)
+
+
+def emit_ks_scores(a, nb, dma):
+    """Key-split item, first stage of a pair: this wave's key block S_KB = 4 p + w of the pair of stages (c, c + 1) that
+    is resident behind this stage's barrier (waves 0 / 1: blocks 0 / 1 of the compute stage, waves 2 / 3: of the stage
+    behind it) against the item's nb query blocks with all 128 features: K and V^T fragments into registers (the V^T
+    image's slot may be refilled from the next barrier on), scores, softmax against this wave's OWN reference.  The
+    stage's DMA pieces ride in the gaps of the score MFMAs (beside VALU work each would stall the wave 50 - 110 cycles)."""
+    blocks = ("A", "B")[:nb]
+    hi, join, nomask, notfirst = (a.uniq("ks" + x) for x in ("hi", "join", "nomask", "nf"))
+    a.i(f"s_cmp_lt_u32 {sr(S_W)}, 2")
+    a.i(f"s_cbranch_scc0 {hi}")
+    a.i(f"v_mov_b32 {vr(V_KSADDR)}, {vr(V_ADDR_V)}")
+    a.i(f"s_branch {join}")
+    a.label(hi)
+    a.i(f"v_mov_b32 {vr(V_KSADDR)}, {vr(V_ADDR_K)}")
+    a.label(join)
+    a.i(f"s_and_b32 {sr(S_T0)}, {sr(S_W)}, 1")
+    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_T0)}, 13")
+    a.i(f"v_add_u32 {vr(V_KSADDR)}, {sr(S_T0)}, {vr(V_KSADDR)}")
+    for f in range(8):
+        a.i(f"ds_read_b128 {ar(A_K + 4 * f, 4)}, {vr(V_KSADDR)} offset:{f * FRAG}")
+    for f in range(8):
+        a.i(f"ds_read_b128 {ar(A_V + 4 * f, 4)}, {vr(V_KSADDR)} offset:{16384 + f * FRAG}")
+    a.i("s_waitcnt lgkmcnt(8)")      # the K fragments (LDS returns in order)
+    emit_with_gaps(a, [mfma_s(0, blk, ks) for ks in range(8) for blk in blocks], dma)
+    a.i("s_nop 7")                   # MFMA results -> VALU
+    a.i("s_nop 7")
+    # the sequence's last key block may be ragged
+    a.i(f"s_sub_u32 {sr(S_T0)}, {sr(S_QB)}, 1")
+    a.i(f"s_cmp_eq_u32 {sr(S_KB)}, {sr(S_T0)}")
+    a.i(f"s_cbranch_scc0 {nomask}")
+    emit_mask(a, 0, blocks)
+    a.label(nomask)
+    # this wave's first tile sets its reference
+    a.i(f"s_cmp_eq_u32 {sr(S_KFIRST)}, 0")
+    a.i(f"s_cbranch_scc1 {notfirst}")
+    a.i(f"s_call_b64 {sr(S_RET, 2)}, .Lpw_ksfirst_{nb}")
+    a.i(f"s_mov_b32 {sr(S_KFIRST)}, 0")
+    a.label(notfirst)
+    lsum = []
+    for blk in blocks:
+        head, pack, ls = softmax_split(0, blk)
+        for op in head + pack:
+            a.i(op)
+        lsum += ls
+    if nb == 2:
+        a.i(f"v_max_f32 {vr(V_T1)}, {vr(V_RS['A'])}, {vr(V_RS['B'])}")
+        a.i(f"v_cmp_nge_f32 vcc, {CHECK_BITS}, {vr(V_T1)}")
+    else:
+        a.i(f"v_cmp_nge_f32 vcc, {CHECK_BITS}, {vr(V_RS['A'])}")
+    a.i("s_nop 4")
+    a.i("s_cmp_lg_u64 vcc, 0")
+    a.ool_call(f".Lpw_coldmid_0_0_{nb}")
+    for op in lsum:
+        a.i(op)
+    a.i("s_waitcnt lgkmcnt(0)")      # the V^T fragments are in registers before the barrier that frees their slot
+    a.i(f"s_mov_b32 {sr(S_KPEND)}, 1")
+
+
+def emit_ks_pv(a, nb, dma):
+    """Key-split item, second stage of a pair (or behind the item's last stage): O^T += V^T P^T of the pending tile,
+    operands in registers since the first stage; the stage's DMA pieces in the gaps"""
+    a.i("s_nop 1")
+    emit_with_gaps(a, pv_mfmas(("A", "B")[:nb]), dma)
+    a.i(f"s_mov_b32 {sr(S_KPEND)}, 0")
+
+
+def emit_ks_first(a, nb):
+    """first tile of a key-split wave (buffer 0): the reference is SET (nothing to rescale)"""
+    a.label(f".Lpw_ksfirst_{nb}")
+    for blk in ("A", "B")[:nb]:
+        l_skip = a.uniq("kfskip")
+        emit_move(a, 0, blk, True, False, l_skip)
+        a.label(l_skip)
+    a.i("s_nop 1")
+    a.i(f"s_setpc_b64 {sr(S_RET, 2)}")
+
+
+def emit_ks_combine(a, nb):
+    """The four waves hold partial (O, l) of the same query block(s) against their own references r_w.  Through the LDS
+    slot of the item's last stage (free until the next stage's barrier): everybody publishes (-r_w, l_w) per row; the
+    common reference is the largest; wave w scales its O by f_w = 2^(r_w - r) / sum_u l_u 2^(r_u - r); then, feature block
+    d = 0 .. 3 in turn, the other three waves hand their scaled block d to wave d (two alternating 12 KiB buffers, one
+    barrier per round), which adds them to its own in a fixed order, packs to bf16 and keeps the two fragments for the
+    item's stores (as the stores of a split item expect them: V_CTX[blk] + 0 .. 7)."""
+    blocks = ("A", "B")[:nb]
+    TS, TR, TO = 0, (16, 48, 64), 80     # temporaries: source block, the three received blocks, own block (all dead by now)
+    ML = {"A": 0, "B": 16}               # (-reference, row sum) of the four waves: 8 registers per query block
+    a.i("s_nop 7")                       # the last PV MFMAs have retired
+    a.i("s_nop 7")
+    a.i("s_nop 7")
+    a.i(f"s_sub_i32 {sr(S_SCRB)}, {sr(S_KS)}, {2 * STAGE}")     # the slot two behind the stage S_KS names = the item's last stage
+    a.i(f"s_cmp_lt_i32 {sr(S_SCRB)}, 0")
+    a.i(f"s_cselect_b32 {sr(S_T0)}, {NRING * STAGE}, 0")
+    a.i(f"s_add_u32 {sr(S_SCRB)}, {sr(S_SCRB)}, {sr(S_T0)}")
+    a.i(f"s_add_u32 {sr(S_SCRB)}, {sr(S_SCRB)}, {sr(S_LDS)}")
+    a.i(f"v_add_u32 {vr(V_SCR16)}, {sr(S_SCRB)}, {vr(V_LANE16)}")
+    a.i(f"v_lshrrev_b32 {vr(V_SCR8)}, 1, {vr(V_LANE16)}")
+    a.i(f"v_add_u32 {vr(V_SCR8)}, {sr(S_SCRB)}, {vr(V_SCR8)}")
+    a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 9")
+    a.i(f"v_add_u32 {vr(V_T5)}, {sr(S_T0)}, {vr(V_SCR8)}")      # this wave's (-reference, row sum) slot
+    l_has = a.uniq("kshas")
+    a.i(f"s_cmp_eq_u32 {sr(S_KFIRST)}, 0")
+    a.i(f"s_cbranch_scc1 {l_has}")
+    for blk in blocks:   # a wave that saw no key block: reference -FLT_MAX, so that its zero sums do not set the common one
+        a.i(f"v_mov_b32 {vr(V_NEGM[blk])}, {FLT_MAX_BITS}")
+    a.label(l_has)
+    a.i("s_barrier")                     # everybody has finished reading the ring slot that becomes the scratch
+    for bi, blk in enumerate(blocks):
+        t = V_T0 if bi == 0 else V_T2    # (V_T0, V_T1) / (V_T2, V_T3): consecutive registers for the 8-byte write
+        a.i(f"v_mov_b32 {vr(t + 1)}, {vr(V_L[blk])}")
+        a.i("s_nop 1")
+        a.i(f"v_permlane32_swap_b32 {vr(V_L[blk])}, {vr(t + 1)}")
+        a.i(f"v_add_f32 {vr(t + 1)}, {vr(V_L[blk])}, {vr(t + 1)}")        # the whole row sum
+        a.i(f"v_mov_b32 {vr(t)}, {vr(V_NEGM[blk])}")
+        a.i(f"ds_write_b64 {vr(V_T5)}, {vr(t, 2)} offset:{bi * 2048}")
+    a.i("s_waitcnt lgkmcnt(0)")
+    a.i("s_barrier")
+    for bi, blk in enumerate(blocks):
+        for u in range(4):
+            a.i(f"ds_read_b64 {vr(ML[blk] + 2 * u, 2)}, {vr(V_SCR8)} offset:{bi * 2048 + u * 512}")
+    a.i("s_waitcnt lgkmcnt(0)")
+    for blk in blocks:
+        n = [ML[blk] + 2 * u for u in range(4)]
+        l = [ML[blk] + 2 * u + 1 for u in range(4)]
+        a.i(f"v_min_f32 {vr(V_T0)}, {vr(n[0])}, {vr(n[1])}")
+        a.i(f"v_min_f32 {vr(V_T1)}, {vr(n[2])}, {vr(n[3])}")
+        a.i(f"v_min_f32 {vr(V_T0)}, {vr(V_T0)}, {vr(V_T1)}")              # -(common reference)
+        for u in range(4):
+            a.i(f"v_sub_f32 {vr(n[u])}, {vr(V_T0)}, {vr(n[u])}")          # r_u - r
+        a.i(f"v_sub_f32 {vr(V_T2)}, {vr(V_T0)}, {vr(V_NEGM[blk])}")       # r_w - r
+        for u in range(4):
+            a.i(f"v_exp_f32 {vr(n[u])}, {vr(n[u])}")
+        a.i(f"v_exp_f32 {vr(V_T2)}, {vr(V_T2)}")
+        a.i("s_nop 0")
+        a.i(f"v_mul_f32 {vr(V_T1)}, {vr(l[0])}, {vr(n[0])}")
+        for u in range(1, 4):
+            a.i(f"v_fmac_f32 {vr(V_T1)}, {vr(l[u])}, {vr(n[u])}")         # the row sum against the common reference
+        emit_recip(a, V_T1, V_INV[blk], V_T3, V_T4, V_T5, V_T0)
+        a.i(f"v_mul_f32 {vr(V_INV[blk])}, {vr(V_INV[blk])}, {vr(V_T2)}")
+        a.i(f"v_cmp_gt_i32 vcc, {sr(S_VALID[blk])}, {vr(V_M)}")
+        a.i(f"v_cndmask_b32 {vr(V_INV[blk])}, 0, {vr(V_INV[blk])}, vcc")  # (rows that do not exist: cleaned up at the packing)
+    rnd = 0
+    for blk in blocks:
+        for d in range(4):
+            buf = 4096 + (rnd & 1) * 12288
+            l_meet, l_skip = a.uniq("ksmeet"), a.uniq("ksskip")
+            a.i(f"s_cmp_eq_u32 {sr(S_W)}, {d}")
+            a.i(f"s_cbranch_scc1 {l_meet}")
+            a.i(f"s_cmp_gt_u32 {sr(S_W)}, {d}")          # rank of this wave among the three sources
+            a.i(f"s_cselect_b32 {sr(S_T0)}, 1, 0")
+            a.i(f"s_sub_u32 {sr(S_T0)}, {sr(S_W)}, {sr(S_T0)}")
+            a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_T0)}, 12")
+            a.i(f"v_add_u32 {vr(V_T5)}, {sr(S_T0)}, {vr(V_SCR16)}")
+            for r in range(16):
+                a.i(f"v_accvgpr_read_b32 {vr(TS + r)}, {ar(A_O[blk] + 16 * d + r)}")
+            for r in range(16):
+                a.i(f"v_mul_f32 {vr(TS + r)}, {vr(TS + r)}, {vr(V_INV[blk])}")
+            for q in range(4):
+                a.i(f"ds_write_b128 {vr(V_T5)}, {vr(TS + 4 * q, 4)} offset:{buf + q * 1024}")
+            a.label(l_meet)
+            a.i("s_waitcnt lgkmcnt(0)")
+            a.i("s_barrier")
+            a.i(f"s_cmp_eq_u32 {sr(S_W)}, {d}")
+            a.i(f"s_cbranch_scc0 {l_skip}")
+            for k in range(3):
+                for q in range(4):
+                    a.i(f"ds_read_b128 {vr(TR[k] + 4 * q, 4)}, {vr(V_SCR16)} offset:{buf + k * 4096 + q * 1024}")
+            for r in range(16):
+                a.i(f"v_accvgpr_read_b32 {vr(TO + r)}, {ar(A_O[blk] + 16 * d + r)}")
+            for r in range(16):
+                a.i(f"v_mul_f32 {vr(TO + r)}, {vr(TO + r)}, {vr(V_INV[blk])}")
+            a.i("s_waitcnt lgkmcnt(0)")
+            for k in range(3):
+                for r in range(16):
+                    a.i(f"v_add_f32 {vr(TO + r)}, {vr(TO + r)}, {vr(TR[k] + r)}")
+            a.i(f"v_cmp_gt_i32 vcc, {sr(S_VALID[blk])}, {vr(V_M)}")
+            for e in range(8):   # 0 * inf / NaN of a row that does not exist must still store 0
+                a.i(f"v_cvt_pk_bf16_f32 {vr(V_T1)}, {vr(TO + 2 * e)}, {vr(TO + 2 * e + 1)}")
+                a.i(f"v_cndmask_b32 {vr(V_CTX[blk] + e)}, 0, {vr(V_T1)}, vcc")
+            a.label(l_skip)
+            rnd += 1
+    emit_ctx_dest(a, True)
+
+
+def emit_ks_item(a, nb):
+    """A tail group of nb = 1 or 2 query blocks as a KEY-SPLIT item: all four waves take the same query block(s) and a
+    quarter of the key blocks each (key block kb belongs to wave kb % 4), with all 128 features -- no wave repeats
+    another one's scores or exponentials; the partial (O, l, reference) are combined through LDS at the end
+    (emit_ks_combine).  The K / V^T stream, its barriers and its counted waits are those of every item (one stage = two
+    key blocks per barrier); the arithmetic happens on every second stage, when the pair (c, c + 1) is resident."""
+    blocks = ("A", "B")[:nb]
+    loop, done = (f".Lpw_ks{nb}_{x}" for x in ("loop", "done"))
+    a.i("s_waitcnt vmcnt(8)")   # the staged Q is older than the newest stage of DMA pieces
+    for blk in blocks:
+        for r in range(32):
+            a.i(f"v_accvgpr_write_b32 {ar(A_Q[blk] + r)}, {vr(V_QS + (0 if blk == 'A' else 32) + r)}")
+    for blk in blocks:
+        for r in range(64):
+            a.i(f"v_accvgpr_write_b32 {ar(A_O[blk] + r)}, 0")
+        a.i(f"v_mov_b32 {vr(V_L[blk])}, 0")
+        for r in range(16):
+            a.i(f"v_mov_b32 {vr(V_NEGM[blk] + r)}, 0")
+    a.i(f"s_mov_b32 {sr(S_KB)}, {sr(S_W)}")
+    a.i(f"s_mov_b32 {sr(S_KFIRST)}, 1")
+    a.i(f"s_mov_b32 {sr(S_KPEND)}, 0")
+    a.i(f"s_mov_b32 {sr(S_CNT)}, {sr(S_NST)}")
+    stamp(a, 22)
+    a.label(loop)
+    for half in (0, 1):
+        plain, joined = a.uniq("ksplain"), a.uniq("ksjoined")
+        stamp(a, 11)
+        emit_stage_top(a)
+        stamp(a, 2)
+        dma = [] if ABLATE & 1 else dma_half_ops(0) + dma_half_ops(1)
+        if half == 0:   # the wave's key block of this pair, if the sequence has it: scores + softmax
+            a.i(f"s_cmp_lt_u32 {sr(S_KB)}, {sr(S_QB)}")
+            a.i(f"s_cbranch_scc0 {plain}")
+            emit_ks_scores(a, nb, dma)
+        else:           # ... and its share of the context
+            a.i(f"s_cmp_eq_u32 {sr(S_KPEND)}, 0")
+            a.i(f"s_cbranch_scc1 {plain}")
+            emit_ks_pv(a, nb, dma)
+        a.i(f"s_branch {joined}")
+        a.label(plain)
+        for op in dma:
+            a.i(op)
+        a.label(joined)
+        emit_dma_advance(a)
+        stamp(a, 20)
+        if half == 1:
+            a.i(f"s_add_u32 {sr(S_KB)}, {sr(S_KB)}, 4")
+        for op in rotate_ops():
+            a.i(op)
+        a.i(f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1")
+        if half == 0:
+            a.i(f"s_cmp_eq_u32 {sr(S_CNT)}, 0")
+            a.i(f"s_cbranch_scc1 {done}")
+        else:
+            a.i(f"s_cmp_lg_u32 {sr(S_CNT)}, 0")
+            a.i(f"s_cbranch_scc1 {loop}")
+    a.label(done)
+    nopend = a.uniq("ksnopend")
+    a.i(f"s_cmp_eq_u32 {sr(S_KPEND)}, 0")     # the item's last stage has no partner: its tile's context here
+    a.i(f"s_cbranch_scc1 {nopend}")
+    emit_ks_pv(a, nb, [])
+    a.label(nopend)
+    stamp(a, 11)
+    emit_ks_combine(a, nb)
+    stamp(a, 21)
     a.i("s_branch .Lpw_next_item")
 
 
@@ -985,18 +1278,12 @@ def emit_all():
     stamp(a, 25)
     a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 0")
     a.i("s_cbranch_scc0 .Lpw_idle_item")
+    if SPLIT_MAX >= 1:
+        a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 2")
+        a.i("s_cbranch_scc1 .Lpw_ks_item")
     emit_item_prologue(a)
     stamp(a, 1)
-    a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 2")
-    a.i("s_cbranch_scc0 .Lpw_normal_item")
-    if SPLIT_MAX >= 2:
-        a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 1")
-        a.i("s_cbranch_scc0 .Lpw_tail1_item")
-        emit_item_body(a, 2, "t2")
-    a.label(".Lpw_tail1_item")
-    emit_item_body(a, 1, "t1")
-    a.label(".Lpw_normal_item")
-    emit_item_body(a, 0, "n")
+    emit_item_body(a, "n")
 
     # ---- a wave without a query block in this item: keeps the stream and the barriers going
     a.label(".Lpw_idle_item")
@@ -1007,7 +1294,7 @@ def emit_all():
         emit_dma_half(a, 0)
         emit_dma_half(a, 1)
     emit_dma_advance(a)
-    for op in rotate_ops(False):
+    for op in rotate_ops():
         a.i(op)
     stamp(a, 9)
     a.i(f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1")
@@ -1041,12 +1328,24 @@ def emit_all():
     a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a.i("s_branch .Lpw_exit")
     # ---- out-of-line code: stubs, subroutines
+    # ---- key-split tail items
+    if SPLIT_MAX >= 1:
+        a.label(".Lpw_ks_item")
+        if SPLIT_MAX >= 2:
+            a.i(f"s_bitcmp1_b32 {sr(S_FLAGS)}, 1")
+            a.i("s_cbranch_scc0 .Lpw_ks1_item")
+            emit_ks_item(a, 2)
+        a.label(".Lpw_ks1_item")
+        emit_ks_item(a, 1)
     a.lines += a.tail
     a.tail = []
     for cur in (0, 1):
         for hn in (True, False):
-            for nb in (1, 2):
-                emit_cold_mid(a, cur, hn, nb)
+            emit_cold_mid(a, cur, hn, 2)
+    if SPLIT_MAX >= 1:
+        emit_cold_mid(a, 0, False, 1)
+        for nb in range(1, min(SPLIT_MAX, 2) + 1):
+            emit_ks_first(a, nb)
     emit_cold_first(a)
     emit_post_barrier_sub(a)
     emit_dma_next_item_sub(a)
@@ -1086,6 +1385,9 @@ def main():
         if "--pad" in sys.argv:
             global PAD
             PAD = int(sys.argv[sys.argv.index("--pad") + 1])
+        if "--no-attach" in sys.argv:
+            global ATTACH
+            ATTACH = False
         if "--split-max" in sys.argv:
             global SPLIT_MAX
             SPLIT_MAX = int(sys.argv[sys.argv.index("--split-max") + 1])

@@ -167,6 +167,10 @@ class Workgroup:
         self.strict = strict
         self.max_instr = 50_000_000
         self.hazards = []
+        self.label_at = {}
+        for name, idx in labels.items():
+            self.label_at.setdefault(idx, []).append(name)
+        self.label_hits = {}
 
     # ------------------------------------------------------------------ helpers
     def hazard(self, w, ins, msg):
@@ -358,6 +362,9 @@ class Workgroup:
                 w.done = True
                 return
             ins = instrs[w.pc]
+            if w.pc in self.label_at:
+                for name in self.label_at[w.pc]:
+                    self.label_hits[name] = self.label_hits.get(name, 0) + 1
             w.icount += 1
             if w.icount > self.max_instr:
                 raise SimError(f"wave {w.wid}: instruction budget exceeded (endless loop?) at {ins.text}")

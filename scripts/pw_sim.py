@@ -111,7 +111,8 @@ def simulate(B, T, grid=8, scale=0.3, seed=0, inc_text=None, nan_pad=False, stri
             w.a[:] = 0x7FC54321
         wg.run()
         stats.append({"bid": bid, "instr": [w.icount for w in wg.waves], "mfma": [w.counts.get("v_mfma_f32_32x32x16_bf16", 0) for w in wg.waves],
-                      "barriers": [w.counts.get("s_barrier", 0) for w in wg.waves], "hazards": wg.hazards})
+                      "barriers": [w.counts.get("s_barrier", 0) for w in wg.waves], "hazards": wg.hazards,
+                      "labels": {k: v for k, v in wg.label_hits.items() if "cold" in k or "ksfirst" in k or k.endswith("_item")}})
         if verbose:
             print(f"  wg {bid}: instr {stats[-1]['instr']} mfma {stats[-1]['mfma']} barriers {stats[-1]['barriers'][0]} ({time.time() - t0:.1f} s)", flush=True)
     # decode + reference
@@ -161,9 +162,13 @@ def main():
     per_block = err.reshape(B, -1).max(axis=1)
     print(f"B={B} T={T} grid={grid}: max |ctx - ref| = {err.max():.4f} (per sequence {np.round(per_block, 4).tolist()}), "
           f"finite={r['finite']} pad rows zero={r['pad_zero']}  [{time.time() - t0:.1f} s]")
+    hits = {}
     for s in r["stats"]:
         for h in s["hazards"]:
             print("HAZARD", s["bid"], h)
+        for k, v in s["labels"].items():
+            hits[k] = hits.get(k, 0) + v
+    print("  label hits (waves):", dict(sorted(hits.items())))
     QB = (T + 31) // 32
     worst = err.max(axis=2).reshape(B, T)
     for b in range(B):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""attention-stage time of one libsavad variant at [B, T] bf16, row_mode 5: pw_time.py <lib.so> B T"""
+"""attention-stage time of one libsavad variant at [B, T] bf16: pw_time.py <lib.so> B T [row_mode (0 = automatic, default 5)] [N]"""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["SAVAD_LIB"] = os.path.abspath(sys.argv[1])
 import torch
 from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, seeded_features
@@ -9,7 +9,13 @@ B, T = int(sys.argv[2]), int(sys.argv[3])
 m = SelfAttentiveVAD(80, 3, 128, 0.5)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()})
 m = m.cuda().eval(); m.precision = "bf16"; m.row_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+N = int(sys.argv[5]) if len(sys.argv) > 5 else 0   # N > 0: only N plain forwards (counter passes serialise every dispatch)
 x = torch.from_numpy(seeded_features(1, (B, T, 80))).cuda().to(torch.bfloat16)
+if N:
+    with torch.no_grad():
+        for _ in range(N): m(x)
+    torch.cuda.synchronize()
+    sys.exit(0)
 with torch.no_grad():
     for _ in range(30): m(x)
     torch.cuda.synchronize()

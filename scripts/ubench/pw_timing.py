@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """phase stamps of the persistent bf16 attention kernel (wave 0 of workgroup 0): pw_timing.py B T"""
 import ctypes, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["SAVAD_LIB"] = os.path.abspath(sys.argv[4] if len(sys.argv) > 4 else "scripts/ubench/libsavad_timing.so")
 import torch
 from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, seeded_features, _lib
@@ -19,7 +19,7 @@ lib.savad_debug_stamps(buf, 16)
 w = []
 for v in buf: w += [v & 0xffffffff, (v >> 32) & 0xffffffff]
 names = {0: "epilogue end -> item start (incl. kernel prologue)", 24: "  cursor advance", 25: "  next item's parameters", 26: "  wait for the staged Q", 27: "  Q -> AGPRs", 28: "  K(0) reads, init, LDS wait", 29: "  S(0) MFMAs + O zeroing", 1: "  first reference (out-of-line call)", 2: "barrier", 3: "vmcnt(8) wait",
-         4: "even step", 5: "odd step", 23: "DMA advance", 6: "last step of an item", 20: "tail item: even step", 21: "tail item: odd step", 22: "tail item: last step", 8: "item epilogue", 9: "idle stages", 10: "tail", 11: "stage dispatch"}
+         4: "even step", 5: "odd step", 23: "DMA advance", 6: "last step of an item", 22: "key-split item: prologue", 20: "key-split item: the wave's tiles", 21: "key-split item: combine", 8: "item epilogue", 9: "idle stages", 10: "tail", 11: "stage dispatch"}
 tot = sum(w[c] for c in names)
 cyc, rt = (w[17] - w[16]) & 0xffffffff, (w[19] - w[18]) & 0xffffffff
 print(f"wave 0 of WG 0: {cyc} shader cycles in {rt / 100.0:.1f} us -> {cyc / max(rt, 1) * 100:.0f} MHz")

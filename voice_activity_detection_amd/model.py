@@ -79,6 +79,13 @@ class SelfAttentiveVAD(nn.Module):
         self._handle_device: Optional[torch.device] = None
         self._synced_versions = None
         self._workspace: Optional[Tensor] = None
+        self._param_dicts = None      # the `_parameters` dicts of the leaf modules, collected once (the module tree is fixed)
+        self._pushed_knobs = None     # (attention_splits, row_mode, precision) the handle was last told
+        self._ws_bytes = {}           # (B, T, knobs) -> savad_workspace_bytes
+        # bumped whenever the caller declares the weights changed behind autograd's back (sync_weights(force=True), a mode switch):
+        # PipelinedVAD's replicas share the parameters but keep their own handles, and re-push when they see a new generation
+        self._weights_generation = 0
+        self._seen_generation = 0
         self.attention_splits = 0  # 0 = automatic
         self.row_mode = 0  # 0 = automatic, 1 = N-split 32-row tiles, 2 / 3 = M-split 128-row tiles, 4 = T <= 32 in one launch (include/savad.h)
         # "fp32": exact-fp32 MFMA (default, log-probs within 1e-4 of the reference).
@@ -97,12 +104,14 @@ class SelfAttentiveVAD(nn.Module):
             _lib.check(lib.savad_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._handle, self._handle_device = h, device
         self._synced_versions = None
+        self._pushed_knobs = None
 
     def _release(self):
         if self._handle is not None:
             _lib.load().savad_destroy(self._handle)
             self._handle = None
             self._synced_versions = None
+            self._pushed_knobs = None
 
     def __del__(self):
         try:
@@ -113,7 +122,7 @@ class SelfAttentiveVAD(nn.Module):
     # The library handle, its device and the cached workspace are per-process runtime state: copies and pickles of
     # the module (copy.copy, copy.deepcopy, torch.save(model)) drop them and recreate them lazily -- a copy never
     # shares (and so never double-frees) the original's native handle.
-    _RUNTIME_ATTRS = ("_handle", "_handle_device", "_synced_versions", "_workspace")
+    _RUNTIME_ATTRS = ("_handle", "_handle_device", "_synced_versions", "_workspace", "_param_dicts", "_pushed_knobs")
 
     def __copy__(self):
         # explicit, so that a shallow copy never depends on which pickling protocol copy.copy() happens to use
@@ -121,6 +130,7 @@ class SelfAttentiveVAD(nn.Module):
         new.__dict__.update(self.__dict__)
         for name in self._RUNTIME_ATTRS:
             new.__dict__[name] = None
+        new.__dict__["_ws_bytes"] = {}
         return new
 
     def _replicate_for_data_parallel(self):
@@ -136,12 +146,16 @@ class SelfAttentiveVAD(nn.Module):
         state = dict(self.__dict__)
         for name in self._RUNTIME_ATTRS:
             state[name] = None
+        state["_ws_bytes"] = {}
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
         for name in self._RUNTIME_ATTRS:
             self.__dict__.setdefault(name, None)
+        self.__dict__.setdefault("_ws_bytes", {})
+        self.__dict__.setdefault("_weights_generation", 0)
+        self.__dict__.setdefault("_seen_generation", 0)
 
     def train(self, mode: bool = True):
         # SWITCHING modes is where parameters were most likely edited behind autograd's back (p.data.copy_ in EMA /
@@ -150,17 +164,45 @@ class SelfAttentiveVAD(nn.Module):
         # plus the fold / pack kernels, ~0.4 ms against a 0.09 ms forward.
         if bool(mode) != self.training:
             self._synced_versions = None
+            self._weights_generation += 1
         return super().train(mode)  # always: children must follow the parent's mode even when it did not change
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() ...: storage moves without a version bump -- re-push (here and in a pipeline's replicas)
+        self._synced_versions = None
+        self._weights_generation += 1
+        return super()._apply(fn, *args, **kwargs)
+
     def _param_versions(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """(identity, _version) of every parameter, read from the leaf modules' own `_parameters` dicts: a replaced Parameter
+        object is seen as well as an in-place update (storage moves are announced by _apply), and the walk costs ~8 us where
+        (data_ptr, _version) over `self.parameters()` cost ~130 (scripts/ubench/host_overhead.py) -- this runs on every forward."""
+        dicts = self._param_dicts
+        if dicts is None:
+            dicts = self._param_dicts = [m._parameters for m in self.modules() if m._parameters]
+        ps = [p for d in dicts for p in d.values()]
+        return tuple(map(id, ps)), [p._version for p in ps]
 
     def sync_weights(self, force: bool = False):
         """Push the module's parameters into the library's packed weight store when they changed.  Changes are detected
-        through (data_ptr, _version): load_state_dict, .to(), optimizer steps and in-place tensor ops are all caught.
+        through object identity + _version (+ the module's own _apply): load_state_dict, .to(), optimizer steps, in-place
+        tensor ops and replaced Parameter objects are all caught.
         NOT caught: writes through `.data` / `.detach()` views (p.data.mul_(...), p.data.copy_(...)), which bump neither --
         call `model.sync_weights(force=True)` after such edits (a `.train()` / `.eval()` that switches the mode also forces a re-push).
         One module instance = one library handle + one cached workspace: use it from one stream at a time."""
+        if force:
+            self._weights_generation += 1
+        if self._seen_generation != self._weights_generation:   # (a replica of a PipelinedVAD sees the base module's counter)
+            self._seen_generation = self._weights_generation
+            self._synced_versions = None
+        if self._handle is None:   # a forced re-push on a module that has not run yet (its replicas may have): nothing to push to yet
+            if force:
+                pdev = self.classifier.weight.device
+                if pdev.type != "cuda":
+                    return
+                self._ensure_handle(pdev)
+            else:
+                return
         versions = self._param_versions()
         if not force and versions == self._synced_versions:
             return
@@ -193,14 +235,31 @@ class SelfAttentiveVAD(nn.Module):
         lib = _lib.load()
         self._ensure_handle(device)
         self.sync_weights()
-        _lib.check(lib.savad_set_attention_splits(self._handle, int(self.attention_splits)))
-        _lib.check(lib.savad_set_row_mode(self._handle, int(self.row_mode)))
-        _lib.check(lib.savad_set_precision(self._handle, 1 if self.precision == "bf16" else 0))
+        knobs = (int(self.attention_splits), int(self.row_mode), self.precision)
+        if knobs != self._pushed_knobs:   # three library calls only when a knob moved, none on the steady path
+            _lib.check(lib.savad_set_attention_splits(self._handle, knobs[0]))
+            _lib.check(lib.savad_set_row_mode(self._handle, knobs[1]))
+            _lib.check(lib.savad_set_precision(self._handle, 1 if knobs[2] == "bf16" else 0))
+            self._pushed_knobs = knobs
         return lib
+
+    def _workspace_bytes(self, lib, B: int, T: int) -> int:
+        key = (B, T, self._pushed_knobs)
+        n = self._ws_bytes.get(key)
+        if n is None:
+            nbytes = ctypes.c_size_t()
+            _lib.check(lib.savad_workspace_bytes(self._handle, B, T, ctypes.byref(nbytes)))
+            if len(self._ws_bytes) > 256:
+                self._ws_bytes.clear()
+            n = self._ws_bytes[key] = nbytes.value
+        return n
 
     def _workspace_for(self, nbytes: int, device: torch.device) -> Tensor:
         ws = self._workspace
         if ws is None or ws.device != device or ws.numel() < nbytes:
+            if ws is not None and ws.device == device:
+                # forwards enqueued on this stream may still read the old block: the allocator must not hand it to another stream first
+                ws.record_stream(torch.cuda.current_stream(device))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)  # caching allocator owns it
             self._workspace = ws
         return ws
@@ -227,16 +286,20 @@ class SelfAttentiveVAD(nn.Module):
             raise ValueError(f"out must be a contiguous float32 [{B}, {T}, 2] tensor on {device}")
         if B == 0 or T == 0:
             return out
-        with torch.cuda.device(device):
-            lib = self._prepare_call(device)
-            nbytes = ctypes.c_size_t()
-            _lib.check(lib.savad_workspace_bytes(self._handle, B, T, ctypes.byref(nbytes)))
-            ws = self._workspace_for(nbytes.value, device)
-            stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(lib.savad_forward_ex(self._handle, ctypes.c_void_p(x.data_ptr()), x_dtype, B, T,
-                                            ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                                            ws.numel(), ctypes.c_void_p(stream)))
+        if torch.cuda.current_device() == device.index:   # (the context manager costs ~10 us; it is only needed to switch devices)
+            self._launch_forward(x, x_dtype, B, T, out, device)
+        else:
+            with torch.cuda.device(device):
+                self._launch_forward(x, x_dtype, B, T, out, device)
         return out
+
+    def _launch_forward(self, x: Tensor, x_dtype: int, B: int, T: int, out: Tensor, device: torch.device) -> None:
+        lib = self._prepare_call(device)
+        ws = self._workspace_for(self._workspace_bytes(lib, B, T), device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(lib.savad_forward_ex(self._handle, ctypes.c_void_p(x.data_ptr()), x_dtype, B, T,
+                                        ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                        ws.numel(), ctypes.c_void_p(stream)))
 
     @torch.no_grad()
     def predict_windows(self, feature: Tensor, half: int, jump: int, chunk: int):

@@ -43,6 +43,7 @@ class PipelinedVAD:
         self._next = 0
         self._busy: List[bool] = [False] * self.depth
         self.active = self.depth   # forwards kept in flight (<= depth): set_active() lets a caller tune it for its shape
+        self.last_replica = 0      # index of the replica / stream the latest submit() used (0 when it ran on the caller's stream)
 
     def set_active(self, n: int) -> None:
         """use only the first n replicas from now on (1 <= n <= depth); call it with nothing in flight"""
@@ -64,14 +65,14 @@ class PipelinedVAD:
             return self.model(features=features, out=out)  # raises the module's own "no CPU fallback" error
         if self.active == 1:   # nothing to overlap: the plain module on the caller's stream (after whatever is still in flight)
             self.join()
+            self.last_replica = 0
             return self.model(features=features, out=out)
         streams = self._ensure_streams(device)
         k = self._next
         self._next = (k + 1) % self.active
+        self.last_replica = k
         rep, s = self._replicas[k], streams[k]
-        for name in _KNOBS:  # knobs set on the base module after construction apply to every replica
-            if getattr(rep, name) != getattr(self.model, name):
-                setattr(rep, name, getattr(self.model, name))
+        self._follow(rep)
         s.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(s):
             y = rep(features=features, out=out)
@@ -80,6 +81,22 @@ class PipelinedVAD:
         y.record_stream(s)
         self._busy[k] = True
         return y
+
+    def _follow(self, rep: SelfAttentiveVAD) -> None:
+        """knobs set on the base module after construction apply to every replica, and so does a declared weight change
+        (model.sync_weights(force=True), a .train() / .eval() switch, .to()): the replica re-pushes at its next forward"""
+        base = self.model
+        if rep is base:
+            return
+        for name in _KNOBS:
+            if getattr(rep, name) != getattr(base, name):
+                setattr(rep, name, getattr(base, name))
+        rep._weights_generation = base._weights_generation
+
+    def wait_for_replica(self, k: int) -> None:
+        """the current stream waits for everything submitted to replica k so far"""
+        if self._streams is not None and self.active > 1:
+            torch.cuda.current_stream(self._streams[k].device).wait_stream(self._streams[k])
 
     def join(self) -> None:
         """the current stream waits for every forward submitted so far"""
@@ -100,7 +117,16 @@ class PipelinedVAD:
 
     def reserve(self, max_frames: int, device=None, max_batch: int = 0) -> None:
         """``SelfAttentiveVAD.reserve`` on every replica (handles, folded weights, positional-encoding tables, workspaces)"""
-        for rep in self._replicas:
-            for name in _KNOBS:
-                setattr(rep, name, getattr(self.model, name))
-            rep.reserve(max_frames, device=device, max_batch=max_batch)
+        dev = torch.device(device) if device is not None else self.model.classifier.weight.device
+        streams = self._ensure_streams(dev) if (dev.type == "cuda" and self.depth > 1) else None
+        for k, rep in enumerate(self._replicas):
+            self._follow(rep)
+            if streams is None:
+                rep.reserve(max_frames, device=device, max_batch=max_batch)
+                continue
+            # on the replica's OWN stream: the workspace it caches here is the one its forwards use there (a block allocated on the
+            # caller's stream could be handed out again while a side-stream forward still reads it)
+            streams[k].wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(streams[k]):
+                rep.reserve(max_frames, device=device, max_batch=max_batch)
+            torch.cuda.current_stream(dev).wait_stream(streams[k])
