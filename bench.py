@@ -131,6 +131,17 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     return None
 
 
+def traffic_note(name, precision, B, T):
+    """what the measured HBM-side bytes of the dominant kernel are made of, where they are far from the algorithmic ones"""
+    if name == "packed_forward":
+        return ("the whole forward in one launch reads x and writes the log-probs (algorithmic) -- and every one of the 8 XCD L2s fetches the "
+                "2.4 MB of packed weights once: 8 x 2.4 MB + x is the measured figure, 0.3 % of the HBM roof at this launch's duration; benign")
+    if name == "attention_bf16" and (B, T) == (256, 800):
+        return ("persistent kernel: q and ctx once, K / V^T once for a sequence's three full groups that run side by side in one XCD's L2, once more "
+                "for the key-split tail item + the full group behind it, which run 0.55 item-times later than their siblings (DESIGN section 4b-3)")
+    return None
+
+
 def gpu_state():
     """sclk / mclk / power / power cap of this rank's GPU from rocm-smi (None when rocm-smi is missing or slow): recorded
     at the start and the end of every leg, so that a box-to-box or leg-to-leg clock difference is visible in the line."""
@@ -244,168 +255,202 @@ def cpu_baseline(state, B: int, T: int, seconds: float):
     }
 
 
+def stub_forward(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """--stub-forward: a stand-in with the forward's signature and output shape (log-softmax over the first two features) for
+    CPU dry runs of this file's control flow under gloo (tests/test_dist_gloo.py).  Nothing measured with it is a result."""
+    out.copy_(torch.log_softmax(x[..., :2].float(), dim=-1))
+    return out
+
+
+class Clock:
+    """HIP events on the current stream when there is a GPU, the host clock in a --stub-forward dry run"""
+
+    def __init__(self, cuda: bool):
+        self.cuda = cuda
+
+    def sync(self):
+        if self.cuda:
+            torch.cuda.synchronize()
+
+    def pair(self):
+        return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if self.cuda else [0.0, 0.0]
+
+    def mark(self, pair, i):
+        if self.cuda:
+            pair[i].record()
+        else:
+            pair[i] = time.perf_counter()
+
+    def seconds(self, pair):
+        return pair[0].elapsed_time(pair[1]) * 1e-3 if self.cuda else pair[1] - pair[0]
+
+
 class Runner:
-    """One workload on this rank: model + resident input + the step function (forward, optionally followed by the
-    per-call all_gather of forward_sharded)."""
+    """One workload on this rank: model + resident input, driven through voice_activity_detection_amd.distributed.ShardedPipeline
+    (rank-local forwards in flight + the RCCL gather of their log-probs; without a process group: the plain pipeline).  Every
+    collective of a run is issued by that module -- this file only decides when."""
 
-    def __init__(self, state, B, T, precision, dev, rank, world, dist, gather, row_mode=0, splits=0, in_flight=0):
-        from voice_activity_detection_amd import PipelinedVAD, SelfAttentiveVAD
+    def __init__(self, state, B, T, precision, dev, rank, world, gather, slots, row_mode=0, splits=0, in_flight=0, stub=False):
+        from voice_activity_detection_amd import distributed as vdist
 
-        self.B, self.T, self.precision, self.dev, self.world, self.rank, self.dist, self.gather = B, T, precision, dev, world, rank, dist, gather
-        model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
-        self.model = model.to(dev).eval()
-        self.model.attention_splits, self.model.row_mode, self.model.precision = splits, row_mode, precision
+        self.vdist = vdist
+        self.B, self.T, self.precision, self.dev, self.world, self.rank = B, T, precision, dev, world, rank
+        self.clock = Clock(dev.type == "cuda")
+        self.stub = stub
         # each rank gets its own shard of the global batch (weak scaling: B per GPU fixed)
         x = torch.from_numpy(np.random.default_rng(rank).uniform(-13.8, 4.2, (B, T, F_MEL)).astype(np.float32)).to(dev)
-        self.x = x.to(torch.bfloat16) if precision == "bf16" else x
-        self.model.reserve(T)
-        self.gathered = torch.empty((world, B, T, 2), dtype=torch.float32, device=dev) if dist else None
-        self.keep = None
-        # consecutive batches are independent: up to 3 forwards in flight (own stream / handle / workspace each,
-        # voice_activity_detection_amd/pipeline.py); in_flight = 0 picks the fastest of 1 / 2 / 3 for this shape during warm-up
+        self.x = x.to(torch.bfloat16) if (precision == "bf16" and not stub) else x
         self.in_flight_request = in_flight
-        self.pipe = PipelinedVAD(self.model, depth=max(in_flight, 1) if in_flight else 3)
-        self.pipe.reserve(T)
-        self.outs = [torch.empty((B, T, 2), dtype=torch.float32, device=dev) for _ in range(self.pipe.depth + 1)]
-        self.submitted = 0
-        self.tuning = None
+        if stub:
+            self.model = None
+            self.sp = vdist.ShardedPipeline(forward=stub_forward, slots=slots, depth=max(in_flight, 1) if in_flight else 3, gather=gather)
+        else:
+            from voice_activity_detection_amd import SelfAttentiveVAD
 
-    def set_gather(self, gather, n_keep):
-        """'step': one all_gather per forward (what forward_sharded does).  'final': every forward writes straight
-        into its slot of a [K,B,T,2] send buffer and ONE all_gather of all K batches closes the block."""
-        self.gather, self.done = gather, 0
-        if self.dist and gather == "final":
-            self.keep = torch.empty((n_keep, self.B, self.T, 2), dtype=torch.float32, device=self.dev)
-            self.keep_all = torch.empty((self.world, n_keep, self.B, self.T, 2), dtype=torch.float32, device=self.dev)
+            model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+            self.model = model.to(dev).eval()
+            self.model.attention_splits, self.model.row_mode, self.model.precision = splits, row_mode, precision
+            self.model.reserve(T)
+            # consecutive batches are independent: up to 3 forwards in flight (own stream / handle / workspace each,
+            # voice_activity_detection_amd/pipeline.py); in_flight = 0 picks the fastest of 1 / 2 / 3 for this shape during warm-up
+            self.sp = vdist.ShardedPipeline(self.model, slots=slots, depth=max(in_flight, 1) if in_flight else 3, gather=gather)
+            self.sp.pipe.reserve(T)
+        self.dist = self.sp.distributed
+        self.tuning = None
+        self.last = None
+
+    def set_gather(self, gather):
+        """'step': one all_gather of [B,T,2] per forward; 'final': every forward writes straight into its slot of a [K,B,T,2]
+        send buffer and ONE all_gather of all K batches closes the block (both: ShardedPipeline)"""
+        self.drain()
+        self.sp.set_gather(gather)
 
     def step(self):
-        with torch.no_grad():
-            if self.dist and self.gather == "final":
-                y = self.pipe.submit(self.x, out=self.keep[self.done % self.keep.shape[0]])
-                self.done += 1
-            elif self.dist:  # one all_gather per forward: the gather orders the forwards, nothing to keep in flight
-                y = self.model(features=self.x)
-                self.dist.all_gather_into_tensor(self.gathered, y)
-            else:
-                y = self.pipe.submit(self.x, out=self.outs[self.submitted % len(self.outs)])
-                self.submitted += 1
-        return y
+        if self.sp._n >= self.sp.slots:   # warm-up loops run longer than one block
+            self.drain()
+        self.sp.submit(self.x)
 
     def drain(self):
-        self.pipe.join()
-        if self.dist and self.gather == "final" and self.done:
-            self.dist.all_gather_into_tensor(self.keep_all, self.keep)
-            self.done = 0
+        outs = self.sp.join()
+        if outs:
+            self.last = outs[-1]           # [world, B, T, 2]
 
     def tune_in_flight(self, steps=0):
         """pick the number of forwards in flight for this shape: time `steps` steps at 1, 2, 3 (untimed warm-up work) and keep the
-        fastest; a fixed --in-flight N skips it.  Every rank tunes on its own clock: nothing in a step is collective here."""
-        if self.in_flight_request or (self.dist and self.gather == "step"):
-            self.pipe.set_active(self.pipe.depth if not (self.dist and self.gather == "step") else 1)
-            if self.in_flight_request:
-                self.tuning = {"fixed": self.in_flight_request}
+        fastest; a fixed --in-flight N skips it.  One decision per job (rank 0's clock): every rank must issue the same collectives."""
+        depth = self.sp.depth
+        if self.in_flight_request or depth == 1:
+            self.drain()
+            self.sp.set_in_flight(depth)
+            self.tuning = {"fixed": self.in_flight_request or 1}
             return
         res = {}
-        for d in range(1, self.pipe.depth + 1):
-            self.pipe.set_active(d)
+        for d in range(1, depth + 1):
+            self.drain()
+            self.sp.set_in_flight(d)
+            n = int(self.vdist.agree(steps or 40, self.dev))
+            for _ in range(10):
+                self.step()
+            self.drain()
+            self.clock.sync()
             t0 = time.perf_counter()
             for _ in range(10):
                 self.step()
-            self.pipe.join()
-            torch.cuda.synchronize()
-            if not steps:  # ~60 ms per candidate, at least 40 steps
-                steps = max(40, int(0.06 / max((time.perf_counter() - t0) / 10, 1e-6)))
-            for _ in range(10):
-                self.step()
-            self.pipe.join()
-            torch.cuda.synchronize()
+            self.drain()
+            self.clock.sync()
+            if not steps:  # ~60 ms per candidate, at least 40 steps -- the same count on every rank
+                n = int(self.vdist.agree(max(40, int(0.06 / max((time.perf_counter() - t0) / 10, 1e-6))), self.dev))
             t0 = time.perf_counter()
-            for _ in range(steps):
+            for _ in range(n):
                 self.step()
-            self.pipe.join()
-            torch.cuda.synchronize()
-            res[d] = (time.perf_counter() - t0) / steps * 1e3
-        self.done = 0
-        best = min(res, key=res.get)
-        if self.dist:  # one decision for the job (rank 0's): later code paths that contain collectives depend on it
-            flag = torch.tensor([best], dtype=torch.int64, device=self.dev)
-            self.dist.broadcast(flag, 0)
-            best = int(flag.item())
-        self.pipe.set_active(best)
+            self.drain()
+            self.clock.sync()
+            res[d] = (time.perf_counter() - t0) / n * 1e3
+        best = int(self.vdist.agree(min(res, key=res.get), self.dev))
+        self.drain()
+        self.sp.set_in_flight(best)
         self.tuning = {str(k): round(v, 4) for k, v in res.items()}
 
     def timed_blocks(self, steps, warmup, min_seconds, max_blocks=400):
-        """-> (per-block wall seconds [max over ranks], per-block HIP-event seconds on this rank, last output)"""
-        dist, dev = self.dist, self.dev
+        """-> (per-block wall seconds [max over ranks], per-block HIP-event seconds on this rank)"""
+        vdist, clock = self.vdist, self.clock
         t0 = time.perf_counter()
         n = 0
         # at least W steps and at least ~0.2 s of them (the clocks ramp for the first ~100 ms of load); with a process
         # group every rank must issue the same number of collectives, so the count is fixed there instead of timed
-        while n < max(warmup, 1) or (n < 10000 and ((not dist and time.perf_counter() - t0 < 0.2) or (dist and n < 40))):
-            y = self.step()
+        while n < max(warmup, 1) or (n < 10000 and ((not self.dist and not self.stub and time.perf_counter() - t0 < 0.2) or (self.dist and n < 40))):
+            self.step()
             n += 1
             if n % 8 == 0:
-                torch.cuda.synchronize()
+                clock.sync()
         self.drain()
-        torch.cuda.synchronize()
+        clock.sync()
         if self.tuning is None:
             self.tune_in_flight()
             self.drain()
-            torch.cuda.synchronize()
+            clock.sync()
         walls, evs = [], []
         total = 0.0
         while len(walls) < 5 or (total < min_seconds and len(walls) < max_blocks):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            if dist:
-                dist.barrier()
-            torch.cuda.synchronize()
+            ev = clock.pair()
+            vdist.barrier()
+            clock.sync()
             t0 = time.perf_counter()
-            e0.record()
+            clock.mark(ev, 0)
             for _ in range(steps):
-                y = self.step()
+                self.step()
             self.drain()
-            e1.record()
-            torch.cuda.synchronize()
+            clock.mark(ev, 1)
+            clock.sync()
             dt = time.perf_counter() - t0
-            if dist:
-                dist.barrier()
+            vdist.barrier()
             walls.append(dt)
-            evs.append(e0.elapsed_time(e1) * 1e-3)
-            total += dt
-            if dist:  # every rank must take the same number of blocks: decide on rank 0's clock
-                flag = torch.tensor([total], dtype=torch.float64, device=dev)
-                dist.broadcast(flag, 0)
-                total = float(flag.item())
-        if dist:
-            t = torch.tensor(walls, dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            walls = [float(v) for v in t.tolist()]
-        return walls, evs, y
+            evs.append(clock.seconds(ev))
+            total = vdist.agree(total + dt, self.dev)   # every rank must take the same number of blocks: rank 0's clock decides
+        return vdist.max_over_ranks(walls, self.dev), evs
+
+    def delivered(self):
+        """the last gathered batch is finite and holds, in this rank's slot, exactly what a forward of this rank's shard gives"""
+        if self.last is None:
+            return False
+        y = torch.empty((self.B, self.T, 2), dtype=torch.float32, device=self.dev)
+        with torch.no_grad():
+            if self.stub:
+                stub_forward(self.x, y)
+            else:
+                self.model(features=self.x, out=y)
+        self.clock.sync()
+        return bool(torch.isfinite(self.last).all().item()) and bool(torch.equal(self.last[self.rank], y))
 
     def kernel_profile(self, steps, ms_hint=None):
         """the same K steps with every kernel bracketed by HIP events on the launch stream -> [(label, ms)]"""
+        if self.stub:
+            return []
         # creating the events idles the GPU; the first ~15 ms of kernels afterwards run at lower clocks (230 -> 207 us per
         # fused launch, seen in the rocprofv3 trace): ~0.15 s of un-recorded forwards first
         settle = max(steps, int(0.15 / (ms_hint * 1e-3))) if ms_hint else 200
         self.drain()
         torch.cuda.synchronize()
+        out = torch.empty((self.B, self.T, 2), dtype=torch.float32, device=self.dev)
         self.model.set_profiling(steps, skip=settle)
         with torch.no_grad():
             for _ in range(settle + steps):   # ONE forward in flight: a launch's duration is the kernel's own
-                self.model(features=self.x, out=self.outs[0])
+                self.model(features=self.x, out=out)
         torch.cuda.synchronize()
         kt = self.model.kernel_times()
         self.model.set_profiling(0)
         return kt
 
 
-def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False):
+def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False, ms_one_forward=None):
     peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
     e = 2 if precision == "bf16" else 4
     fwd_tflops = flops_per_frame(T) * B * T / (ms_forward * 1e-3) / 1e12
+    one_tflops = flops_per_frame(T) * B * T / ((ms_one_forward or ms_forward) * 1e-3) / 1e12
     if not ktimes:
-        return {"bound": "mfma", "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / peak, 4), "peak": peak, "unit": "TFLOP/s"}
+        return {"bound": "mfma", "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / peak, 4),
+                "forward_frac_one_forward": round(one_tflops / peak, 4), "peak": peak, "unit": "TFLOP/s"}
     by_name = {}
     for n, t in ktimes:
         by_name.setdefault(n, []).append(t)
@@ -432,6 +477,7 @@ def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False):
         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
         "traffic": measured_traffic(dom, precision, B, T),
         "traffic_unit": "bytes/launch (rocprofv3 PMC pass under profiles/, quoted only when its csrc_hash matches the running kernels)",
+        "traffic_note": traffic_note(dom, precision, B, T),
         "algorithmic_bytes": dom_bytes, "algorithmic_flops": dom_flops,
         # the same launch against the HBM roofline: the non-binding one in fp32 -- the fp32 MFMA
         # rate caps the attention stage at 9.8 % of 8 TB/s
@@ -440,6 +486,8 @@ def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False):
         "ms_per_launch": round(dom_ms, 4),
         # whole forward: all launches' FLOPs over ms_per_step (the throughput figure: with several forwards in flight, theirs)
         "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / peak, 4),
+        # ... and over the wall time of ONE forward at a time (comparable with the per-kernel fractions; SURVEY section 8d's figure)
+        "forward_achieved_one_forward": round(one_tflops, 2), "forward_frac_one_forward": round(one_tflops / peak, 4),
         "per_kernel": per_kernel, "rocprof_reference": prof_file,
         "kernels_ms": {f"{i}:{n}": round(t, 4) for i, (n, t) in enumerate(ktimes)},
     }
@@ -628,10 +676,17 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="independent forwards kept in flight (own HIP stream / library handle / workspace each): 0 = pick the fastest "
                          "of 1, 2, 3 for the shape during warm-up (default), N = exactly N")
-    ap.add_argument("--gather", default="final", choices=["step", "final"],
-                    help="multi-GPU: which gather mode `value` is quoted on (both are always measured and printed): 'final' (default) = "
-                         "every forward writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block -- north_star's "
-                         "'a single RCCL gather over xGMI at the end'; 'step' = one all_gather per forward (forward_sharded)")
+    ap.add_argument("--gather", default="step", choices=["step", "final"],
+                    help="multi-GPU: which gather mode `value` is quoted on (both are always measured and printed): 'step' (default) = "
+                         "one all_gather of the [B,T,2] log-probs per forward, issued while the newer forwards run; 'final' = every forward "
+                         "writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block -- north_star's 'a single RCCL "
+                         "gather over xGMI at the end' (both: voice_activity_detection_amd.distributed.ShardedPipeline)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend: nccl (= RCCL, default); gloo only together with --stub-forward")
+    ap.add_argument("--stub-forward", action="store_true",
+                    help="CPU dry run of this file's control flow (no GPU, no library): a stand-in forward; the line it prints is marked "
+                         "and carries no measurement (tests/test_dist_gloo.py runs it with two gloo ranks)")
+    ap.add_argument("--config3-shape", default="256,800", help="per-rank [B,T] of the config3 leg (dry runs use a small one)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -641,55 +696,66 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
+    stub = args.stub_forward
+    if args.backend == "gloo" and not stub:
+        sys.exit("--backend gloo is for --stub-forward dry runs: the product runs on HIP devices over RCCL")
+    if stub:
+        dev = torch.device("cpu")
+        torch.set_num_threads(1)
+    else:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a HIP device")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("SAVAD_BENCH_FORCE_DIST") == "1"  # the env var lets a 1-GPU box exercise RCCL
     if use_dist:
-        import torch.distributed as dist  # RCCL ("nccl" backend on ROCm)
+        import torch.distributed as dist  # "nccl" = RCCL on ROCm
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from voice_activity_detection_amd import distributed as vdist
     from voice_activity_detection_amd import seeded_state_dict
 
     B, T, K = args.batch, args.frames, args.steps
-    state = seeded_state_dict(1234)
-    main_run = Runner(state, B, T, args.precision, dev, rank, world, dist, args.gather, args.row_mode, args.splits, args.in_flight)
+    state = None if stub else seeded_state_dict(1234)
+    main_run = Runner(state, B, T, args.precision, dev, rank, world, args.gather, K, args.row_mode, args.splits, args.in_flight, stub)
     frames_per_step = world * B * T
 
     # ---- the headline measurement
-    clocks0 = gpu_state()
-    main_run.set_gather(args.gather, K)
-    walls, evs, y = main_run.timed_blocks(K, args.warmup, args.min_seconds)
+    clocks0 = None if stub else gpu_state()
+    walls, evs = main_run.timed_blocks(K, args.warmup, args.min_seconds)
     head = summarize(walls, evs, K, frames_per_step)
-    ok = bool(torch.isfinite(y).all().item())
+    ok = main_run.delivered()
     gather_modes = None
-    if use_dist:  # the collective really delivered this rank's shard; and the OTHER gather mode, for comparison
-        got = main_run.gathered[rank] if args.gather == "step" else main_run.keep_all[rank, (K - 1) % K]
-        ok = ok and bool(torch.equal(got, y))
+    if use_dist:  # the OTHER gather mode, for comparison
         other = "final" if args.gather == "step" else "step"
-        main_run.set_gather(other, K)
-        w2, e2, _ = main_run.timed_blocks(K, 2, args.min_seconds / 2)
+        main_run.set_gather(other)
+        w2, e2 = main_run.timed_blocks(K, 2, args.min_seconds / 2)
         alt = summarize(w2, e2, K, frames_per_step)
+        ok = ok and main_run.delivered()
         gather_modes = {f"gather_{args.gather}_ms": head["ms_per_step"], f"gather_{other}_ms": alt["ms_per_step"],
                         f"gather_{other}_value": alt["value"],
-                        "note": "step = one RCCL all_gather of [B,T,2] log-probs per forward (forward_sharded, the product path); "
-                                "final = each forward writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block"}
-        main_run.set_gather(args.gather, K)
-    # the same K-step blocks with ONE forward in flight (what rounds 1-2 reported; the kernels' own durations are measured this way)
+                        "note": "step = one RCCL all_gather of [B,T,2] log-probs per forward, issued while the newer forwards run; final = each "
+                                "forward writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block "
+                                "(voice_activity_detection_amd.distributed.ShardedPipeline; `value` is quoted on gather_" + args.gather + ")"}
+        main_run.set_gather(args.gather)
+    # the same K-step blocks with ONE forward in flight (wall time of one forward; the kernels' own durations are measured this way)
     one = None
-    if main_run.pipe.active > 1:
-        tuned = main_run.pipe.active
-        main_run.pipe.set_active(1)
-        w1, e1, _ = main_run.timed_blocks(K, 2, args.min_seconds / 2)
+    if main_run.sp.in_flight > 1:
+        tuned = main_run.sp.in_flight
+        main_run.drain()
+        main_run.sp.set_in_flight(1)
+        w1, e1 = main_run.timed_blocks(K, 2, args.min_seconds / 2)
         one = summarize(w1, e1, K, frames_per_step)
-        main_run.pipe.set_active(tuned)
-    ktimes = [] if args.no_events else main_run.kernel_profile(min(K, 20), (one or head)["ms_per_step"])
-    clocks1 = gpu_state()
+        main_run.drain()
+        main_run.sp.set_in_flight(tuned)
+    ktimes = [] if (args.no_events or stub) else main_run.kernel_profile(min(K, 20), (one or head)["ms_per_step"])
+    clocks1 = None if stub else gpu_state()
 
     # ---- secondary legs, measured in the same run so that they are driver-witnessed
     secondary = {}
@@ -699,34 +765,46 @@ def main():
         """run one secondary leg; it must never take the headline line down with it"""
         if want is not None and key not in want:
             return
-        c0 = gpu_state()
+        c0 = None if stub else gpu_state()
         try:
             res = fn()
         except Exception as exc:
+            if use_dist:
+                raise   # a rank that skips collectives its peers still issue would hang the job: fail loudly instead
             res = {"error": f"{type(exc).__name__}: {exc}"}
-        res["clocks"] = {"start": c0, "end": gpu_state()}
+        res["clocks"] = {"start": c0, "end": None if stub else gpu_state()}
         secondary[key] = res
-        torch.cuda.empty_cache()
+        if not stub:
+            torch.cuda.empty_cache()
 
     def shape_leg(prec, b2, t2, gm):
         def run():
-            r = Runner(state, b2, t2, prec, dev, rank, world, dist, gm or "step", in_flight=args.in_flight)
-            r.set_gather(gm or "step", 20)
             k2 = 20 if t2 > 32 else 50
-            w, e, y2 = r.timed_blocks(k2, 5, args.min_seconds)
+            r = Runner(state, b2, t2, prec, dev, rank, world, gm or "step", k2, in_flight=args.in_flight, stub=stub)
+            w, e = r.timed_blocks(k2, 5, args.min_seconds)
             s = summarize(w, e, k2, world * b2 * t2)
-            kt = [] if args.no_events else r.kernel_profile(10, s["ms_per_step"])
+            s1 = s
+            if r.sp.in_flight > 1:   # and one forward at a time
+                tuned = r.sp.in_flight
+                r.drain()
+                r.sp.set_in_flight(1)
+                w1, e1 = r.timed_blocks(k2, 2, args.min_seconds / 2)
+                s1 = summarize(w1, e1, k2, world * b2 * t2)
+                r.drain()
+                r.sp.set_in_flight(tuned)
+            kt = [] if args.no_events else r.kernel_profile(10, s1["ms_per_step"])
             s.update({"workload": workload_label(prec, b2, t2), "global_batch": world * b2, "unit": "frames/s",
-                      "in_flight": r.pipe.active, "in_flight_tuning_ms": r.tuning,
-                      "finite": bool(torch.isfinite(y2).all().item()),
-                      "roofline": roofline_block(kt, prec, b2, t2, s["ms_per_step"], profiled_shape=True)})
+                      "in_flight": r.sp.in_flight, "in_flight_tuning_ms": r.tuning,
+                      "ms_per_step_one_in_flight": s1["ms_per_step"], "value_one_in_flight": s1["value"],
+                      "finite": r.delivered(),
+                      "roofline": roofline_block(kt, prec, b2, t2, s["ms_per_step"], profiled_shape=True, ms_one_forward=s1["ms_per_step"])})
             if gm:
                 s["parallelism"] = f"batch-shard x{world} + 1 RCCL all_gather of [{b2},{t2},2] f32 per forward"
             return s
         return run
 
     if not args.no_secondary:
-        if world == 1 and not use_dist:
+        if world == 1 and not use_dist and not stub:
             if (args.precision, B, T) != ("bf16", 256, 800):
                 leg("configs2_bf16_b256_t800", shape_leg("bf16", 256, 800, None))
             if (args.precision, B, T) != ("fp32", 1000, 7):
@@ -734,16 +812,28 @@ def main():
             leg("configs0_clip10s_audio_to_probabilities", lambda: clip_pipeline(state, dev, 10.0, args.min_seconds))
             leg("configs3_global_b2048_one_gpu", lambda: config3_global_one_gpu(state, dev, args.min_seconds))
             leg("configs4_stream_1h", lambda: stream_one_hour(state, dev, args.min_seconds))
-        else:
-            leg("config3", shape_leg("bf16", 256, 800, "step"))  # configs[3]: [256 x world, 800, 80] bf16, batch-sharded
+        elif use_dist:
+            b3, t3 = (int(v) for v in args.config3_shape.split(","))
+            leg("config3", shape_leg("bf16", b3, t3, "step"))  # configs[3]: [256 x world, 800, 80] bf16, batch-sharded
+
+    # every rank's collective counts (they must agree: a mismatch is a hang waiting to happen)
+    counts = vdist.collective_counts()
+    all_counts = [counts]
+    if use_dist:
+        all_counts = [None] * world
+        dist.all_gather_object(all_counts, counts)
 
     if rank == 0:
+        one_fwd = one or head
         line = {
             "metric": "audio frames/sec (whole node)", "value": head["value"], "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "ms_per_step_min": head["ms_per_step_min"], "ms_per_step_hip_events_median": head["ms_per_step_hip_events_median"],
+            # SURVEY section 8d's own definition (wall time of ONE forward at a time) beside the throughput figure `value`
+            "value_one_forward": one_fwd["value"], "ms_one_forward": one_fwd["ms_per_step"],
             "timing": {"statistic": "median over blocks of exactly K steps (barrier + synchronize on both sides of every block; max over ranks)",
-                       "blocks": head["blocks"], "timed_seconds": head["timed_seconds"]},
+                       "blocks": head["blocks"], "timed_seconds": head["timed_seconds"],
+                       "value_is": f"throughput with `in_flight` independent batches in flight; value_one_forward / ms_one_forward = one forward at a time"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate",
             "data": "synthetic (seeded U(-13.8,4.2) mel frames, seeded random-init weights)",
@@ -751,15 +841,20 @@ def main():
                        "parallelism": f"batch-shard x{world}" + ((" + 1 RCCL all_gather of the [B,T,2] log-probs per forward" if args.gather == "step"
                                                                    else " + 1 RCCL all_gather of all K batches' log-probs per block") if use_dist else "")},
             "finite": ok,
-            "in_flight": 1 if (use_dist and args.gather == "step") else main_run.pipe.active,
+            "in_flight": main_run.sp.in_flight,
             "in_flight_note": "consecutive batches are independent: `in_flight` forwards are kept in flight, each on its own HIP stream with its own "
                               "library handle and workspace (voice_activity_detection_amd.PipelinedVAD; same bits as one at a time); picked during "
-                              "warm-up from the ms per step in in_flight_tuning; roofline.per_kernel and roofline.frac are measured with ONE in flight",
+                              "warm-up from the ms per step in in_flight_tuning; roofline.per_kernel, roofline.frac and roofline.forward_frac_one_forward "
+                              "are measured with ONE in flight, roofline.forward_frac with `in_flight`",
             "in_flight_tuning_ms": main_run.tuning,
-            "ms_per_step_one_in_flight": (one or head)["ms_per_step"], "value_one_in_flight": (one or head)["value"],
-            "roofline": roofline_block(ktimes, args.precision, B, T, head["ms_per_step"], profiled_shape=True),
+            "ms_per_step_one_in_flight": one_fwd["ms_per_step"], "value_one_in_flight": one_fwd["value"],
+            "roofline": roofline_block(ktimes, args.precision, B, T, head["ms_per_step"], profiled_shape=True, ms_one_forward=one_fwd["ms_per_step"]),
             "clocks": {"start": clocks0, "end": clocks1},
+            "collective_counts": all_counts,
         }
+        if stub:
+            line.update({"stub_forward": True, "data": "STUB forward on the CPU (control-flow dry run): no number in this line is a measurement",
+                         "dtype": "none (stub)"})
         if gather_modes:
             line.update(gather_modes)
         for k, v in secondary.items():
@@ -768,12 +863,12 @@ def main():
         rest = {k: v for k, v in secondary.items() if k != "config3"}
         if rest:
             line["secondary"] = rest
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not stub:
             line["cpu_baseline"] = cpu_baseline(state, B, T, args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if use_dist:
-        dist.barrier()
+        vdist.barrier()
         dist.destroy_process_group()
 
 

@@ -123,3 +123,75 @@ def test_two_rank_streaming_shard_and_merge(tmp_path, n_frames):
         covered += [tuple(s) for s in np.load(tmp_path / f"span{r}.npy").reshape(-1, 2)]
     covered.sort()
     assert covered[0][0] == 0 and covered[-1][1] == W and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
+# ---- the multi-batch form: ShardedPipeline / forward_sharded_many ------------------------------------------------------------
+def _pipeline_worker(rank, world, port, batch, gather, depth, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import torch_port
+    from voice_activity_detection_amd.distributed import ShardedPipeline, collective_counts, forward_sharded_many
+    from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
+
+    state = {k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()}
+
+    def fwd(x, out):   # the CPU stand-in of model(features=x, out=out)
+        out.copy_(torch_port.forward(state, x))
+        return out
+
+    sp = ShardedPipeline(forward=fwd, slots=3, depth=depth, gather=gather)
+    batches = [torch.from_numpy(seeded_features(20 + i, (batch, 9, 80))) for i in range(5)]   # 5 batches through 3 slots: two joins
+    before = collective_counts()["all_gather"]
+    ys = forward_sharded_many(sp, batches)
+    n_gathers = collective_counts()["all_gather"] - before
+    np.save(os.path.join(out_dir, f"y{rank}.npy"), torch.stack(ys).numpy())
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), np.array([n_gathers]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch,gather,depth", [(6, "step", 1), (6, "final", 1), (5, "step", 3), (5, "final", 3), (1, "step", 2)])
+def test_two_rank_sharded_pipeline_matches_unsharded(tmp_path, batch, gather, depth):
+    """K batches per join through ShardedPipeline on two gloo ranks (even, ragged and single-row global batches; gathers lagging
+    behind the forwards as with several forwards in flight): every rank ends up with the unsharded results, after one all_gather
+    per forward ('step') or one per join ('final')."""
+    from oracle import torch_port
+    from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
+
+    world = 2
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), batch, gather, depth, str(tmp_path)), nprocs=world, join=True)
+    state = {k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()}
+    ref = np.stack([torch_port.forward(state, torch.from_numpy(seeded_features(20 + i, (batch, 9, 80)))).numpy() for i in range(5)])
+    for r in range(world):
+        y = np.load(tmp_path / f"y{r}.npy")
+        assert y.shape == ref.shape and np.abs(y - ref).max() < 1e-6
+        assert int(np.load(tmp_path / f"g{r}.npy")[0]) == (5 if gather == "step" else 2)
+
+
+def test_bench_runs_with_two_gloo_ranks(tmp_path):
+    """bench.py's N > 1 control flow end to end on the CPU: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+    --backend gloo --stub-forward` -- in-flight tuning agreed across the ranks, K-step blocks, both gather modes, the config3 leg,
+    ONE JSON line from rank 0, the same number of collectives on both ranks, a clean exit.  (The stand-in forward replaces the
+    library; everything between it and the JSON line is the code the driver's 8-GPU run executes.)"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(repo / "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-forward",
+           "--steps", "3", "--warmup", "1", "--min-seconds", "0.01", "--batch", "2", "--frames", "40", "--config3-shape", "3,24"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["stub_forward"] is True and d["finite"] is True
+    assert d["steps"] == 3 and d["config"]["global_batch"] == 4
+    assert "gather_step_ms" in d and "gather_final_ms" in d and "value_one_forward" in d
+    assert set(d["in_flight_tuning_ms"]) == {"1", "2", "3"}          # the tuning ran (and was agreed: both ranks went on)
+    assert d["config3"]["finite"] is True and d["config3"]["global_batch"] == 6
+    c0, c1 = d["collective_counts"]
+    assert c0 == c1 and c0["all_gather"] > 0 and c0["barrier"] > 0

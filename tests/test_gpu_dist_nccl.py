@@ -166,3 +166,34 @@ def test_config3_global_batch_on_one_gpu(torch_cuda, model, state1234, rccl):
     pick = [0, 255, 256, 1000, 1791, 2047]                  # first / last sequence of shards 0, 1, 3, 6, 7
     xin = xd[pick].float().cpu().numpy()                    # the oracle sees the same bf16-rounded features
     assert np.abs(yh[pick] - oracle.forward(state1234, xin)).max() < 2e-2  # BF16_TOL of tests/test_gpu_parity.py
+
+
+@pytest.mark.parametrize("gather", ["step", "final"])
+@pytest.mark.parametrize("precision,shape", [("fp32", (8, 200, 80)), ("bf16", (40, 264, 80)), ("fp32", (500, 7, 80))])
+def test_sharded_pipeline_through_rccl(torch_cuda, model, rccl, gather, precision, shape):
+    """ShardedPipeline (the multi-batch form of forward_sharded: K rank-local forwards in flight on their own streams, the RCCL
+    gather of their log-probs per forward -- lagging behind the newer forwards -- or once at join): the module's own bits for
+    every batch, in order, for several joins, with inputs produced right before submit and outputs read right after join."""
+    from voice_activity_detection_amd.distributed import ShardedPipeline, collective_counts
+
+    torch = torch_cuda
+    model.precision = precision
+    try:
+        sp = ShardedPipeline(model, slots=4, depth=3, gather=gather)
+        assert sp.world == 1 and sp.distributed
+        before = collective_counts()["all_gather"]
+        n = 0
+        for rnd in range(3):
+            xs = [torch.from_numpy(feats(100 * rnd + i, shape)).cuda() for i in range(4 if rnd < 2 else 2)]
+            for x in xs:
+                sp.submit(x * 1.0)             # a temporary: the pipeline must keep it alive
+            outs = [o.clone() for o in sp.join()]
+            n += len(xs)
+            with torch.no_grad():
+                for x, o in zip(xs, outs):
+                    assert tuple(o.shape) == (1, shape[0], shape[1], 2)
+                    assert torch.equal(o[0], model(features=x))
+        got = collective_counts()["all_gather"] - before
+        assert got == (n if gather == "step" else 3)
+    finally:
+        model.precision = "fp32"

@@ -140,7 +140,8 @@ class ShardedPipeline:
         self.gather, self.group, self.slots = gather, group, int(slots)
         self._forward = forward
         self.pipe = None
-        if model is not None:
+        self._stand_in_depth = self._stand_in_active = max(int(depth or 1), 1)   # a stand-in forward runs synchronously: the
+        if model is not None:                                                      # depth only sets how far the gathers lag
             from .pipeline import PipelinedVAD
 
             self.pipe = PipelinedVAD(model, depth)
@@ -154,8 +155,12 @@ class ShardedPipeline:
         self._replica_of: List[int] = []   # which pipeline replica ran batch k
 
     @property
+    def depth(self) -> int:
+        return self.pipe.depth if self.pipe is not None else self._stand_in_depth
+
+    @property
     def in_flight(self) -> int:
-        return self.pipe.active if self.pipe is not None else 1
+        return self.pipe.active if self.pipe is not None else self._stand_in_active
 
     def set_in_flight(self, n: int) -> None:
         """forwards kept in flight from now on (1 .. depth); call it between joins, with the same n on every rank"""
@@ -163,6 +168,10 @@ class ShardedPipeline:
             raise RuntimeError("set_in_flight between submit and join")
         if self.pipe is not None:
             self.pipe.set_active(n)
+        elif not 1 <= n <= self._stand_in_depth:
+            raise ValueError(f"in_flight must be in [1, {self._stand_in_depth}], got {n}")
+        else:
+            self._stand_in_active = int(n)
 
     def set_gather(self, gather: str) -> None:
         if gather not in ("step", "final"):
@@ -181,7 +190,8 @@ class ShardedPipeline:
 
     def _gather_one(self, k: int) -> None:
         # gather="step": log-probs of batch k -> rows [k * world, (k + 1) * world) of the receive buffer
-        _all_gather(self._recv[k * self.world:(k + 1) * self.world], self._send[k], self.group)
+        out = self._recv[k * self.world:(k + 1) * self.world]            # [world, B, T, 2]
+        _all_gather(out.view((-1,) + tuple(out.shape[2:])), self._send[k], self.group)   # (the concatenating form: gloo knows no other)
 
     @torch.no_grad()
     def submit(self, features: torch.Tensor) -> None:
@@ -212,7 +222,8 @@ class ShardedPipeline:
             self.pipe.wait_for_replica(self._replica_of[k])
 
     def join(self) -> List[torch.Tensor]:
-        """-> [world, B, T, 2] per batch submitted since the last join, in submission order"""
+        """-> [world, B, T, 2] per batch submitted since the last join, in submission order.  The tensors are views of the
+        pipeline's own buffers: consume (or clone) them before the next submit()."""
         n = self._n
         if n == 0:
             return []
@@ -258,7 +269,7 @@ def forward_sharded_many(pipeline: ShardedPipeline, batches: Sequence[torch.Tens
             pipeline.submit(shard.contiguous())
         for g in pipeline.join():        # [world, per, T, 2]
             if B % world == 0:
-                results.append(g.reshape(B, g.shape[2], 2))
+                results.append(g.reshape(B, g.shape[2], 2).clone())   # (join() hands out views of buffers the next chunk reuses)
             else:
                 parts = []
                 for r in range(world):
