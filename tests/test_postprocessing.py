@@ -131,8 +131,7 @@ def test_predict_cli_writes_json_v03(tmp_path, state1234):
 
 def test_audio_loading_formats_and_resampling(tmp_path):
     """AudioData.load restated (vad/data_models/audio_data.py:18-34): .pcm, PCM WAV of several widths / channel counts,
-    and other sample rates -> float32 mono @16 kHz.  (The resampler is scipy's polyphase filter, not resampy: values
-    are unpinned against the reference; length and spectral content are checked.)"""
+    and other sample rates -> float32 mono @16 kHz.  (The resampler's sample values: test_resampler_against_the_resampy_restatement.)"""
     import wave
 
     import numpy as np
@@ -177,6 +176,34 @@ def test_audio_loading_formats_and_resampling(tmp_path):
         assert abs(np.argmax(spec) * 16000 / 12000 - 440.0) < 2.0
         assert abs(np.abs(y[2000:14000]).max() - 0.5) < 0.01
     assert len(resample_to_16k(np.zeros(44101, np.float32), 44100)) == int(np.ceil(44101 * 16000 / 44100))
+
+
+def test_resampler_against_the_resampy_restatement():
+    """features.resample_to_16k (numpy, vectorised) against oracle/resample.py, the loop-by-loop restatement of what the reference
+    calls -- librosa.resample(..., res_type="kaiser_fast") = resampy's windowed-sinc interpolation + fix_length
+    (vad/data_models/audio_data.py:27-30) -- on 8 kHz, 44.1 kHz, 48 kHz, 22.05 kHz and an awkward-ratio source: chirp + noise.
+    Both are parity-UNPINNED against resampy itself (absent here); as an independent check the band-limited part of the signal
+    must also agree with scipy's polyphase resampler (a different filter) away from the edges."""
+    import numpy as np
+    from scipy.signal import resample_poly
+
+    from oracle import resample as ref
+    from voice_activity_detection_amd.features import resample_to_16k
+
+    rng = np.random.default_rng(5)
+    for rate, n in ((8000, 1500), (44100, 4000), (48000, 3001), (22050, 2000), (16001, 700), (44100, 1), (8000, 2)):
+        t = np.arange(n) / rate
+        x = (0.4 * np.sin(2 * np.pi * (300 + 4000 * t) * t) + 0.1 * rng.standard_normal(n)).astype(np.float32)
+        want, got = ref.resample(x, rate), resample_to_16k(x, rate)
+        assert got.dtype == np.float32 and got.shape == want.shape == (int(np.ceil(n * 16000 / rate)),)
+        assert np.abs(got - want).max() < 2e-6, (rate, np.abs(got - want).max())
+    # a tone well inside both pass bands: the two resamplers agree to a fraction of a percent in the middle of the signal
+    for rate, up, down in ((44100, 160, 441), (8000, 2, 1), (48000, 1, 3)):
+        n = rate // 2
+        x = (0.5 * np.sin(2 * np.pi * 700.0 * np.arange(n) / rate)).astype(np.float32)
+        a, b = resample_to_16k(x, rate), resample_poly(x.astype(np.float64), up, down)
+        m = min(len(a), len(b))
+        assert np.abs(a[400:m - 400] - b[400:m - 400]).max() < 5e-3
 
 
 def test_reference_clip_fixture_host_side():
