@@ -115,6 +115,8 @@ S_KB = 96                      # key-split items: the key block this wave takes 
 S_KFIRST = 97                  # key-split items: 1 until this wave has seen its first key block
 S_SCRB = 98                    # key-split items: LDS byte address of the combine scratch
 S_KPEND = 99                   # key-split items: 1 while a tile's probabilities wait for their PV MFMAs
+S_ATTSH, S_ATTMASK = 34, 35    # a sequence's tail item is attached to its full group g = (bi >> S_ATTSH) & S_ATTMASK
+S_PRE = 80                     # 1: the previous item's seam already moved this item's Q into place and computed S^T(0)
 FLT_MAX_BITS = "0x7f7fffff"
 S_TM = 58                      # timing builds: s[58:59]
 TIMING = False
@@ -122,6 +124,9 @@ PAD = 0              # experiments: s_nop 0 instructions in front (shifts the st
 COUNT_ONLY = False   # timing builds: only the cold-path call counters, no stamps
 SPLIT_MAX = 2   # tail groups of up to this many query blocks are key-split items (experiments: 0, 1)
 ATTACH = True   # a sequence's tail item runs right in front of its first full item (False: all tail items last, round 3's order)
+NT = 3          # bit 0: Q loads, bit 1: ctx stores carry the non-temporal bit -- they have no reuse, K / V^T have (same time at
+                # [256,800], -5 % at [384,800], 8 MB less fabric traffic per launch; --nt 0 for the plain loads / stores)
+SEAM = True     # an ordinary item's last PV MFMAs / epilogue share their MFMA gaps with the NEXT item's Q move and S^T(0) (False: round 3)
 ABLATE = 0   # experiments (results WRONG): 1 no DMA pieces, 2 no barrier, 4 no row maxima / reference check, 8 no exp / sum / pack,
              # 16 no LDS operand reads
 
@@ -231,9 +236,9 @@ def mfma_s(buf, blk, ks, c0=False):
     return f"v_mfma_f32_32x32x16_bf16 {vr(D, 16)}, {ar(A_K + 4 * ks, 4)}, {ar(A_Q[blk] + 4 * ks, 4)}, {C}"
 
 
-def mfma_pv(blk, nbd, j):
+def mfma_pv(blk, nbd, j, c0=False):
     O = A_O[blk] + 16 * nbd
-    return f"v_mfma_f32_32x32x16_bf16 {ar(O, 16)}, {ar(A_V + 4 * (2 * nbd + j), 4)}, {vr(V_P[blk] + 4 * j, 4)}, {ar(O, 16)}"
+    return f"v_mfma_f32_32x32x16_bf16 {ar(O, 16)}, {ar(A_V + 4 * (2 * nbd + j), 4)}, {vr(V_P[blk] + 4 * j, 4)}, {'0' if c0 else ar(O, 16)}"
 
 
 def kread(f, addr, off):
@@ -293,12 +298,17 @@ def emit_cursor_next(a, c, tag):
 
 
 def emit_attach(a, c, l_end):
-    """the cursor has just reached the full group (bi, g): when it is the sequence's first one and the sequence has a
-    tail group, the tail group runs first (ph 2)"""
-    ph, g = c, c + 2
-    a.i(f"s_cmp_lg_u32 {sr(g)}, 0")
-    a.i(f"s_cbranch_scc1 {l_end}")
+    """the cursor has just reached the full group (bi, g): when it is the one the sequence's tail group is attached to,
+    the tail group runs first (ph 2).  Which one: g = (bi >> S_ATTSH) & S_ATTMASK -- with d = gcd(NGF, workgroups per XCD) > 1
+    a workgroup sees the same g (mod d) in every round, and 'always group 0' would hand all tails to 1 / d of the workgroups
+    ([256,600]: 4 items on the even workgroups, 2 on the odd ones); the attached group's residue mod d follows the rounds
+    instead, so that every workgroup takes its turn.  d = 1 (T = 800: NGF = 3): group 0, a tail on every workgroup."""
+    ph, bi, g = c, c + 1, c + 2
     a.i(f"s_cmp_eq_u32 {sr(S_TAILQ)}, 0")
+    a.i(f"s_cbranch_scc1 {l_end}")
+    a.i(f"s_lshr_b32 {sr(S_T0)}, {sr(bi)}, {sr(S_ATTSH)}")
+    a.i(f"s_and_b32 {sr(S_T0)}, {sr(S_T0)}, {sr(S_ATTMASK)}")
+    a.i(f"s_cmp_lg_u32 {sr(g)}, {sr(S_T0)}")
     a.i(f"s_cbranch_scc1 {l_end}")
     a.i(f"s_mov_b32 {sr(ph)}, 2")
 
@@ -466,7 +476,7 @@ def emit_q_request(a):
         emit_block_addr(a, S_T4, S_QF, S_T3, S_T2, S_T1)
         for f in range(8):
             dst = V_QS + (0 if blk == "A" else 32) + 4 * f
-            a.i(f"global_load_dwordx4 {vr(dst, 4)}, {vr(V_OFF[f // 4])}, {sr(S_T4, 2)} offset:{(f % 4) * FRAG}")
+            a.i(f"global_load_dwordx4 {vr(dst, 4)}, {vr(V_OFF[f // 4])}, {sr(S_T4, 2)} offset:{(f % 4) * FRAG}" + (" nt" if NT & 1 else ""))
     a.label(l_skip)
 
 
@@ -481,7 +491,7 @@ def emit_ctx_stores(a):
         a.i(f"s_bitcmp1_b32 {sr(S_PEND)}, {bit}")
         a.i(f"s_cbranch_scc0 {l_skip}")
         for f in range(8):
-            a.i(f"global_store_dwordx4 {vr(V_OFF[f // 4])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{(f % 4) * FRAG}")
+            a.i(f"global_store_dwordx4 {vr(V_OFF[f // 4])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{(f % 4) * FRAG}" + (" nt" if NT & 2 else ""))
         a.label(l_skip)
     a.i(f"s_branch {l_end}")
     a.label(l_split)   # S_CDST / S_CDSTB already point at fragment 2w of the block
@@ -490,7 +500,7 @@ def emit_ctx_stores(a):
         a.i(f"s_bitcmp1_b32 {sr(S_PEND)}, {bit}")
         a.i(f"s_cbranch_scc0 {l_skip}")
         for f in range(2):
-            a.i(f"global_store_dwordx4 {vr(V_OFF[0])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{f * FRAG}")
+            a.i(f"global_store_dwordx4 {vr(V_OFF[0])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{f * FRAG}" + (" nt" if NT & 2 else ""))
         a.label(l_skip)
     a.label(l_end)
     a.i(f"s_mov_b32 {sr(S_PEND)}, 0")
@@ -544,11 +554,12 @@ def softmax_split(buf, blk):
     return head, pack, lsum
 
 
-def pv_mfmas(blocks):
-    return [mfma_pv(blk, nbd, j) for blk in blocks for j in range(2) for nbd in range(4)]
+def pv_mfmas(blocks, first=False):
+    """first: the item's first tile -- O^T = V^T P^T starts from zero (nobody has to clear the accumulators)"""
+    return [mfma_pv(blk, nbd, j, c0=(first and j == 0)) for blk in blocks for j in range(2) for nbd in range(4)]
 
 
-def emit_step(a, i_par, has_prev, has_next, dma, book):
+def emit_step(a, i_par, has_prev, has_next, dma, book, first_pv=False):
     """Key block i (parity i_par: its scores sit in buffer i_par; the next tile's go to the other one).  Two-stage
     pipeline: the step issues  [O^T += V^T(i-1) P^T(i-1)]  (has_prev)  then  [S^T(i+1) = K(i+1) Q^T]  (has_next)  while the
     VALU works through tile i: exponentials, row sums, bf16 packing -- nothing the MFMAs of this step wait for.
@@ -557,7 +568,7 @@ def emit_step(a, i_par, has_prev, has_next, dma, book):
                                          DMA pieces, stream advance, address rotation, the reference check"""
     cur, nxt = i_par, 1 - i_par
     blocks = ("A", "B")
-    mfP = pv_mfmas(blocks) if has_prev else []
+    mfP = pv_mfmas(blocks, first=first_pv) if has_prev else []
     mfS = []
     if has_next:
         for ks in range(8):
@@ -639,13 +650,6 @@ def emit_step(a, i_par, has_prev, has_next, dma, book):
             a.i(op)
 
 
-def emit_drain(a):
-    """O^T += V^T P^T of the item's last tile"""
-    a.i("s_waitcnt lgkmcnt(0)")
-    for op in pv_mfmas(("A", "B")):
-        a.i(op)
-
-
 def emit_mask(a, buf, blocks):
     """ragged last key block (T % 32 != 0): scores of keys that do not exist -> -1e30 (lane (m, h), register r <-> key
     8 (r >> 2) + 4 h + (r & 3)); the MFMAs that wrote the tile are at least 16 MFMAs behind"""
@@ -678,13 +682,13 @@ def emit_stage(a, kind):
         emit_step(a, 0, kind == "mid", True, kh, [])
         stamp(a, c_even)
         emit_step(a, 1, True, True, vh + dma_advance_ops(a),
-                  odd_book + ([f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"] if kind == "mid" else []))
+                  odd_book + ([f"s_sub_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"] if kind == "mid" else []), first_pv=(kind == "fmid"))
         stamp(a, c_odd)
     elif kind in ("last2", "flast2"):
         emit_step(a, 0, kind == "last2", True, kh, [])
         stamp(a, c_even)
         emit_mask(a, 1, blocks)
-        emit_step(a, 1, True, False, vh + dma_advance_ops(a), odd_book)
+        emit_step(a, 1, True, False, vh + dma_advance_ops(a), odd_book, first_pv=(kind == "flast2"))
         stamp(a, c_last)
     else:
         emit_mask(a, 0, blocks)
@@ -780,28 +784,39 @@ def emit_cold_mid(a, cur, has_next, nblocks):
 
 
 # ------------------------------------------------------------------------------------------------ item prologue / epilogue
+def q_move_ops():
+    return [f"v_accvgpr_write_b32 {ar(A_Q['A'] + r)}, {vr(V_QS + r)}" for r in range(64)]
+
+
+def s0_mfmas():
+    """S^T(0) = K(0) Q^T of both query blocks against the reference 0 (C = 0)"""
+    return [mfma_s(0, blk, ks, c0=(ks == 0)) for ks in range(8) for blk in ("A", "B")]
+
+
 def emit_item_prologue(a):
-    """Q of this item from staging into a[128:191]; S^T(0) with C = 0 beside the zeroing of O; reference of tile 0"""
+    """Q of this item from staging into a[128:191] and S^T(0) -- unless the previous item's seam has done both (S_PRE);
+    reference of tile 0.  (O needs no clearing: the first tile's PV MFMAs start from C = 0.)"""
+    l_pre = a.uniq("predone")
+    if SEAM:
+        a.i(f"s_cmp_eq_u32 {sr(S_PRE)}, 1")
+        a.i(f"s_cbranch_scc1 {l_pre}")
     a.i("s_waitcnt vmcnt(8)")   # the staged Q is older than the newest stage of DMA pieces
     stamp(a, 26)
-    for r in range(64):
-        a.i(f"v_accvgpr_write_b32 {ar(A_Q['A'] + r)}, {vr(V_QS + r)}")
+    for op in q_move_ops():
+        a.i(op)
     stamp(a, 27)
     for f in range(8):
         a.i(kread(f, V_ADDR_V, 0))
+    a.i("s_waitcnt lgkmcnt(0)")
+    stamp(a, 28)
+    for op in s0_mfmas():
+        a.i(op)
+    a.label(l_pre)
+    a.i(f"s_mov_b32 {sr(S_PRE)}, 0")
     for blk in ("A", "B"):
         a.i(f"v_mov_b32 {vr(V_L[blk])}, 0")
         for r in range(16):
             a.i(f"v_mov_b32 {vr(V_NEGM[blk] + r)}, 0")
-    a.i("s_waitcnt lgkmcnt(0)")
-    stamp(a, 28)
-    n = 0
-    for ks in range(8):
-        for blk in ("A", "B"):
-            a.i(mfma_s(0, blk, ks, c0=(ks == 0)))
-            for _ in range(8):
-                a.i(f"v_accvgpr_write_b32 {ar(n)}, 0")
-                n += 1
     stamp(a, 29)
     # tile 0 is the last tile only when QB == 1, which this kernel never sees (T > 32)
     a.i(f"s_call_b64 {sr(S_RET, 2)}, .Lpw_coldfirst_0")
@@ -860,6 +875,63 @@ def emit_normalise(a, blk, nregs, dst):
     a.label(l_end)
 
 
+def normalise_ops(blk, dst):
+    """emit_normalise for a query block whose 32 rows all exist, as a straight list (the fast seam spreads it over MFMA gaps)"""
+    rec = Asm()
+    rec.i(f"v_mov_b32 {vr(V_T0)}, {vr(V_L[blk])}")
+    rec.i("s_nop 1")
+    rec.i(f"v_permlane32_swap_b32 {vr(V_L[blk])}, {vr(V_T0)}")
+    rec.i(f"v_add_f32 {vr(V_T0)}, {vr(V_L[blk])}, {vr(V_T0)}")
+    emit_recip(rec, V_T0, V_INV[blk], V_T1, V_T2, V_T3, V_T4)
+    head = [ln.strip() for ln in rec.lines]
+    body = []
+    for e in range(32):
+        body += [f"v_accvgpr_read_b32 {vr(V_T1)}, {ar(A_O[blk] + 2 * e)}", f"v_accvgpr_read_b32 {vr(V_T2)}, {ar(A_O[blk] + 2 * e + 1)}",
+                 f"v_mul_f32 {vr(V_T1)}, {vr(V_T1)}, {vr(V_INV[blk])}", f"v_mul_f32 {vr(V_T2)}, {vr(V_T2)}, {vr(V_INV[blk])}",
+                 f"v_cvt_pk_bf16_f32 {vr(dst + e)}, {vr(V_T1)}, {vr(V_T2)}"]
+    return head, body
+
+
+def emit_seam(a):
+    """The end of an ordinary item.  When this wave's NEXT item is an ordinary one too and both of its query blocks here are
+    whole, the last tile's PV MFMAs carry the next item's Q move in their gaps, and that item's S^T(0) MFMAs carry the first
+    third of this item's epilogue -- the matrix pipe never waits for the seam's VALU work, and the next prologue finds its
+    operands in place (S_PRE).  Otherwise: the plain PV MFMAs and the epilogue."""
+    l_plain, l_done = a.uniq("seamplain"), a.uniq("seamdone")
+    a.i("s_waitcnt lgkmcnt(0)")      # V^T fragments of the last tile
+    if SEAM:
+        a.i(f"s_and_b32 {sr(S_T0)}, {sr(S_NFLAGS)}, 5")
+        a.i(f"s_cmp_eq_u32 {sr(S_T0)}, 1")            # the next item: this wave has a block, and it is not a key-split item
+        a.i(f"s_cbranch_scc0 {l_plain}")
+        a.i(f"s_cmp_ge_i32 {sr(S_VALID['B'])}, 32")   # both query blocks of THIS item are whole (implies block A's 32 rows)
+        a.i(f"s_cbranch_scc0 {l_plain}")
+        a.i("s_waitcnt vmcnt(8)")    # the staged Q of the next item is older than the newest stage of DMA pieces
+        for f in range(8):           # K(0) of the next item: its stage 0 sits behind the barrier of this item's last stage
+            a.i(kread(f, V_ADDR_V, 0))
+        emit_with_gaps(a, pv_mfmas(("A", "B")), q_move_ops())
+        stamp(a, 11)
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i("s_nop 1")
+        (ha, ba), (hb, bb) = normalise_ops("A", V_CTX["A"]), normalise_ops("B", V_CTX["B"])
+        # the row sums and reciprocals first (no O access: the PV MFMAs are still in flight), then block A's context from gap 5 on
+        fill = ha + hb + ba + bb
+        k = 7 * 16                   # ~7 instructions per gap hide; the rest follows the last MFMA
+        emit_with_gaps(a, s0_mfmas(), fill[:k])
+        for op in fill[k:]:
+            a.i(op)
+        emit_ctx_dest(a, False)
+        a.i(f"s_mov_b32 {sr(S_PRE)}, 1")
+        stamp(a, 8)
+        a.i(f"s_branch {l_done}")
+        a.label(l_plain)
+    for op in pv_mfmas(("A", "B")):
+        a.i(op)
+    stamp(a, 11)
+    emit_item_epilogue(a)
+    stamp(a, 8)
+    a.label(l_done)
+
+
 def emit_ctx_dest(a, split):
     """where the finished item's context goes: blocks qa, qa + 1 of the sequence (split: this wave's fragments 2w, 2w + 1)"""
     a.i(f"s_add_u32 {sr(S_T3)}, {sr(S_SEQBLK)}, {sr(S_QA)}")
@@ -908,10 +980,7 @@ def emit_item_body(a, tag):
     a.label(l_two)
     emit_stage(a, "flast2")
     a.label(l_done)
-    emit_drain(a)
-    stamp(a, 11)
-    emit_item_epilogue(a)
-    stamp(a, 8)
+    emit_seam(a)
     a.i("s_branch .Lpw_next_item")
 
 
@@ -964,10 +1033,22 @@ def emit_ks_scores(a, nb, dma):
     a.i(f"s_call_b64 {sr(S_RET, 2)}, .Lpw_ksfirst_{nb}")
     a.i(f"s_mov_b32 {sr(S_KFIRST)}, 0")
     a.label(notfirst)
+    for blk in blocks:               # the exponentials here, the rest of the softmax behind the next barrier: the two waves that
+        head, _, _ = softmax_split(0, blk)   # work on this stage and the two that finish the previous pair's tile take about as long
+        for op in head[:16]:
+            a.i(op)
+    a.i("s_waitcnt lgkmcnt(0)")      # the V^T fragments are in registers before the barrier that frees their slot
+    a.i(f"s_mov_b32 {sr(S_KPEND)}, 1")
+
+
+def emit_ks_pv(a, nb, dma):
+    """Key-split item, second stage of a pair (or behind the item's last stage): row sums, reference check and bf16 packing of
+    the pending tile, then O^T += V^T P^T, operands in registers since the first stage; the stage's DMA pieces in the gaps"""
+    blocks = ("A", "B")[:nb]
     lsum = []
     for blk in blocks:
         head, pack, ls = softmax_split(0, blk)
-        for op in head + pack:
+        for op in head[16:] + pack:
             a.i(op)
         lsum += ls
     if nb == 2:
@@ -980,15 +1061,8 @@ def emit_ks_scores(a, nb, dma):
     a.ool_call(f".Lpw_coldmid_0_0_{nb}")
     for op in lsum:
         a.i(op)
-    a.i("s_waitcnt lgkmcnt(0)")      # the V^T fragments are in registers before the barrier that frees their slot
-    a.i(f"s_mov_b32 {sr(S_KPEND)}, 1")
-
-
-def emit_ks_pv(a, nb, dma):
-    """Key-split item, second stage of a pair (or behind the item's last stage): O^T += V^T P^T of the pending tile,
-    operands in registers since the first stage; the stage's DMA pieces in the gaps"""
     a.i("s_nop 1")
-    emit_with_gaps(a, pv_mfmas(("A", "B")[:nb]), dma)
+    emit_with_gaps(a, pv_mfmas(blocks), dma)
     a.i(f"s_mov_b32 {sr(S_KPEND)}, 0")
 
 
@@ -1220,6 +1294,14 @@ def emit_all():
     a.i(f"s_add_u32 {sr(S_BX)}, %4, 7")                      # sequences of this XCD: b = 8 bi + xcd < B
     a.i(f"s_sub_u32 {sr(S_BX)}, {sr(S_BX)}, {sr(S_XCD)}")
     a.i(f"s_lshr_b32 {sr(S_BX)}, {sr(S_BX)}, 3")
+    # d = the largest power of two that divides NGF and the stride (the stride is one: 32 workgroups per XCD); S_ATTSH = log2(stride / d)
+    a.i(f"s_max_u32 {sr(S_T0)}, {sr(S_NGF)}, 1")
+    a.i(f"s_ff1_i32_b32 {sr(S_T0)}, {sr(S_T0)}")
+    a.i(f"s_ff1_i32_b32 {sr(S_T1)}, {sr(S_STRIDE)}")
+    a.i(f"s_min_u32 {sr(S_T0)}, {sr(S_T0)}, {sr(S_T1)}")
+    a.i(f"s_sub_u32 {sr(S_ATTSH)}, {sr(S_T1)}, {sr(S_T0)}")
+    a.i(f"s_lshl_b32 {sr(S_ATTMASK)}, 1, {sr(S_T0)}")
+    a.i(f"s_sub_u32 {sr(S_ATTMASK)}, {sr(S_ATTMASK)}, 1")
     a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_W)}, 12")
     a.i(f"s_add_u32 {sr(S_LDSW)}, {sr(S_LDS)}, {sr(S_T0)}")
     a.i(f"v_add_u32 {vr(V_OFF[1])}, 4096, {vr(V_LANE16)}")
@@ -1234,6 +1316,7 @@ def emit_all():
     a.i(f"v_add_u32 {vr(V_ADDR_K)}, {sr(S_KS)}, {vr(V_LDSL)}")
     a.i(f"s_mov_b32 {sr(S_PEND)}, 0")
     a.i(f"s_mov_b32 {sr(S_QPEND)}, 0")
+    a.i(f"s_mov_b32 {sr(S_PRE)}, 0")
     a.i(f"s_mov_b32 {sr(S_DSTREAM)}, 0")
     a.i(f"s_mov_b32 {sr(S_DLDS)}, {sr(S_LDSW)}")
     a.i(f"s_mov_b32 {sr(S_DBASE)}, {sr(S_LDSW)}")
@@ -1385,6 +1468,12 @@ def main():
         if "--pad" in sys.argv:
             global PAD
             PAD = int(sys.argv[sys.argv.index("--pad") + 1])
+        if "--nt" in sys.argv:
+            global NT
+            NT = int(sys.argv[sys.argv.index("--nt") + 1])
+        if "--no-seam" in sys.argv:
+            global SEAM
+            SEAM = False
         if "--no-attach" in sys.argv:
             global ATTACH
             ATTACH = False

@@ -123,6 +123,7 @@ def parse_program(text, operand_map=None):
         if mo:
             offset = int(mo.group(1))
             rest = rest[:mo.start()] + rest[mo.end():]
+        rest = re.sub(r"\b(nt|sc0|sc1|glc|slc)\b", "", rest)   # cache-policy bits: no functional meaning
         if op == "s_waitcnt":
             ops = rest.strip()
         else:
@@ -436,6 +437,10 @@ class Workgroup:
             first = ka <= kb if "min" in op else ka >= kb
             w.scc = int(first)
             self.wrs(w, o[0], a if first else b)
+            return None
+        if op == "s_ff1_i32_b32":
+            x = R(w, ins, o[1])
+            self.wrs(w, o[0], (x & -x).bit_length() - 1 if x else MASK32)
             return None
         if op == "s_cselect_b32":
             self.wrs(w, o[0], R(w, ins, o[1]) if w.scc else R(w, ins, o[2]))

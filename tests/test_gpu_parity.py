@@ -1062,14 +1062,21 @@ def test_config4_one_hour_stream_full_size(torch_cuda, model, state1234, precisi
         if precision == "fp32":
             assert torch.equal(other, p)  # a window's result does not depend on its batch slot or on the chunking
         else:
-            # bf16: chunks of >= 256 windows take the persistent attention kernel (savad.hip, pw_pays), smaller ones the
-            # first-generation kernel (so does the 132-window rest of 900 = 3 x 256 + 132); the two agree bit for bit except in
-            # how a sequence's last 32 frames are summed (key-split tail item).  So: the same bits within either kernel's range
-            # of chunk sizes, the bf16 rounding of those frames across.
-            p300 = StreamingPredictor(model, "cuda", T, hop, max_batch=300).predict_device(fd)
-            assert torch.equal(StreamingPredictor(model, "cuda", T, hop, max_batch=450).predict_device(fd), p300)
-            assert torch.equal(StreamingPredictor(model, "cuda", T, hop, max_batch=180).predict_device(fd), other)
-            assert float((other - p).abs().max()) < 3e-3 and float((p300 - p).abs().max()) < 3e-3
+            # bf16: automatic picks the persistent attention kernel or the first-generation one by batch size (savad.hip, pw_pays);
+            # the two agree bit for bit except in how a sequence's last 32 frames are summed (key-split tail item).  So: with
+            # either kernel forced, the same bits whatever the chunking; across the two, the bf16 rounding of those frames.
+            forced = {}
+            for mode in (1, 5):
+                model.row_mode = mode
+                try:
+                    a = StreamingPredictor(model, "cuda", T, hop, max_batch=300).predict_device(fd)
+                    b = StreamingPredictor(model, "cuda", T, hop, max_batch=180).predict_device(fd)
+                finally:
+                    model.row_mode = 0
+                assert torch.equal(a, b), mode
+                forced[mode] = a
+            assert float((forced[1] - forced[5]).abs().max()) < 3e-3
+            assert float((other - p).abs().max()) < 3e-3 and float((forced[5] - p).abs().max()) < 3e-3
     finally:
         model.precision = "fp32"
     ph = p.cpu().numpy()

@@ -826,13 +826,34 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     if ((rc = prepare_bf16_launch(m))) return rc;
     Prof prof(m, st);
     const bool automatic_bf16 = m->row_mode == 0 || m->row_mode == 4;
-    // The persistent attention kernel (one 4 x 64-row workgroup per CU walking (sequence, 8 query blocks) items) wins once
-    // every workgroup gets at least three full items of a long key walk; below that its coarse items leave CUs idle
-    // while others work.  Measured, attention stage per layer, first-generation / persistent kernel (same bits):
-    // [256,800] 96.2 / 89.5 us, [384,800] 150.3 / 143.4, [192,800] 78.4 / 78.1, [128,800] 54.5 / 58.3, [512,400] 63.9 / 64.2.
+    // The persistent attention kernel (one 4 x 64-row workgroup per CU walking (sequence, 8 query blocks) items) against the
+    // first-generation one: a cost model of both, from the sweep scripts/ubench/pw_sweep.py (round 4, us per launch, first-generation /
+    // persistent): [96,800] 43.4 / 50.1, [128,800] 52.6 / 52.0, [160,800] 67.3 / 58.3, [192,800] 77.9 / 74.1, [224,800] 90.8 / 78.1,
+    // [256,800] 97.7 / 82.4, [512,800] 193.3 / 163.7, [256,1000] 143.7 / 117.7, [128,1600] 176.1 / 144.3, [64,3200] 333.9 / 284.5,
+    // [512,400] 65.3 / 63.8.  Persistent: the busiest workgroup's items (the cursor of scripts/gen_attn_pw.py restated: full groups
+    // with a stride of 32 per XCD, a sequence's tail group attached to one of them; a key-split tail costs 0.55 of a full item) times
+    // 0.62 us per key block + 7 us per item, + 5 us per launch.  First generation: 0.54 ns per (query block x key block) + 2.5 ns per
+    // query block, per sequence.  The persistent kernel is picked when the model has it 3 % ahead.
     auto pw_pays = [](int Bq, int Tq) {
-        const int QBq = (Tq + 31) / 32;
-        return QBq >= 20 && (long)Bq * (QBq / 8) >= 3L * bf::PW_GRID;
+        const int QBq = (Tq + 31) / 32, NGFq = QBq >> 3, TQq = QBq & 7;
+        if (NGFq == 0) return false;
+        const int wg = bf::PW_GRID / 8;
+        auto ff1 = [](int x) { return __builtin_ctz((unsigned)x); };
+        const int t0 = ff1(NGFq) < ff1(wg) ? ff1(NGFq) : ff1(wg), sh = ff1(wg) - t0, mask = (1 << t0) - 1;
+        const int S = (Bq + 7) / 8;  // sequences of the fullest XCD
+        const double ctail = TQq == 0 ? 0.0 : (TQq <= 2 ? 0.55 : 1.0);
+        double busiest = 0.0;
+        for (int j = 0; j < wg; ++j) {
+            double n = 0.0;
+            for (long i = j; i / NGFq < S; i += wg) {
+                const int bi = (int)(i / NGFq), g = (int)(i % NGFq);
+                n += 1.0 + ((TQq && g == ((bi >> sh) & mask)) ? ctail : 0.0);
+            }
+            busiest = n > busiest ? n : busiest;
+        }
+        const double t_pw = busiest * (0.62 * QBq + 7.0) + 5.0;
+        const double t_first = (double)Bq * (5.4e-4 * QBq * QBq + 2.5e-3 * QBq);
+        return t_pw < 0.97 * t_first;
     };
     auto run = [&](auto nw_tag) {
         constexpr int NW = decltype(nw_tag)::value;

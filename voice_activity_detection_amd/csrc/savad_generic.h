@@ -200,7 +200,8 @@ inline Plan plan(int B, int T, int Dm, int force_query_tiles) {
         long tq = force_query_tiles > 1 ? (T + force_query_tiles - 1) / force_query_tiles : (long)(SCORE_CAP / T);
         p.tq = (int)(tq < 1 ? 1 : (tq > T ? T : tq));
     } else {
-        const size_t cb = SCORE_CAP / tt;
+        size_t cb = SCORE_CAP / tt;
+        cb = cb > 65535 ? 65535 : cb;  // cb is a grid.z of the score GEMMs (HIP: at most 65535); the b0 loop takes the rest
         p.cb = (int)(cb > (size_t)B ? (size_t)B : cb);
         p.tq = T;
     }

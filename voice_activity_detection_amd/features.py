@@ -35,7 +35,7 @@ def resample_to_16k(audio: np.ndarray, sample_rate: int) -> np.ndarray:
     beta 8.5555; table scaled by the ratio and strided when downsampling -- then zero-padded to ceil(n * 16000 / rate) samples
     (librosa's fix_length).  numpy only, vectorised over blocks of output samples.  librosa / resampy are absent from this
     image, so parity with THEM is unpinned; this function is held to a loop-by-loop restatement of resampy's published code
-    (oracle/resample.py) on 8 kHz / 44.1 kHz / 48 kHz fixtures (tests/test_postprocessing.py)."""
+    (the test-side CPU restatement, resample.py) on 8 kHz / 44.1 kHz / 48 kHz fixtures (tests/test_postprocessing.py)."""
     x = np.asarray(audio, dtype=np.float32)
     rate = int(sample_rate)
     if rate == SAMPLE_RATE or x.shape[0] == 0:

@@ -86,6 +86,7 @@ class SelfAttentiveVAD(nn.Module):
         # PipelinedVAD's replicas share the parameters but keep their own handles, and re-push when they see a new generation
         self._weights_generation = 0
         self._seen_generation = 0
+        self._pdev = None             # device of the parameters (cached: nn.Module attribute lookups are slow; _apply resets it)
         self.attention_splits = 0  # 0 = automatic
         self.row_mode = 0  # 0 = automatic, 1 = N-split 32-row tiles, 2 / 3 = M-split 128-row tiles, 4 = T <= 32 in one launch (include/savad.h)
         # "fp32": exact-fp32 MFMA (default, log-probs within 1e-4 of the reference).
@@ -156,6 +157,7 @@ class SelfAttentiveVAD(nn.Module):
         self.__dict__.setdefault("_ws_bytes", {})
         self.__dict__.setdefault("_weights_generation", 0)
         self.__dict__.setdefault("_seen_generation", 0)
+        self.__dict__["_pdev"] = None
 
     def train(self, mode: bool = True):
         # SWITCHING modes is where parameters were most likely edited behind autograd's back (p.data.copy_ in EMA /
@@ -171,6 +173,7 @@ class SelfAttentiveVAD(nn.Module):
         # .to() / .cuda() / .float() ...: storage moves without a version bump -- re-push (here and in a pipeline's replicas)
         self._synced_versions = None
         self._weights_generation += 1
+        self._pdev = None
         return super()._apply(fn, *args, **kwargs)
 
     def _param_versions(self):
@@ -229,7 +232,9 @@ class SelfAttentiveVAD(nn.Module):
             raise _lib.SavadError("training-mode dropout is outside this build's scope: call model.eval()")
         if self.precision not in ("fp32", "bf16"):
             raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.precision!r}")
-        pdev = self.classifier.weight.device
+        pdev = self._pdev
+        if pdev is None:
+            pdev = self._pdev = self.classifier.weight.device
         if pdev != device:
             raise _lib.SavadError(f"model parameters are on {pdev}, features on {device}")
         lib = _lib.load()
@@ -272,13 +277,14 @@ class SelfAttentiveVAD(nn.Module):
         device = features.device
         if device.type != "cuda" or self.precision not in ("fp32", "bf16"):
             self._prepare_call(device)  # raises the matching error
-        x = features.detach()
+        x = features.detach() if features.requires_grad else features
         x_dtype = 0
         if self.precision == "bf16" and x.dtype == torch.bfloat16:
             x_dtype = 1  # bf16 features are consumed as they are
         elif x.dtype != torch.float32:
             x = x.float()
-        x = x.contiguous()
+        if not x.is_contiguous():
+            x = x.contiguous()
         B, T, _ = x.shape
         if out is None:
             out = torch.empty((B, T, 2), dtype=torch.float32, device=device)
