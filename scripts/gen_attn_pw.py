@@ -126,6 +126,18 @@ SPLIT_MAX = 2   # tail groups of up to this many query blocks are key-split item
 ATTACH = True   # a sequence's tail item runs right in front of its first full item (False: all tail items last, round 3's order)
 NT = 3          # bit 0: Q loads, bit 1: ctx stores carry the non-temporal bit -- they have no reuse, K / V^T have (same time at
                 # [256,800], -5 % at [384,800], 8 MB less fabric traffic per launch; --nt 0 for the plain loads / stores)
+POLICY = {1: " nt", 2: " sc0 sc1", 3: " sc0 sc1 nt", 4: " sc1", 5: " sc0"}   # experiments: --qpol / --cpol pick another cache policy
+
+
+def q_policy():
+    return QPOL if QPOL is not None else (" nt" if NT & 1 else "")
+
+
+def ctx_policy():
+    return CPOL if CPOL is not None else (" nt" if NT & 2 else "")
+
+
+QPOL = CPOL = None
 SEAM = True     # an ordinary item's last PV MFMAs / epilogue share their MFMA gaps with the NEXT item's Q move and S^T(0) (False: round 3)
 ABLATE = 0   # experiments (results WRONG): 1 no DMA pieces, 2 no barrier, 4 no row maxima / reference check, 8 no exp / sum / pack,
              # 16 no LDS operand reads
@@ -476,7 +488,7 @@ def emit_q_request(a):
         emit_block_addr(a, S_T4, S_QF, S_T3, S_T2, S_T1)
         for f in range(8):
             dst = V_QS + (0 if blk == "A" else 32) + 4 * f
-            a.i(f"global_load_dwordx4 {vr(dst, 4)}, {vr(V_OFF[f // 4])}, {sr(S_T4, 2)} offset:{(f % 4) * FRAG}" + (" nt" if NT & 1 else ""))
+            a.i(f"global_load_dwordx4 {vr(dst, 4)}, {vr(V_OFF[f // 4])}, {sr(S_T4, 2)} offset:{(f % 4) * FRAG}" + q_policy())
     a.label(l_skip)
 
 
@@ -491,7 +503,7 @@ def emit_ctx_stores(a):
         a.i(f"s_bitcmp1_b32 {sr(S_PEND)}, {bit}")
         a.i(f"s_cbranch_scc0 {l_skip}")
         for f in range(8):
-            a.i(f"global_store_dwordx4 {vr(V_OFF[f // 4])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{(f % 4) * FRAG}" + (" nt" if NT & 2 else ""))
+            a.i(f"global_store_dwordx4 {vr(V_OFF[f // 4])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{(f % 4) * FRAG}" + ctx_policy())
         a.label(l_skip)
     a.i(f"s_branch {l_end}")
     a.label(l_split)   # S_CDST / S_CDSTB already point at fragment 2w of the block
@@ -500,7 +512,7 @@ def emit_ctx_stores(a):
         a.i(f"s_bitcmp1_b32 {sr(S_PEND)}, {bit}")
         a.i(f"s_cbranch_scc0 {l_skip}")
         for f in range(2):
-            a.i(f"global_store_dwordx4 {vr(V_OFF[0])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{f * FRAG}" + (" nt" if NT & 2 else ""))
+            a.i(f"global_store_dwordx4 {vr(V_OFF[0])}, {vr(V_CTX[blk] + 4 * f, 4)}, {sr(dst, 2)} offset:{f * FRAG}" + ctx_policy())
         a.label(l_skip)
     a.label(l_end)
     a.i(f"s_mov_b32 {sr(S_PEND)}, 0")
@@ -1468,6 +1480,11 @@ def main():
         if "--pad" in sys.argv:
             global PAD
             PAD = int(sys.argv[sys.argv.index("--pad") + 1])
+        global QPOL, CPOL
+        if "--qpol" in sys.argv:
+            QPOL = POLICY[int(sys.argv[sys.argv.index("--qpol") + 1])]
+        if "--cpol" in sys.argv:
+            CPOL = POLICY[int(sys.argv[sys.argv.index("--cpol") + 1])]
         if "--nt" in sys.argv:
             global NT
             NT = int(sys.argv[sys.argv.index("--nt") + 1])

@@ -28,6 +28,9 @@ rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -f csv -d $OUT/pmc_l2 -o
 echo "pmc_l2 rc=$?"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 -f csv -d $OUT/pmc_inst -o pmc -- $BENCH > $OUT/pmc_inst.log 2>&1
 echo "pmc_inst rc=$?"
+# what leaves the L2s towards the fabric, by request size and by destination (DRAM = HBM behind the Infinity Cache; the rest: peer / IO)
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum -f csv -d $OUT/pmc_ea -o pmc -- $BENCH > $OUT/pmc_ea.log 2>&1
+echo "pmc_ea rc=$?"
 cd $REPO
 python scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -52,7 +52,7 @@ for f in find("trace/**/*kernel_trace.csv"):
                                          "Workgroup_Size", "Grid_Size")}
         print(f"{k:28s} {cols}")
 
-for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_l2", "pmc_inst"):
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_l2", "pmc_inst", "pmc_ea"):
     files = find(f"{sub}/**/*counter_collection.csv")
     if not files:
         continue

@@ -166,6 +166,13 @@ def test_checkpoints_load_without_arbitrary_unpickling(tmp_path, state1234, monk
     assert isinstance(P._load_checkpoint(tmp_path / "opaque.checkpoint", True)["config"], _Opaque)
     monkeypatch.setenv("SAVAD_TRUST_CHECKPOINT", "1")
     assert isinstance(P._load_checkpoint(tmp_path / "opaque.checkpoint", False)["config"], _Opaque)
+    # only an unlisted global falls through to the full unpickle: a missing or truncated file is reported as what it is, trusted or not
+    with pytest.raises(FileNotFoundError):
+        P._load_checkpoint(tmp_path / "nowhere.checkpoint", True)
+    (tmp_path / "cut.checkpoint").write_bytes((tmp_path / "ok.checkpoint").read_bytes()[:100])
+    with pytest.raises(Exception) as info:
+        P._load_checkpoint(tmp_path / "cut.checkpoint", True)
+    assert "weights_only" not in str(info.value)
 
 
 class _Opaque:

@@ -165,7 +165,7 @@ def test_config3_global_batch_on_one_gpu(torch_cuda, model, state1234, rccl):
     assert np.isfinite(yh).all() and np.abs(np.logaddexp(yh[..., 0], yh[..., 1])).max() < 1e-5
     pick = [0, 255, 256, 1000, 1791, 2047]                  # first / last sequence of shards 0, 1, 3, 6, 7
     xin = xd[pick].float().cpu().numpy()                    # the oracle sees the same bf16-rounded features
-    assert np.abs(yh[pick] - oracle.forward(state1234, xin)).max() < 2e-2  # BF16_TOL of tests/test_gpu_parity.py
+    assert np.abs(yh[pick] - oracle.forward(state1234, xin)).max() < 1.2e-2  # BF16_TOL of tests/test_gpu_parity.py
 
 
 @pytest.mark.parametrize("gather", ["step", "final"])

@@ -560,7 +560,8 @@ def test_streaming_long_form(torch_cuda, model, state1234, n, T, hop):
 
 
 # ---- bf16 operands (BASELINE configs[2..3]): judged on AUC and a loose log-prob bound, not on 1e-4 ----------
-BF16_TOL = 2e-2  # measured 5.6e-3 max-abs log-prob error (fp32 residual stream + statistics); torch-CPU bf16 end-to-end shows 1.5e-2
+BF16_TOL = 1.2e-2  # 2x the measured 5.7e-3 max-abs log-prob error over these shapes and all launch schedules (scripts/ubench/bf16_tol_probe.py,
+                   # round 4; fp32 residual arithmetic + statistics); torch-CPU bf16 end-to-end shows 1.5e-2
 
 
 def run_bf16(torch, model, x, bf16_input=False):
@@ -835,9 +836,9 @@ def test_bf16_reference_moves(torch_cuda, state1234):
         m.row_mode = mode
         ys[mode] = run_bf16(torch, m, x)
         assert np.isfinite(ys[mode]).all()
-        # peaked softmaxes amplify the bf16 rounding of q and k: the bound is looser than BF16_TOL, the decisions are not
-        assert np.abs(ys[mode] - ref).max() < 0.25, np.abs(ys[mode] - ref).max()
-        assert ((ys[mode][..., 1] > ys[mode][..., 0]) == (ref[..., 1] > ref[..., 0])).mean() > 0.99
+        # peaked softmaxes amplify the bf16 rounding of q and k: measured 8.8e-3 (bf16_tol_probe.py), bound = 2x; decisions agree on 99.8 %
+        assert np.abs(ys[mode] - ref).max() < 2e-2, np.abs(ys[mode] - ref).max()
+        assert ((ys[mode][..., 1] > ys[mode][..., 0]) == (ref[..., 1] > ref[..., 0])).mean() > 0.995
     assert np.array_equal(ys[1], ys[3])
 
 

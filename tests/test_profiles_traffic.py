@@ -1,0 +1,72 @@
+"""Regression guard on wasted HBM-side traffic: every committed PMC pass (profiles/*_traffic.json, scripts/profile_gpu.sh) that was
+taken on exactly the kernel sources in the tree (csrc_hash) must show, for every kernel of the forward, measured bytes per launch
+(FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md) within 1.2x of the algorithmic bytes bench.py prices
+the launch at -- re-reads are the first thing to fix on a memory-side kernel.  Kernels with a KNOWN, explained excess carry their
+own bound below; a new excess fails here before it reaches a bench line."""
+import json
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+
+# profile name pattern -> (precision, B, T, bytes per element of q / k / v / ctx)
+WORKLOADS = [("bf16_b256", ("bf16", 256, 800, 2)), ("t7", ("fp32", 1000, 7, 4)), ("t50", ("fp32", 512, 50, 4)), ("", ("fp32", 32, 800, 4))]
+# rocprofv3 kernel name (as scripts/summarize_profile.py shortens it) -> bench.py launch label
+LABELS = {
+    "attention_row_kernel<false>": "attention_row", "attention_row_kernel<true>": "attention_row_last", "input_qkv_kernel_m": "input_qkv",
+    "attention_kernel": "attention", "row_kernel_m<false>": "row", "row_kernel_m<true>": "row_last",
+    "attention_pw_kernel_bf16": "attention_bf16", "attention_kernel_bf16<4>": "attention_bf16",
+    "row_kernel_bf16<false, 4>": "row_bf16", "row_kernel_bf16<true, 4>": "row_last_bf16", "input_qkv_kernel_bf16<__bf16, 4>": "input_qkv_bf16",
+    "packed_forward_kernel": "packed_forward",
+}
+# explained excesses: kernel -> (bound, why)
+KNOWN = {
+    "packed_forward_kernel": (12.0, "[1000,7,80]: 2.3 MB algorithmic; each of the 8 XCD L2s fetches the 2.4 MB of packed weights once: 0.3 % of the HBM roof"),
+    "attention_pw_kernel_bf16": (1.65, "T = 800: the key-split tail item's workgroup starts its full group 0.55 item-times behind the sequence's other two "
+                                       "groups and fetches K / V^T a second time (+105 MB); T = 768, no tail group: 1.00x (DESIGN section 4b-3)"),
+    "row_kernel_m<false>": (1.35, "[512,50,80]: key-split partials O / m / l of three splits are part of the launch's reads (not in the per-frame algorithmic figure)"),
+    "row_kernel_m<true>": (1.6, "as row_kernel_m<false>, against a smaller algorithmic figure (no q / k / v written)"),
+    "attention_kernel": (1.6, "[512,50,80]: three key splits write unnormalised partials + (m, l) instead of one context"),
+}
+
+
+def workload_of(name):
+    for pat, wl in WORKLOADS:
+        if pat and f"_{pat}_traffic" in name:
+            return wl
+    return WORKLOADS[-1][1]
+
+
+def test_committed_traffic_profiles_show_no_unexplained_rereads():
+    from bench import kernel_source_hash, launch_work
+
+    want = kernel_source_hash()
+    files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if json.loads(f.read_text()).get("csrc_hash") == want]
+    if not files:
+        pytest.skip(f"no profiles/*_traffic.json was taken on the kernel sources in the tree (csrc_hash {want}): run scripts/profile_gpu.sh")
+    checked = 0
+    for f in files:
+        prec, B, T, e = workload_of(f.name)
+        for kernel, entry in json.loads(f.read_text()).items():
+            label = LABELS.get(kernel)
+            if label is None or not isinstance(entry, dict):
+                continue
+            _, algorithmic = launch_work(label, B, T, e)
+            ratio = entry["hbm_bytes_per_launch"] / algorithmic
+            bound, why = KNOWN.get(kernel, (1.2, None))
+            assert ratio <= bound, (f"{f.name}: {kernel} moves {entry['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch against {algorithmic / 1e6:.1f} MB "
+                                    f"algorithmic ({ratio:.2f}x > {bound}x)" + (f"; known excess: {why}" if why else ""))
+            checked += 1
+    assert checked > 0
+
+
+def test_the_guard_would_have_flagged_round_3():
+    """profiles/r3_bf16_b256_traffic.json: 330 MB against 210 MB (1.57x) -- above the default bound this file applies to new kernels"""
+    from bench import launch_work
+
+    entry = json.loads((REPO / "profiles" / "r3_bf16_b256_traffic.json").read_text())["attention_pw_kernel_bf16"]
+    _, algorithmic = launch_work("attention_bf16", 256, 800, 2)
+    assert entry["hbm_bytes_per_launch"] / algorithmic > 1.2

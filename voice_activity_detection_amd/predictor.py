@@ -93,10 +93,14 @@ class VADFromScratchPredictor:
                 break
             except (ImportError, AttributeError):
                 continue
+        import pickle
+
+        if not hasattr(torch.serialization, "safe_globals"):
+            raise RuntimeError("this torch build has no torch.serialization.safe_globals: checkpoints cannot be loaded with weights_only=True")
         try:
             with torch.serialization.safe_globals(safe):
                 return torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-        except Exception as exc:  # pickle.UnpicklingError of an unlisted global
+        except pickle.UnpicklingError as exc:  # an unlisted global: only this falls through; I/O and format errors propagate as they are
             if not (trust or os.environ.get("SAVAD_TRUST_CHECKPOINT") == "1"):
                 raise RuntimeError(
                     f"{checkpoint_path}: not loadable with weights_only=True ({str(exc).splitlines()[0]}). If you trust the "
