@@ -327,7 +327,7 @@ class Runner:
         self.sp.set_gather(gather)
 
     def step(self):
-        if self.sp._n >= self.sp.slots:   # warm-up loops run longer than one block
+        if self.sp.pending >= self.sp.slots:   # warm-up loops run longer than one block
             self.drain()
         self.sp.submit(self.x)
 

@@ -120,6 +120,7 @@ S_PRE = 80                     # 1: the previous item's seam already moved this 
 FLT_MAX_BITS = "0x7f7fffff"
 S_TM = 58                      # timing builds: s[58:59]
 TIMING = False
+WGTIME = False       # timing builds (--wgtime): no phase stamps; wave 0 of every workgroup with j < 16 stores its (start, end) on the 100 MHz clock
 PAD = 0              # experiments: s_nop 0 instructions in front (shifts the stream by 4 bytes each)
 COUNT_ONLY = False   # timing builds: only the cold-path call counters, no stamps
 SPLIT_MAX = 2   # tail groups of up to this many query blocks are key-split items (experiments: 0, 1)
@@ -1286,6 +1287,10 @@ def emit_all():
     a.i("s_mov_b64 exec, -1")
     for _ in range(PAD):
         a.i("s_nop 0")
+    if WGTIME:
+        a.i(f"s_memrealtime {sr(S_TM, 2)}")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"s_and_b32 {sr(81)}, {sr(S_TM)}, 0xffff")        # start, low 16 bits of the 10 ns clock
     if TIMING:
         a.i(f"v_mov_b32 {vr(V_ACC)}, 0")
         a.i(f"s_memtime {sr(S_TM, 2)}")
@@ -1420,6 +1425,26 @@ def emit_all():
         a.i("s_mov_b32 exec_hi, -1")
         a.label(l_nopub)
     a.label(".Lpw_end")
+    if WGTIME:
+        l_nowg = a.uniq("nowg")
+        a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        a.i(f"s_memrealtime {sr(S_TM, 2)}")
+        a.i("s_waitcnt lgkmcnt(0)")
+        a.i(f"s_cmp_lg_u32 {sr(S_W)}, 0")
+        a.i(f"s_cbranch_scc1 {l_nowg}")
+        a.i(f"s_cmp_ge_u32 {sr(S_J)}, 16")
+        a.i(f"s_cbranch_scc1 {l_nowg}")
+        a.i(f"s_lshl_b32 {sr(S_TM)}, {sr(S_TM)}, 16")
+        a.i(f"s_or_b32 {sr(S_TM)}, {sr(S_TM)}, {sr(81)}")     # end << 16 | start
+        a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_J)}, 3")
+        a.i(f"s_add_u32 {sr(S_T0)}, {sr(S_T0)}, {sr(S_XCD)}")
+        a.i(f"s_lshl_b32 {sr(S_T0)}, {sr(S_T0)}, 2")
+        a.i(f"v_mov_b32 {vr(V_T0)}, {sr(S_T0)}")
+        a.i(f"v_mov_b32 {vr(V_T1)}, {sr(S_TM)}")
+        a.i("s_mov_b64 exec, 1")
+        a.i(f"global_store_dword {vr(V_T0)}, {vr(V_T1)}, %16")
+        a.i("s_mov_b64 exec, -1")
+        a.label(l_nowg)
     a.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a.i("s_branch .Lpw_exit")
     # ---- out-of-line code: stubs, subroutines
@@ -1475,6 +1500,8 @@ def main():
     if "--out" in sys.argv:  # experiment variant: [--ablate MASK] [--timing] --out FILE
         ABLATE = int(sys.argv[sys.argv.index("--ablate") + 1]) if "--ablate" in sys.argv else 0
         TIMING = "--timing" in sys.argv or "--count" in sys.argv
+        global WGTIME
+        WGTIME = "--wgtime" in sys.argv
         global COUNT_ONLY
         COUNT_ONLY = "--count" in sys.argv
         if "--pad" in sys.argv:

@@ -1231,3 +1231,52 @@ def test_pipelined_forwards_are_the_modules_bits(torch_cuda, state1234, precisio
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(got, ref))
     m.row_mode = 0
+
+
+def test_pipeline_replicas_follow_weight_changes(torch_cuda, state1234):
+    """PipelinedVAD's replicas share the module's parameters but own their native handles: every way the module learns of a weight
+    change must reach them too -- in-place updates (version counter), load_state_dict, `.data` edits announced by
+    sync_weights(force=True) (also on a base module that has never run a forward itself: StreamingPredictor's case), a train / eval
+    switch, and a storage move (.to): the pipeline's results stay the CPU checker's for the CURRENT weights."""
+    from oracle import oracle
+    from voice_activity_detection_amd import PipelinedVAD, seeded_state_dict
+
+    torch = torch_cuda
+    st = {k: v.copy() for k, v in state1234.items()}
+    m = make_model(torch, st)
+    pipe = PipelinedVAD(m, depth=2)
+    x = feats(31, (6, 40, 80))
+    xd = torch.from_numpy(x).cuda()
+
+    def check():
+        outs = pipe.forward_many([xd, xd, xd])
+        torch.cuda.synchronize()
+        ref = oracle.forward(st, x)
+        for o in outs:
+            assert np.abs(o.cpu().numpy() - ref).max() < TIGHT
+
+    check()                                   # the base module's own handle does not exist yet: only the replicas have run
+    assert m._handle is None
+    with torch.no_grad():                     # (1) `.data` edit: invisible to version counters -> announced by force
+        m.classifier.bias.data.add_(0.5)
+    st["classifier.bias"] = st["classifier.bias"] + 0.5
+    m.sync_weights(force=True)
+    check()
+    with torch.no_grad():                     # (2) in-place update through the parameter: seen by every replica on its own
+        m.input_layer["0"].bias.mul_(1.5)
+    st["input_layer.0.bias"] = st["input_layer.0.bias"] * 1.5
+    check()
+    st2 = seeded_state_dict(4321)             # (3) load_state_dict
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in st2.items()})
+    st.clear()
+    st.update(st2)
+    check()
+    with torch.no_grad():                     # (4) `.data` edit + a train / eval round trip (the mode switch forces the re-push)
+        m.classifier.weight.data.mul_(-1.0)
+    st["classifier.weight"] = st["classifier.weight"] * -1.0
+    m.train()
+    m.eval()
+    check()
+    m.to("cpu")                               # (5) storage moves: the replicas must not keep pushing from freed pointers
+    m.to("cuda")
+    check()

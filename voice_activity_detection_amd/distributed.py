@@ -155,6 +155,11 @@ class ShardedPipeline:
         self._replica_of: List[int] = []   # which pipeline replica ran batch k
 
     @property
+    def pending(self) -> int:
+        """batches submitted since the last join() (at most `slots`)"""
+        return self._n
+
+    @property
     def depth(self) -> int:
         return self.pipe.depth if self.pipe is not None else self._stand_in_depth
 
