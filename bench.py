@@ -7,15 +7,17 @@
 
 One "step" = one pass of the hot path over one batch of synthetic mel frames: forward of
 SelfAttentiveVAD on a device-resident [B, T, F] tensor -> device-resident [B, T, 2] log-probs
-(N > 1: every rank runs its own B-sequence shard; the log-probs of the K batches of a timed block are gathered over RCCL
-by ONE all_gather that closes the block -- north_star's "single RCCL gather at the end" -- or, with --gather step, by the
-per-call all_gather of `voice_activity_detection_amd.distributed.forward_sharded`; both are measured on every N > 1 run).
+(N > 1: every rank runs its own B-sequence shard through voice_activity_detection_amd.distributed.ShardedPipeline, which issues every
+collective of the run: by default one RCCL all_gather of [B,T,2] per forward, lagging behind the forwards in flight (--gather step, what
+`value` is quoted on); with --gather final every forward writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block --
+north_star's "single RCCL gather at the end".  Both are measured on every N > 1 run.  `--backend gloo --stub-forward` runs the same control
+flow on CPU ranks with a stand-in forward: a dry run for tests/test_dist_gloo.py, never a measurement.)
 Default workload = BASELINE.json configs[1]: [32, 800, 80] fp32 per GPU, seeded weights.
 
 The K batches of a block are independent, so up to three of them are kept IN FLIGHT (voice_activity_detection_amd.PipelinedVAD: one HIP
 stream, library handle and workspace per forward in flight; the same bits as one at a time): the warm-up times 1, 2 and 3 in flight and
 the timed blocks use the fastest (--in-flight N fixes it).  Every step's work is complete inside its block (join + synchronize before the
-clock stops).  The one-at-a-time figure is printed beside `value` (ms_per_step_one_in_flight), and the per-kernel roofline block is
+clock stops).  The one-at-a-time figure is printed beside `value` (value_one_forward / ms_one_forward), and the per-kernel roofline block is
 measured with ONE forward in flight, so that a launch's duration is the kernel's own.
 
 Timing: W warm-up steps (at least 0.2 s of them, so the clocks have ramped), then BLOCKS
