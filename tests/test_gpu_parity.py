@@ -1280,3 +1280,35 @@ def test_pipeline_replicas_follow_weight_changes(torch_cuda, state1234):
     m.to("cpu")                               # (5) storage moves: the replicas must not keep pushing from freed pointers
     m.to("cuda")
     check()
+
+
+def test_bf16_persistent_attention_random_shapes(torch_cuda):
+    """seeded random (B, T) for the persistent attention kernel, weighted towards the tail forms (QB mod 8 in {1, 2}: key-split items of one
+    and two query blocks; 3..7: ordinary ragged tail items; 0: none), ragged last key blocks, fewer sequences than XCDs and more items than
+    workgroups: one-layer model, row_mode 5 against row_mode 1 -- the same bits outside the key-split rows, the bf16 rounding of the context
+    inside them -- and against the CPU checker."""
+    from oracle import oracle
+    from voice_activity_detection_amd import seeded_state_dict
+
+    torch = torch_cuda
+    st = seeded_state_dict(79, num_layers=1)
+    m = make_model(torch, st, L=1)
+    rng = np.random.default_rng(2024)
+    for it in range(28):
+        QB = int(rng.choice([2, 3, 8, 9, 10, 12, 16, 17, 18, 21, 24, 25, 26, 33, 34, 41]))
+        T = 32 * (QB - 1) + int(rng.integers(1, 33))
+        B = int(rng.integers(1, max(2, min(70, 24000 // T))))
+        if it % 7 == 6:
+            B = int(rng.integers(260, 300)) if T <= 100 else B   # more items than workgroups on the short forms
+        x = feats(int(rng.integers(1 << 30)), (B, T, 80))
+        ys = {}
+        for mode in (1, 5):
+            m.row_mode = mode
+            ys[mode] = run_bf16(torch, m, x)
+        same = pw_key_split_rows(T)
+        assert np.isfinite(ys[5]).all(), (B, T)
+        assert np.array_equal(ys[1][:, :same], ys[5][:, :same]), (B, T)
+        if same < T:
+            assert np.abs(ys[1][:, same:] - ys[5][:, same:]).max() < 4e-3, (B, T)
+        ref = oracle.forward(st, x, threads=16)
+        assert np.abs(ys[5] - ref).max() < BF16_TOL, (B, T, np.abs(ys[5] - ref).max())
