@@ -1312,63 +1312,3 @@ def test_bf16_persistent_attention_random_shapes(torch_cuda):
             assert np.abs(ys[1][:, same:] - ys[5][:, same:]).max() < 4e-3, (B, T)
         ref = oracle.forward(st, x, threads=16)
         assert np.abs(ys[5] - ref).max() < BF16_TOL, (B, T, np.abs(ys[5] - ref).max())
-
-
-@pytest.mark.parametrize("shape,bf16_input", [((267, 768, 80), False), ((267, 768, 80), True), ((2100, 50, 80), False), ((300, 800, 80), False)])
-def test_bf16_remainder_tiles_same_bits(torch_cuda, model, state1234, shape, bf16_input):
-    """bf16, large batches: the blocks past the last full round of the input / row stages' workgroups run as N-split TILES, the last
-    workgroups of the same launch (savad_kernels_bf16.h: row_tile_bf16, input_tile_bf16; 6 408 = 3 x 2 048 + 264 blocks at [267,768],
-    4 200 = 2 x 2 048 + 104 at [2100,50]).  A tile computes its block in the M-split kernels' own operation order: the log-probs must be
-    the bits of row_mode 1 (every block on the M-split path, no tiles) wherever the attention stage is the same arithmetic -- T = 768
-    and T = 50 have no key-split tail item.  [300,800]: 7 500 = 3 x 2 048 + 1 356 blocks, more than 3/8 of a round: no tiles.  Sampled
-    sequences of the tiled region against the CPU checker everywhere."""
-    from oracle import oracle
-
-    torch = torch_cuda
-    x = feats(sum(shape) + 3, shape)
-    ys = {}
-    for mode in (0, 1, 5):
-        if mode == 5 and shape[1] <= 32:
-            continue
-        model.row_mode = mode
-        try:
-            ys[mode] = run_bf16(torch, model, x, bf16_input=bf16_input)
-            again = run_bf16(torch, model, x, bf16_input=bf16_input)
-        finally:
-            model.row_mode = 0
-        assert np.isfinite(ys[mode]).all() and np.array_equal(again, ys[mode]), mode
-    if shape[1] in (768, 50):
-        assert np.array_equal(ys[0], ys[1])
-    if shape[1] == 768:
-        assert np.array_equal(ys[1], ys[5])
-    B = shape[0]
-    pick = [0, B // 2, B - 3, B - 2, B - 1]          # the last sequences live in the tiled blocks
-    xin = x[pick]
-    if bf16_input:
-        xin = torch.from_numpy(xin).to(torch.bfloat16).float().numpy()
-    ref = oracle.forward(state1234, xin, threads=16)
-    assert np.abs(ys[0][pick] - ref).max() < BF16_TOL * (3 if bf16_input else 1)
-
-
-def test_bf16_remainder_tiles_are_graph_capturable(torch_cuda, model):
-    """a forward whose input / row launches end in N-split tiles replays from a hipGraph with the eager bits"""
-    torch = torch_cuda
-    model.precision = "bf16"
-    try:
-        shape = (267, 768, 80)
-        x0, x1 = (torch.from_numpy(feats(s, shape)).cuda() for s in (51, 52))
-        static_x = x0.clone()
-        with torch.no_grad():
-            eager0, eager1 = model(features=x0).clone(), model(features=x1).clone()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                static_y = model(features=static_x)
-            g.replay()
-            torch.cuda.synchronize()
-            assert torch.equal(static_y, eager0)
-            static_x.copy_(x1)
-            g.replay()
-            torch.cuda.synchronize()
-            assert torch.equal(static_y, eager1)
-    finally:
-        model.precision = "fp32"

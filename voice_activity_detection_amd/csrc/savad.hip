@@ -74,7 +74,6 @@ struct savad_model {
     size_t frag_bytes = 0;
     bool frag_dirty = true;
     bool lds_attrs_set = false;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the bf16 kernels
-    int wave_slots = 2048;  // bf16 path: waves of the 4-wave workgroups resident on the device at two workgroups per CU
     size_t f_win = 0;
     struct LayerFrag {
         size_t wqkv, wo, w1, w2;
@@ -785,11 +784,6 @@ int prepare_bf16_launch(savad_model* m) {
     if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::attention_pw_kernel_bf16, bf::PW_LDS_BYTES))) return rc;
-    static_assert(bf::TILE_LDS_BYTES <= r4, "a tile workgroup lives in the LDS of the launch it belongs to");
-    int dev = 0, cus = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus > 0) m->wave_slots = cus * 8;
     m->lds_attrs_set = true;
     return SAVAD_OK;
 }
@@ -864,26 +858,16 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     auto run = [&](auto nw_tag) {
         constexpr int NW = decltype(nw_tag)::value;
         constexpr int ring = bf::Ring<NW>::NRING * bf::RING_BYTES;
-        // Blocks past the last FULL round of the stage's 4-wave workgroups (nblk mod wave_slots, when that is at most 3/8 of a round)
-        // go to N-split tiles: one block per workgroup, the LAST workgroups of the same launch (savad_kernels_bf16.h: they take the
-        // slots the last full round drains); row_mode 1 / 2 keep every block on the M-split kernels.
-        int ntile = 0;
-        if (NW == 4 && !bp.fused && (automatic_bf16 || m->row_mode == 5) && bp.nblk >= m->wave_slots) {
-            const int r = bp.nblk % m->wave_slots;
-            if (r > 0 && r * 8 <= m->wave_slots * 3) ntile = r;
-        }
-        const int nfull = bp.nblk - ntile;
-        const int tile_wg0 = ntile ? nfull / NW : INT_MAX;
-        const int grid_rows = ntile ? nfull / NW + ntile : bp.nblk_pad / NW;
+        const int grid_rows = bp.nblk_pad / NW;
         const dim3 wg(64 * NW);
         if (x_is_bf16)
             hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<__bf16, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const __bf16*)x,
                                B, T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb,
-                               qf, kf, vtf, c, m->d_sat, tile_wg0, nfull);
+                               qf, kf, vtf, c, m->d_sat);
         else
             hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<float, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const float*)x, B,
                                T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf,
-                               kf, vtf, c, m->d_sat, tile_wg0, nfull);
+                               kf, vtf, c, m->d_sat);
         prof.mark("input_qkv_bf16");
         char* sets[2][3] = {{qf, kf, vtf}, {W + bp.q2, W + bp.k2, W + bp.vt2}};
         for (int l = 0; l < L; ++l) {
@@ -913,8 +897,6 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
             A.out = out;
             A.qscale = c;
             A.satcnt = m->d_sat;
-            A.tile_wg0 = bp.fused ? INT_MAX : tile_wg0;
-            A.tile_blk0 = nfull;
             if (bp.fused) {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
                 const dim3 grid(8 * (((long)B * NG + 7) / 8));

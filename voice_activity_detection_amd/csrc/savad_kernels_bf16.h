@@ -257,15 +257,6 @@ __device__ __forceinline__ bf16x8 load_x_frag(const __bf16* p, bool valid) {
     return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
 }
 
-// the N-split tiles of a launch's remainder blocks (defined behind the row kernel)
-struct RowArgsBf16;
-template <bool LAST>
-__device__ __forceinline__ void row_tile_bf16(const char* ctxf, const RowArgsBf16& A, int blk, char* smem);
-template <typename XT>
-__device__ __forceinline__ void input_tile_bf16(const XT* x, int B, int T, int F, int nblk, const char* win_frag, const float* bin, const float* pe,
-                                                const char* wqkv_frag, const float* bqkv, hres_t* hbuf, char* qf, char* kf, char* vtf, float qscale,
-                                                unsigned* satcnt, int blk, char* smem);
-
 // ---------------------------------------------------------------------------------------------
 // Kernel 1 (bf16): input Linear + PE -> h (fp32) -> LN -> Q, K, V^T fragments.  NW waves = NW blocks.
 // XT = float or __bf16 input features.
@@ -275,13 +266,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf1
     const XT* __restrict__ x, int B, int T, int F, int nblk, const char* __restrict__ win_frag,
     const float* __restrict__ bin, const float* __restrict__ pe, const char* __restrict__ wqkv_frag,
     const float* __restrict__ bqkv, hres_t* __restrict__ hbuf, char* __restrict__ qf, char* __restrict__ kf,
-    char* __restrict__ vtf, float qscale, unsigned* __restrict__ satcnt, int tile_wg0, int tile_blk0) {
+    char* __restrict__ vtf, float qscale, unsigned* __restrict__ satcnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (NW == 4 && (int)blockIdx.x >= tile_wg0) {  // the launch's last workgroups: one block each as an N-split tile (input_tile_bf16)
-        input_tile_bf16<XT>(x, B, T, F, nblk, win_frag, bin, pe, wqkv_frag, bqkv, hbuf, qf, kf, vtf, qscale, satcnt,
-                            tile_blk0 + (int)blockIdx.x - tile_wg0, smem);
-        return;
-    }
     using R = Ring<NW>;
     float* lbq = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
@@ -533,8 +519,6 @@ struct RowArgsBf16 {
     float* out;           // LAST
     float qscale;
     unsigned* satcnt;     // residual-stream saturation counter (store_hblock)
-    int tile_wg0, tile_blk0;  // row_kernel_bf16<., 4>: workgroups blockIdx.x >= tile_wg0 run ONE block each as an N-split tile: block
-                              // tile_blk0 + blockIdx.x - tile_wg0 (tile_wg0 = INT_MAX: none)
 };
 
 // The whole row chain of block `blk` for one wave.  In: xp = the block's attention context as B-operand fragments.
@@ -642,10 +626,6 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
 template <bool LAST, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(const char* __restrict__ ctxf, RowArgsBf16 A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (NW == 4 && (int)blockIdx.x >= A.tile_wg0) {  // (workgroup-uniform)
-        row_tile_bf16<LAST>(ctxf, A, A.tile_blk0 + (int)blockIdx.x - A.tile_wg0, smem);
-        return;
-    }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = blockIdx.x * NW + w;
@@ -656,292 +636,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(cons
         if (blk >= A.nblk) xp[ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});  // pad blocks: attention never wrote them
     }
     row_stage_bf16<LAST, NW>(A, smem, xp, blk, true, lane, w);
-}
-
-// ---------------------------------------------------------------------------------------------
-// N-split TILES of the two memory-side stages (round 4): ONE block of 32 rows per 4-wave workgroup, wave w owning
-// output-feature block w of every GEMM with the FULL contraction -- the M-split kernels' own operation order, so a
-// block's results are the same bits whichever kernel computed it.  A block is latency-bound on one wave (a chain of 384
-// dependent-phase MFMAs); four waves sharing it take about a fifth of the time.  They exist for the blocks PAST the last
-// full round of the M-split launch (6 400 blocks on 2 048 wave slots are 3.125 rounds: the last 64 workgroups used to run
-// nearly alone, +14 us per launch): the launcher gives that remainder to these tiles as the LAST workgroups of the same launch
-// (blockIdx >= tile_wg0), so that they take the slots the last full round drains.  (As separate launches on a second,
-// low-priority stream beside the main launch they measured 17 - 24 us SLOWER per stage than no tiles at all: the fork / join
-// through events costs more than the tail; scripts/ubench/README.md.)
-//   row tile : h1[w] = h[w] + bo[w] + (ctx Wo^T)[w]  -> exchange (fp32 rows through LDS) -> LN -> hidden chunk w of the FFN
-//              -> exchange (bf16 fragments through LDS) -> o[w] = h1[w] + b2[w] + (relu(..) W2^T)[w] over all 32 K-steps in the
-//              M-split order -> exchange -> LN -> q[w], k[w], v^T[w]   (LAST: wave 0 runs the classifier)
-//   input tile: h0[w] = bin[w] + pe[w] + (x Win^T)[w] -> exchange -> LN -> q[w], k[w], v^T[w]
-// Weights come straight from L2 into the A operand (fragment-major: one load = one contiguous KiB); nothing is shared
-// between workgroups, so there is no ring.
-// ---------------------------------------------------------------------------------------------
-constexpr int TILE_LDS_BYTES = 4 * 4096 + 32 * FRAG_BYTES + 9 * D * 4;  // four fp32 row slices | the FFN's 32 hidden-activation fragments | biases
-
-// A tile streams its weight fragments in GROUPS of eight (one n-block x 8 K-steps = 8 KiB per wave = 32 VGPRs), double-buffered in
-// registers and requested by hand one group ahead of the MFMAs that consume them -- left to itself hipcc sinks each load to its first
-// use and the chain pays an L2 round trip per group (savad_kernels.h, finding (vi): same remedy).  The waits name the buffer as an
-// in / out operand so that no MFMA reading it can move above them; other vector-memory operations in flight only make a counted
-// wait stricter (loads return in order).
-struct WGroup {
-    u32x4 v[8];
-};
-__device__ __forceinline__ void wgroup_load(WGroup& g, const char* frag0 /* wave-uniform: fragment (n-block, K-step 0) */, unsigned voff /* lane * 16 */) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(g.v[i]) : "v"(voff), "s"(frag0 + (i >> 2) * 4096), "n"((i & 3) * 1024));
-}
-template <int PENDING>  // younger requests allowed to stay in flight (8 per group)
-__device__ __forceinline__ void wgroup_wait(WGroup& g) {
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(g.v[0]), "+v"(g.v[1]), "+v"(g.v[2]), "+v"(g.v[3]), "+v"(g.v[4]), "+v"(g.v[5]), "+v"(g.v[6]), "+v"(g.v[7])
-                 : "n"(PENDING));
-}
-// acc += W[n-block] x over the group's 8 K-steps, ascending (gemm_ring's order for that n-block)
-__device__ __forceinline__ f32x16 wgroup_gemm(f32x16 acc, const WGroup& g, const bf16x8 (&xp)[8]) {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) acc = SAVAD_MFMA_BF16(__builtin_bit_cast(bf16x8, g.v[ks]), xp[ks], acc);
-    return acc;
-}
-
-__device__ __forceinline__ void load_hblock_one(f32x16& x, const hres_t* hb, int nb, int lane) {
-#pragma unroll
-    for (int gp = 0; gp < 2; ++gp) {
-        const f16x8 t = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(hb + ((nb * 2 + gp) * 64 + lane) * 8));
-        const f32x8 f = __builtin_convertvector(t, f32x8);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) x[8 * gp + s] += f[s];
-    }
-}
-// feature block nb of store_hblock (same clamp, same conversion; every element is counted by the one wave that owns it)
-__device__ __forceinline__ void store_hblock_one(hres_t* hb, const f32x16& x, int nb, int lane, unsigned* __restrict__ satcnt) {
-    float amax = 0.0f;
-#pragma unroll
-    for (int gp = 0; gp < 2; ++gp) {
-        f32x8 f;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            amax = fmaxf(amax, fabsf(x[8 * gp + s]));
-            f[s] = fminf(fmaxf(x[8 * gp + s], -65504.0f), 65504.0f);
-        }
-        const f16x8 t = __builtin_convertvector(f, f16x8);
-        *reinterpret_cast<u32x4*>(hb + ((nb * 2 + gp) * 64 + lane) * 8) = __builtin_bit_cast(u32x4, t);
-    }
-    if (__any(!(amax <= 65504.0f))) {
-        unsigned c = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c += !(fabsf(x[r]) <= 65504.0f);
-        if (c) atomicAdd(satcnt, c);
-    }
-}
-// every wave hands its 32-feature slice of the block's rows to the other three: `mine` -> full[0..3] (full[w] = mine)
-__device__ __forceinline__ void tile_exchange_rows(float* xrow, const f32x16& mine, f32x16 (&full)[4], int w, int lane) {
-    f32x4* slot = reinterpret_cast<f32x4*>(xrow);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) slot[(w * 4 + g) * 64 + lane] = f32x4{mine[4 * g], mine[4 * g + 1], mine[4 * g + 2], mine[4 * g + 3]};
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 t = slot[(u * 4 + g) * 64 + lane];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) full[u][4 * g + e] = t[e];
-        }
-}
-// acc = bias[w] + (W x)[n-block w]: the M-split gemm_ring's operation order for that n-block (K-steps ascending)
-__device__ __forceinline__ f32x16 tile_gemm8(f32x16 acc, const char* frag0 /* fragment (n-block, K-step 0) */, const bf16x8 (&xp)[8], int lane) {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) acc = SAVAD_MFMA_BF16(ldfrag(frag0 + (ks * 64 + lane) * 16), xp[ks], acc);
-    return acc;
-}
-// this wave's feature block w of Q (pre-scaled), K and V^T of block blk: qkv_block_bf16 for n-block w of each of the three
-__device__ __forceinline__ void tile_qkv(const char* wqkv_frag, const float* bqkv, const bf16x8 (&xp)[8], char* __restrict__ qf,
-                                         char* __restrict__ kf, char* __restrict__ vtf, int blk, int w, int lane, float qscale) {
-    const int n = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int rb = 0; rb < 3; ++rb) {
-        const char* frag0 = wqkv_frag + (size_t)((rb * 4 + w) * 8) * FRAG_BYTES;
-        f32x16 acc;
-        if (rb < 2) {
-            acc = tile_gemm8(bias_block(bqkv + D * rb + 32 * w, h), frag0, xp, lane);
-        } else {
-            const float bv = bqkv[2 * D + 32 * w + n];  // swapped form: lane = output feature
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bv;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = SAVAD_MFMA_BF16(xp[ks], ldfrag(frag0 + (ks * 64 + lane) * 16), acc);
-        }
-        if (rb == 0) acc *= qscale;
-        char* dst = rb == 0 ? qf : (rb == 1 ? kf : vtf);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) stfrag(dst + ((size_t)blk * 8 + 2 * w + j) * FRAG_BYTES + lane * 16, pack_half(acc, j));
-    }
-}
-
-template <bool LAST>
-__device__ __forceinline__ void row_tile_bf16(const char* __restrict__ ctxf, const RowArgsBf16& A, int blk /* < A.nblk */, char* smem) {
-    float* xrow = reinterpret_cast<float*>(smem);
-    char* hid = smem + 4 * 4096;
-    float* lbo = reinterpret_cast<float*>(smem + 4 * 4096 + 32 * FRAG_BYTES);
-    float* lb1 = lbo + D;
-    float* lb2 = lb1 + DFF;
-    float* lbn = lb2 + D;
-    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned voff = (unsigned)lane * 16u;
-    // this wave's weight groups, in the order it consumes them: Wo[w] | W1 chunk w, n-blocks 0..3 | W2[w], chunks 0..3 | Wq[w], Wk[w], Wv[w]
-    const char* g_wo = A.wo_frag + (size_t)(w * 8) * FRAG_BYTES;
-    const char* g_w1 = A.w1_frag + (size_t)(w * 4 * 8) * FRAG_BYTES;
-    const char* g_w2 = A.w2_frag + (size_t)(w * 32) * FRAG_BYTES;
-    const char* g_wn = LAST ? nullptr : A.wn_frag + (size_t)(w * 8) * FRAG_BYTES;
-    WGroup ga, gb;
-    wgroup_load(ga, g_wo, voff);
-    stage_bias(lbo, A.bo, D);
-    stage_bias(lb1, A.b1, DFF);
-    stage_bias(lb2, A.b2, D);
-    if (!LAST) stage_bias(lbn, A.bn, 3 * D);
-    bf16x8 xp[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) xp[ks] = ldfrag(ctxf + ((size_t)blk * 8 + ks) * FRAG_BYTES + lane * 16);
-    hres_t* hb = A.hbuf + (size_t)blk * HBLK_FLOATS;
-    f32x16 mine = zero16();
-    load_hblock_one(mine, hb, w, lane);
-    wgroup_load(gb, g_w1, voff);                      // W1 (chunk w, n-block 0)
-    __syncthreads();                                  // the biases
-    // ---- h1[w] = h[w] + bo[w] + (ctx Wo^T)[w]
-    mine += bias_block(lbo + 32 * w, h);
-    wgroup_wait<8>(ga);
-    mine = wgroup_gemm(mine, ga, xp);
-    f32x16 full[4];
-    tile_exchange_rows(xrow, mine, full, w, lane);
-    f32x4 xg[16];
-    layernorm_regs(full, xg);
-    pack_row(xg, xp);
-    // ---- FFN: hidden chunk w here, all four chunks through LDS, output block w
-    f32x16 o = mine;
-    o += bias_block(lb2 + 32 * w, h);
-    auto hidden = [&](WGroup& g, int nbl) {
-        f32x16 a = wgroup_gemm(bias_block(lb1 + 128 * w + 32 * nbl, h), g, xp);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) stfrag(hid + ((w * 8 + 2 * nbl + j) * 64 + lane) * 16, pack_half(a, j));
-    };
-    wgroup_load(ga, g_w1 + 1 * BLK_BYTES, voff);
-    wgroup_wait<8>(gb);
-    hidden(gb, 0);
-    wgroup_load(gb, g_w1 + 2 * BLK_BYTES, voff);
-    wgroup_wait<8>(ga);
-    hidden(ga, 1);
-    wgroup_load(ga, g_w1 + 3 * BLK_BYTES, voff);
-    wgroup_wait<8>(gb);
-    hidden(gb, 2);
-    wgroup_load(gb, g_w2, voff);                      // W2[w], K-steps 0..7
-    wgroup_wait<8>(ga);
-    hidden(ga, 3);
-    __syncthreads();
-    auto ffn2 = [&](const WGroup& g, int ch) {
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            o = SAVAD_MFMA_BF16(__builtin_bit_cast(bf16x8, g.v[ks]), ldfrag(hid + ((ch * 8 + ks) * 64 + lane) * 16), o);
-    };
-    wgroup_load(ga, g_w2 + 1 * BLK_BYTES, voff);
-    wgroup_wait<8>(gb);
-    ffn2(gb, 0);
-    wgroup_load(gb, g_w2 + 2 * BLK_BYTES, voff);
-    wgroup_wait<8>(ga);
-    ffn2(ga, 1);
-    wgroup_load(ga, g_w2 + 3 * BLK_BYTES, voff);
-    wgroup_wait<8>(gb);
-    ffn2(gb, 2);
-    if (!LAST) wgroup_load(gb, g_wn, voff);           // Wq[w]
-    if (!LAST)
-        wgroup_wait<8>(ga);
-    else
-        wgroup_wait<0>(ga);
-    ffn2(ga, 3);
-    if (!LAST) store_hblock_one(hb, o, w, lane, A.satcnt);
-    tile_exchange_rows(xrow, o, full, w, lane);   // (everybody left the first exchange's reads before the hidden barrier)
-    layernorm_regs(full, xg);
-    if (!LAST) {
-        pack_row(xg, xp);
-        const int n = lane & 31;
-        auto store_block = [&](char* dst, const f32x16& acc) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) stfrag(dst + ((size_t)blk * 8 + 2 * w + j) * FRAG_BYTES + lane * 16, pack_half(acc, j));
-        };
-        wgroup_load(ga, g_wn + 4 * BLK_BYTES, voff);  // Wk[w]  (the store of h above may be older than these loads: the counted waits only get stricter)
-        wgroup_wait<8>(gb);
-        f32x16 q = wgroup_gemm(bias_block(lbn + 32 * w, h), gb, xp);
-        q *= A.qscale;
-        wgroup_load(gb, g_wn + 8 * BLK_BYTES, voff);  // Wv[w]
-        store_block(A.qf, q);
-        wgroup_wait<8>(ga);
-        const f32x16 k = wgroup_gemm(bias_block(lbn + D + 32 * w, h), ga, xp);
-        store_block(A.kf, k);
-        f32x16 v;
-        const float bv = lbn[2 * D + 32 * w + n];     // swapped form: lane = output feature
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = bv;
-        wgroup_wait<0>(gb);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) v = SAVAD_MFMA_BF16(xp[ks], __builtin_bit_cast(bf16x8, gb.v[ks]), v);
-        store_block(A.vtf, v);
-    } else if (w == 0) {
-        float z0 = 0.0f, z1 = 0.0f;
-#pragma unroll
-        for (int G = 0; G < 16; ++G) {
-            const f32x4 c0 = ld4(A.wc + 8 * G + 4 * h), c1 = ld4(A.wc + D + 8 * G + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                z0 = __builtin_fmaf(xg[G][e], c0[e], z0);
-                z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
-            }
-        }
-        z0 = half_sum(z0) + A.bn[0];
-        z1 = half_sum(z1) + A.bn[1];
-        const float mx = fmaxf(z0, z1);
-        const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
-        size_t row;
-        int t_frame;
-        const bool valid = (blk < A.nblk) && slot_row(A.B, A.T, blk, m, row, t_frame);
-        if (h == 0 && valid) *reinterpret_cast<f32x2*>(A.out + row * 2) = f32x2{z0 - lse, z1 - lse};
-    }
-}
-
-template <typename XT>
-__device__ __forceinline__ void input_tile_bf16(
-    const XT* __restrict__ x, int B, int T, int F, int nblk, const char* __restrict__ win_frag, const float* __restrict__ bin,
-    const float* __restrict__ pe, const char* __restrict__ wqkv_frag, const float* __restrict__ bqkv, hres_t* __restrict__ hbuf,
-    char* __restrict__ qf, char* __restrict__ kf, char* __restrict__ vtf, float qscale, unsigned* __restrict__ satcnt, int blk, char* smem) {
-    float* xrow = reinterpret_cast<float*>(smem);
-    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    size_t row;
-    int t_frame;
-    const bool valid = (blk < nblk) && slot_row(B, T, blk, m, row, t_frame);
-    if (!valid) {
-        row = 0;
-        t_frame = 0;
-    }
-    f32x16 mine = zero16();
-    add_bias(mine, bin + 32 * w, h);
-    add_block(mine, pe + (size_t)t_frame * D + 32 * w, h);
-    const int KS = F / 16;
-    const XT* xr = x + row * (size_t)F;
-    for (int ks = 0; ks < KS; ++ks) {
-        const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
-        const bf16x8 xf = load_x_frag(xr + f0, valid);
-        mine = SAVAD_MFMA_BF16(ldfrag(win_frag + ((size_t)(w * KS + ks) * 64 + lane) * 16), xf, mine);
-    }
-    store_hblock_one(hbuf + (size_t)blk * HBLK_FLOATS, mine, w, lane, satcnt);
-    f32x16 full[4];
-    tile_exchange_rows(xrow, mine, full, w, lane);
-    f32x4 xg[16];
-    layernorm_regs(full, xg);
-    bf16x8 xp[8];
-    pack_row(xg, xp);
-    tile_qkv(wqkv_frag, bqkv, xp, qf, kf, vtf, blk, w, lane, qscale);
 }
 
 // ---------------------------------------------------------------------------------------------
