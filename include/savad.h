@@ -108,7 +108,7 @@ int savad_forward_ex(savad_handle h, const void* x, int x_dtype, int B, int T, f
 
 /* Tuning knob: number of key-range splits of the attention stage (0 = automatic). */
 int savad_set_attention_splits(savad_handle h, int splits);
-/* Tuning knob: the launch schedule (results differ only in fp32 summation order; default 0 = automatic).
+/* Tuning knob: the launch schedule (results differ only in summation order; default 0 = automatic).
  *   fp32 operands
  *     1  row-wise stages on 32-row tiles, output features split over the workgroup's 4 waves; attention is its own
  *        launch (what automatic picks for small T > 32 batches)
@@ -123,8 +123,10 @@ int savad_set_attention_splits(savad_handle h, int splits);
  *     1  separate attention / row launches, 4-wave workgroups      2  the same with 8-wave workgroups
  *     3  fused launches (T > 32)                                    0  fused up to ~4 workgroups per CU
  *     5  separate launches with the attention stage as ONE persistent launch (4 waves x 64 query rows per CU walking
- *        (sequence, 8 query blocks) items; csrc/savad_attn_pw_bf16.h); same bits as 1.  Automatic picks it for large
- *        batches of long sequences (>= 3 items per CU, T >= 609) */
+ *        (sequence, 8 query blocks) items; csrc/savad_attn_pw_bf16.h).  Same bits as 1 except for the frames of a sequence's
+ *        tail group of one or two query blocks (ceil(T / 32) mod 8 in {1, 2}), whose keys are summed as four partial softmaxes
+ *        (key-split item): those agree with 1 to the bf16 rounding of the context.  Automatic picks it where a cost model of
+ *        both attention kernels (savad.hip, pw_pays) has it ahead: large batches of long sequences ([160+,800], [256,1000] ...) */
 int savad_set_row_mode(savad_handle h, int mode);
 /* Per-kernel timing (bench.py's roofline block).  savad_set_profiling(h, capacity): the next `capacity` calls of
  * savad_forward bracket every launch with hipEvents on `stream` (capacity 0 switches profiling off and frees the
