@@ -139,6 +139,8 @@ def ctx_policy():
 
 
 QPOL = CPOL = None
+BALANCE = 0     # experiments (--balance N): 1 the first half of a step (K reads, exponentials, block A's row sum beside the PV MFMAs) is laid
+                # out by estimated ISSUE cost per MFMA gap instead of by instruction count; 2 the second half too
 SEAM = True     # an ordinary item's last PV MFMAs / epilogue share their MFMA gaps with the NEXT item's Q move and S^T(0) (False: round 3)
 ABLATE = 0   # experiments (results WRONG): 1 no DMA pieces, 2 no barrier, 4 no row maxima / reference check, 8 no exp / sum / pack,
              # 16 no LDS operand reads
@@ -557,6 +559,34 @@ def spread(gaps, ops, lo, hi):
         gaps[lo + (k * n) // len(ops)].append(op)
 
 
+ISSUE_COST = {"ds_read_b128": 15, "v_exp_f32": 8, "global_load_lds_dwordx4": 8}   # cycles a wave cannot issue its next MFMA (estimates; others 4)
+
+
+def op_cost(op):
+    return sum(ISSUE_COST.get(ln.split()[0], 4) for ln in op.split("\n\t"))
+
+
+def spread_balanced(gaps, ops, lo, hi):
+    """ops (kept in order) over gaps[lo:hi] so that every gap carries about the same estimated issue cost on top of what it holds"""
+    if hi <= lo or not ops:
+        if ops:
+            gaps[max(0, min(lo, len(gaps) - 1))].extend(ops)
+        return
+    load = [sum(op_cost(o) for o in gaps[g]) for g in range(lo, hi)]
+    total = sum(load) + sum(op_cost(o) for o in ops)
+    k, g = 0, 0
+    while k < len(ops):
+        left = hi - lo - g
+        target = (total - sum(load[:g])) / left if left > 0 else 1e9      # what the remaining gaps must carry on average
+        c = op_cost(ops[k])
+        if g < hi - lo - 1 and load[g] > 0 and load[g] + c > target + 2:
+            g += 1
+            continue
+        gaps[lo + g].append(ops[k])
+        load[g] += c
+        k += 1
+
+
 def softmax_split(buf, blk):
     """softmax_ops(buf, blk) in three groups: exponentials + row sum (what the reference check needs), bf16 packing,
     and the update of the running row sum (which must wait for the check)"""
@@ -607,8 +637,11 @@ def emit_step(a, i_par, has_prev, has_next, dma, book, first_pv=False):
     if len(blocks) == 2:
         for k in range(len(exps["A"])):
             one += [exps["A"][k], exps["B"][k]]
-        one += adds["A"]
-        two += adds["B"]
+        if BALANCE >= 3:     # both row sums beside the S^T MFMAs: the two halves then carry about the same issue cost
+            two += [x for pair in zip(adds["A"], adds["B"]) for x in pair]
+        else:
+            one += adds["A"]
+            two += adds["B"]
     else:
         one += exps["A"]
         two += adds["A"]
@@ -626,13 +659,33 @@ def emit_step(a, i_par, has_prev, has_next, dma, book, first_pv=False):
         dma = [op for op in dma if not (op.startswith("global_load_lds") or "m0" in op)]
     a.i("s_waitcnt lgkmcnt(0)")       # V^T(i-1) fragments (requested in the previous step)
     pre = []
-    if nP >= 4:
+    if nP >= 4 and BALANCE:
+        # K reads two per gap while the exponentials may not start yet (the last MFMA of S^T(i) was issued at the very end of the
+        # previous step: its readers start 2 MFMAs in), the others between the exponentials; every gap the same issue cost
+        gaps[0].extend(kr[0:2])
+        gaps[1].extend(kr[2:4])
+        rest, krl, n_e = [], kr[4:], 0
+        for op in one:
+            rest.append(op)
+            if op.startswith("v_exp"):
+                n_e += 1
+                if n_e % 6 == 0 and krl:
+                    rest.append(krl.pop(0))
+        rest += krl
+        spread_balanced(gaps, rest, 2, nP)
+    elif nP >= 4:
         # the last MFMA of S^T(i) was issued at the very end of the previous step: its readers start 2 MFMAs in
         spread(gaps, kr, 0, max(1, nP // 2))
         spread(gaps, one, 2, nP)
     else:
         pre = kr + one
-    if N - nP > 0:
+    if N - nP > 0 and BALANCE >= 2:
+        spread(gaps, vr_ops, nP, nP + max(1, (N - nP) // 2))
+        spread(gaps, dma, nP, N)
+        spread(gaps, book, nP + (N - nP) // 2, N)
+        spread_balanced(gaps, two, nP, N)
+        post = []
+    elif N - nP > 0:
         spread(gaps, vr_ops, nP, nP + max(1, (N - nP) // 2))
         spread(gaps, two, nP, N)
         spread(gaps, dma, nP, N)
@@ -1512,6 +1565,9 @@ def main():
             QPOL = POLICY[int(sys.argv[sys.argv.index("--qpol") + 1])]
         if "--cpol" in sys.argv:
             CPOL = POLICY[int(sys.argv[sys.argv.index("--cpol") + 1])]
+        if "--balance" in sys.argv:
+            global BALANCE
+            BALANCE = int(sys.argv[sys.argv.index("--balance") + 1])
         if "--nt" in sys.argv:
             global NT
             NT = int(sys.argv[sys.argv.index("--nt") + 1])
