@@ -195,3 +195,41 @@ def test_bench_runs_with_two_gloo_ranks(tmp_path):
     assert d["config3"]["finite"] is True and d["config3"]["global_batch"] == 6
     c0, c1 = d["collective_counts"]
     assert c0 == c1 and c0["all_gather"] > 0 and c0["barrier"] > 0
+
+
+def test_sharded_pipeline_without_a_process_group():
+    """no process group: the plain pipeline (world 1, no collective), with its argument checks"""
+    from voice_activity_detection_amd.distributed import ShardedPipeline, collective_counts, forward_sharded_many
+
+    calls = []
+
+    def fwd(x, out):
+        calls.append(tuple(x.shape))
+        out.copy_(torch.log_softmax(x[..., :2], dim=-1))
+        return out
+
+    with pytest.raises(ValueError):
+        ShardedPipeline(forward=fwd, gather="sometimes")
+    with pytest.raises(ValueError):
+        ShardedPipeline()
+    sp = ShardedPipeline(forward=fwd, slots=2, depth=3, gather="step")
+    assert (sp.world, sp.rank, sp.distributed, sp.depth, sp.in_flight) == (1, 0, False, 3, 3)
+    before = collective_counts()
+    x = torch.randn(3, 5, 80)
+    sp.submit(x)
+    sp.submit(x + 1)
+    assert sp.pending == 2
+    with pytest.raises(RuntimeError):
+        sp.submit(x)                      # more batches than slots between two joins
+    with pytest.raises(RuntimeError):
+        sp.set_in_flight(1)               # ... and no retuning in between either
+    outs = sp.join()
+    assert len(outs) == 2 and tuple(outs[0].shape) == (1, 3, 5, 2) and sp.pending == 0 and sp.join() == []
+    assert torch.equal(outs[1][0], torch.log_softmax((x + 1)[..., :2], dim=-1))
+    sp.set_in_flight(1)
+    sp.set_gather("final")
+    ys = forward_sharded_many(sp, [x, x + 1, x + 2])      # three batches through two slots
+    assert len(ys) == 3 and torch.equal(ys[2], torch.log_softmax((x + 2)[..., :2], dim=-1))
+    sp.submit(torch.randn(4, 7, 80))       # another shape after a join: buffers follow
+    assert tuple(sp.join()[0].shape) == (1, 4, 7, 2)
+    assert collective_counts() == before
