@@ -544,14 +544,14 @@ __device__ __forceinline__ void wload_frag(WBlock& wb, const float* __restrict__
     const float* p = frag + (size_t)block * FRAG_BLOCK;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(wb.v[i]) : "v"(voff), "s"(p + (i >> 2) * 1024), "n"((i & 3) * 1024));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(wb.v[i]) : "v"(voff), "s"(p + (i >> 2) * 1024), "n"((i & 3) * 1024));
 }
 template <int PENDING>  // younger requests allowed to stay in flight (16 per block)
 __device__ __forceinline__ void wwait(WBlock& wb) {
     asm volatile("s_waitcnt vmcnt(%16)"
-                 : "+v"(wb.v[0]), "+v"(wb.v[1]), "+v"(wb.v[2]), "+v"(wb.v[3]), "+v"(wb.v[4]), "+v"(wb.v[5]), "+v"(wb.v[6]), "+v"(wb.v[7]),
-                   "+v"(wb.v[8]), "+v"(wb.v[9]), "+v"(wb.v[10]), "+v"(wb.v[11]), "+v"(wb.v[12]), "+v"(wb.v[13]), "+v"(wb.v[14]),
-                   "+v"(wb.v[15])
+                 : "+a"(wb.v[0]), "+a"(wb.v[1]), "+a"(wb.v[2]), "+a"(wb.v[3]), "+a"(wb.v[4]), "+a"(wb.v[5]), "+a"(wb.v[6]), "+a"(wb.v[7]),
+                   "+a"(wb.v[8]), "+a"(wb.v[9]), "+a"(wb.v[10]), "+a"(wb.v[11]), "+a"(wb.v[12]), "+a"(wb.v[13]), "+a"(wb.v[14]),
+                   "+a"(wb.v[15])
                  : "n"(PENDING));
 }
 
@@ -746,12 +746,16 @@ __global__ __launch_bounds__(256, 1) void row_kernel(
         wmma_k128(a, wa, xg);
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
-        // the next W1 slice, or the next layer's query block; the LAST launch re-reads a block it will not use (keeps
-        // the wait count uniform)
+        // the next W1 slice, or the next layer's query block; the LAST launch re-reads a block it will not use (keeps the
+        // wait count uniform and the loop free of branches: a request in one arm of a branch makes the compiler copy blocks
+        // that are still in flight where the arms meet)
         wload_frag(wa, (ch + 1 < 4 || LAST) ? frag : nfrag, ch + 1 < 4 ? 16 + 4 * w + ch + 1 : w, voff);
         wwait<16>(wb);
         wmma_w2(o, wb, a);
     }
+    // ... but it WAITS for that block: a request left in flight lands on whatever the compiler keeps in those registers by
+    // then (round 4: one wrong 32-row tile in a few percent of the runs with other streams' kernels pressing on the L2)
+    if (LAST) wwait<0>(wa);
     SAVAD_STAMP(35);
     // reduce-scatter the 4 K-split partials: wave w ends up with feature block w
     f32x16 own = o[0];
@@ -1020,7 +1024,7 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.0f);
             // the next W1 slice, or the next layer's query block; behind the last layer the stream simply re-reads a
-            // block it will not use (keeps the wait count uniform)
+            // block it will not use (keeps the wait count uniform; waited for behind the layer loop)
             wload_frag(wa, ch + 1 < 4 ? frag : nfrag, ch + 1 < 4 ? 16 + 4 * w + ch + 1 : w, voff);
             SAVAD_STAMP(43);
             wwait<16>(wb);
@@ -1048,6 +1052,7 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
         own += h1;  // residual onto the un-normalised stream (transformer.py:235-237)
         SAVAD_STAMP(57);
     }
+    wwait<0>(wa);  // the block requested behind the last layer is never used, but must not land on reused registers (see row_kernel)
     // ---- final LayerNorm (folded into the classifier) + Linear(D, 2) + log-softmax (self_attention.py:26-28)
     store_block(xb0 + m * XLD + 32 * w, own, h);
     __syncthreads();
