@@ -29,11 +29,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, batch, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def _worker(rank, world, rendezvous, batch, out_dir):
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
     from oracle import torch_port
     from voice_activity_detection_amd.distributed import forward_sharded
     from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
@@ -58,7 +56,7 @@ def test_two_rank_gloo_matches_unsharded(tmp_path, batch):
     from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
 
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), batch, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, str(tmp_path / "rendezvous"), batch, str(tmp_path)), nprocs=world, join=True)
     state = {k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()}
     ref = torch_port.forward(state, torch.from_numpy(seeded_features(3, (batch, 9, 80)))).numpy()
     for r in range(world):
@@ -69,11 +67,9 @@ def test_two_rank_gloo_matches_unsharded(tmp_path, batch):
     assert sum(sizes) == batch and max(sizes) - min(sizes) <= 1
 
 
-def _stream_worker(rank, world, port, n_frames, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def _stream_worker(rank, world, rendezvous, n_frames, out_dir):
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
     from oracle import oracle, torch_port
     from voice_activity_detection_amd.distributed import sharded_rows
     from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
@@ -109,7 +105,7 @@ def test_two_rank_streaming_shard_and_merge(tmp_path, n_frames):
     from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
 
     world, T, hop = 2, 24, 12
-    mp.spawn(_stream_worker, args=(world, _free_port(), n_frames, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_stream_worker, args=(world, str(tmp_path / "rendezvous"), n_frames, str(tmp_path)), nprocs=world, join=True)
     ref_probs, ref_logp = oracle.predict_streaming(seeded_state_dict(1234), seeded_features(5, (n_frames, 80)), T=T, hop=hop)
     W = ref_logp.shape[0]
     covered = []
@@ -126,11 +122,9 @@ def test_two_rank_streaming_shard_and_merge(tmp_path, n_frames):
 
 
 # ---- the multi-batch form: ShardedPipeline / forward_sharded_many ------------------------------------------------------------
-def _pipeline_worker(rank, world, port, batch, gather, depth, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def _pipeline_worker(rank, world, rendezvous, batch, gather, depth, out_dir):
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
     from oracle import torch_port
     from voice_activity_detection_amd.distributed import ShardedPipeline, collective_counts, forward_sharded_many
     from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
@@ -160,7 +154,7 @@ def test_two_rank_sharded_pipeline_matches_unsharded(tmp_path, batch, gather, de
     from voice_activity_detection_amd.seeded import seeded_features, seeded_state_dict
 
     world = 2
-    mp.spawn(_pipeline_worker, args=(world, _free_port(), batch, gather, depth, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_pipeline_worker, args=(world, str(tmp_path / "rendezvous"), batch, gather, depth, str(tmp_path)), nprocs=world, join=True)
     state = {k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()}
     ref = np.stack([torch_port.forward(state, torch.from_numpy(seeded_features(20 + i, (batch, 9, 80)))).numpy() for i in range(5)])
     for r in range(world):
@@ -180,10 +174,13 @@ def test_bench_runs_with_two_gloo_ranks(tmp_path):
     from pathlib import Path
 
     repo = Path(__file__).resolve().parent.parent
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(repo / "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-forward",
-           "--steps", "3", "--warmup", "1", "--min-seconds", "0.01", "--batch", "2", "--frames", "40", "--config3-shape", "3,24"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    for attempt in range(3):   # the driver's own command line (a fixed --master-port): a port picked here can be gone by the time it is bound
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), str(repo / "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-forward",
+               "--steps", "3", "--warmup", "1", "--min-seconds", "0.01", "--batch", "2", "--frames", "40", "--config3-shape", "3,24"]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        if res.returncode == 0 or "EADDRINUSE" not in res.stderr and "address already in use" not in res.stderr.lower():
+            break
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
