@@ -11,14 +11,19 @@ weight block they never waited for and the registers were reused for the reduce-
 registers of a requested block in AGPRs before its wait on the key-split path) and showed up only when other streams' kernels
 made the weight loads miss the L2 -- as one wrong 32-row tile in a few percent of the runs of one GPU test.
 
-The check walks every path of every kernel's control-flow graph (path-sensitive, states memoised per basic block) with the
-queue of vector-memory loads in flight, retires them as the `s_waitcnt vmcnt(N)` on the path allow (loads return in order;
-stores are ignored, which can only keep a load "in flight" longer than it really is), and reports every instruction that reads
-or writes a register an asm-issued load has not yet delivered.  Compiler-issued loads are only counted (the compiler waits for
-its own).  tests/test_async_load_hazards.py runs it on the kernels in the tree.
+The check runs a data flow over every kernel's control-flow graph: per load that may be in flight, how many vector-memory
+operations were issued after it; `s_waitcnt vmcnt(N)` retires the loads at distance >= N (loads return in order); where paths
+meet a load keeps its smallest distance (exact per load over all paths, infeasible ones included).  Every instruction that reads
+or writes a register of a load still in flight is reported (a younger LOAD into the same register is ordered by the in-order
+return and is not).  On compiler assembly only asm-issued loads are checked and stores are ignored (the stricter reading for
+hand-placed waits); on the disassembly of a built library (--lib: the artifact that ships) every load is -- the compiler's own
+code passes because it waits before it touches a destination -- with stores in the queue, as the compiler's waits assume.
+tests/test_async_load_hazards.py runs the --lib form on the library in the tree; both forms report the same 531 / 56 / 464
+accesses for `row_kernel<true>` / `row_kernel<false>` / `packed_forward_kernel` as they were before the fix.
 
     python scripts/check_async_loads.py             # compiles csrc/savad.hip to assembly (cached by source hash) and checks it
     python scripts/check_async_loads.py --asm f.s   # checks an assembly file
+    python scripts/check_async_loads.py --lib voice_activity_detection_amd/libsavad.so   # the device code of the built library itself
 """
 from __future__ import annotations
 
@@ -35,6 +40,7 @@ CSRC = REPO / "voice_activity_detection_amd" / "csrc"
 
 _REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 _LOAD = re.compile(r"^(global_load|buffer_load|flat_load|scratch_load)")
+_STORE = re.compile(r"^(global_store|buffer_store|flat_store|scratch_store|global_atomic|buffer_atomic|flat_atomic)")
 _LABEL = re.compile(r"^([.\w$]+):")
 
 
@@ -49,19 +55,20 @@ def regs(text: str) -> frozenset:
 
 
 class Insn:
-    __slots__ = ("line", "text", "op", "in_asm", "is_load", "dst", "touched", "vmcnt", "target", "kind")
+    __slots__ = ("line", "text", "op", "in_asm", "is_load", "is_store", "dst", "touched", "vmcnt", "target", "kind")
 
     def __init__(self, line: int, text: str, in_asm: bool):
         self.line, self.text, self.in_asm = line, text, in_asm
         self.op = text.split()[0]
         args = text[len(self.op):]
         self.is_load = bool(_LOAD.match(self.op))
+        self.is_store = bool(_STORE.match(self.op))
         self.dst = frozenset()
         if self.is_load and "lds" not in self.op and " lds" not in args:
             first = args.split(",")[0]
             self.dst = regs(first)
-            args_rest = ",".join(args.split(",")[1:])
-            self.touched = regs(args_rest) | self.dst
+            # (a load into the destination of an older load still in flight is ordered by the in-order return: only its address counts)
+            self.touched = regs(",".join(args.split(",")[1:]))
         else:
             self.touched = regs(args)
         self.vmcnt = None
@@ -75,7 +82,7 @@ class Insn:
         self.kind = "plain"
         if self.op == "s_branch":
             self.kind, self.target = "jump", args.strip()
-        elif self.op.startswith("s_cbranch"):
+        elif self.op.startswith("s_cbranch") or self.op == "s_call_b64":   # (a call: into the callee, whose s_setpc ends that path, and past it)
             self.kind, self.target = "cond", args.strip().split(",")[-1].strip()
         elif self.op in ("s_endpgm", "s_setpc_b64"):
             self.kind = "end"
@@ -113,52 +120,110 @@ def kernels(asm_text: str):
         yield sym, blocks
 
 
-def check_kernel(blocks, max_states: int = 200000):
-    """-> (hazards, truncated); a hazard is (line, text, line of the pending load, its text)"""
-    index = {label: k for k, (label, _) in enumerate(blocks)}
-    loads = {}
-    hazards = {}
-    seen = set()
-    work = [(0, ())]
-    while work:
-        k, state = work.pop()
-        if (k, state) in seen:
+def kernels_disassembly(dis_text: str):
+    """the same from `llvm-objdump -d --symbolize-operands --no-show-raw-insn` of a code object: no asm markers there, so EVERY
+    vector-memory load is checked (the compiler's own must pass as well: it waits before it reuses a destination)"""
+    fn = re.compile(r"^[0-9a-f]{16} <([^>]+)>:$")
+    blocks, cur, sym = [], None, None
+    for n, line in enumerate(dis_text.split("\n"), 1):
+        m = fn.match(line)
+        if m:
+            name = m.group(1)
+            if re.fullmatch(r"L\d+", name):
+                if cur is not None:
+                    blocks.append(cur)
+                    cur = (name, [])
+                continue
+            if sym is not None:
+                blocks.append(cur)
+                yield sym, blocks
+            sym, blocks, cur = name, [], (name, [])
             continue
-        if len(seen) >= max_states:
-            return sorted(hazards.values()), True
-        seen.add((k, state))
-        pending = list(state)   # (load line, is_asm) in issue order
+        if cur is None or not line.startswith("\t"):
+            continue
+        code = line.split("//")[0].strip()
+        if code:
+            cur[1].append(Insn(n, code, True))
+    if sym is not None:
+        blocks.append(cur)
+        yield sym, blocks
+
+
+def disassemble_library(lib: Path) -> str:
+    """device code of a built libsavad.so: .hip_fatbin -> the gfx950 code object -> llvm-objdump"""
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = Path(d) / "fat.bin", Path(d) / "dev.co"
+        subprocess.run([str(llvm / "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", str(lib), str(fat)], check=True)
+        listing = subprocess.run([str(llvm / "clang-offload-bundler"), "--list", "--type=o", f"--input={fat}"], check=True,
+                                 capture_output=True, text=True).stdout.split()
+        targets = [t for t in listing if "gfx950" in t]
+        if len(targets) != 1:
+            raise RuntimeError(f"{lib}: expected one gfx950 code object, found {listing}")
+        subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", f"--targets={targets[0]}",
+                        f"--output={co}"], check=True)
+        return subprocess.run([str(llvm / "llvm-objdump"), "-d", "--symbolize-operands", "--no-show-raw-insn", str(co)], check=True,
+                              capture_output=True, text=True).stdout
+
+
+def check_kernel(blocks, count_stores: bool = False):
+    """-> (hazards, truncated = False); a hazard is (line, text, line of the pending load, its text).
+
+    Data flow over the control-flow graph.  The state is, for every load that may be in flight, the number of vector-memory
+    operations issued after it (its distance from the young end of the queue): an issue adds one to every distance, and
+    `s_waitcnt vmcnt(N)` retires every load whose distance is >= N (loads return in order).  Where paths meet, a load keeps
+    its SMALLEST distance -- the path on which it is youngest is the one on which it stays in flight longest -- which makes the
+    result exact per load over all paths of the graph (infeasible ones included: conservative).
+    count_stores: stores and atomics take their place in the queue (gfx9 has one counter for both and the compiler's own waits
+    rely on their retiring in issue order); without it they are ignored, which is the stricter reading for hand-placed waits."""
+    index = {label: k for k, (label, _) in enumerate(blocks)}
+    loads, hazards = {}, {}
+    state_in = [None] * len(blocks)
+    state_in[0] = {}
+    work = [0]
+
+    def merge_into(k, st):
+        cur = state_in[k]
+        if cur is None:
+            state_in[k] = dict(st)
+            work.append(k)
+            return
+        changed = False
+        for key, r in st.items():
+            if cur.get(key, 1 << 30) > r:
+                cur[key] = r
+                changed = True
+        if changed:
+            work.append(k)
+
+    while work:
+        k = work.pop()
+        st = dict(state_in[k])
         ended = False
-        succ = []
         for ins in blocks[k][1]:
             if ins.vmcnt is not None:
-                if ins.vmcnt < len(pending):
-                    pending = pending[len(pending) - ins.vmcnt:] if ins.vmcnt else []
+                st = {key: r for key, r in st.items() if r < ins.vmcnt}
                 continue
-            for pl, is_asm in pending:
-                if is_asm and ins.touched & loads[pl].dst:
+            for pl in st:
+                if ins.touched & loads[pl].dst:
                     hazards.setdefault((ins.line, pl), (ins.line, ins.text, pl, loads[pl].text))
-            if ins.is_load:
-                loads[ins.line] = ins
-                pending.append((ins.line, ins.in_asm))
-                if len(pending) > 64:   # the counter saturates at 63: older ones must have been waited for by construction
-                    pending = pending[-64:]
+            if ins.is_load or (count_stores and ins.is_store):
+                st = {key: r + 1 for key, r in st.items() if r + 1 < 64}   # (the counter holds 63: older ones have returned)
+                if ins.is_load and ins.in_asm and ins.dst:
+                    loads[ins.line] = ins
+                    st[ins.line] = 0
             if ins.kind == "jump":
-                succ = [index[ins.target]] if ins.target in index else []
+                if ins.target in index:
+                    merge_into(index[ins.target], st)
                 ended = True
                 break
-            if ins.kind == "cond" and ins.target in index:
-                succ.append(index[ins.target])
+            if ins.kind == "cond" and ins.target in index:   # the taken edge leaves with the queue as it is HERE, not at the block's end
+                merge_into(index[ins.target], st)
             if ins.kind == "end":
                 ended = True
-                succ = []
                 break
         if not ended and k + 1 < len(blocks):
-            succ.append(k + 1)
-        st = tuple(pending)
-        for s in succ:
-            if (s, st) not in seen:
-                work.append((s, st))
+            merge_into(k + 1, st)
     return sorted(hazards.values()), False
 
 
@@ -189,22 +254,32 @@ def compile_asm(verbose: bool = False) -> Path:
 
 def check_file(path: Path):
     """-> {kernel symbol: (hazards, truncated)} for every kernel with asm-issued loads"""
+    return _check(kernels(path.read_text()), False)
+
+
+def check_library(lib: Path):
+    """the same for the device code inside a built library (every kernel with vector-memory loads, every load)"""
+    return _check(kernels_disassembly(disassemble_library(lib)), True)
+
+
+def _check(kernel_iter, count_stores):
     report = {}
-    for sym, blocks in kernels(path.read_text()):
+    for sym, blocks in kernel_iter:
         if not any(i.is_load and i.in_asm for _, b in blocks for i in b):
             continue
-        report[sym] = check_kernel(blocks)
+        report[sym] = check_kernel(blocks, count_stores=count_stores)
     return report
 
 
 def main() -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--asm", type=Path, help="assembly file to check (default: compile csrc/savad.hip)")
+    ap.add_argument("--lib", type=Path, help="check the device code inside this built library instead (all loads, not only asm-issued ones)")
     ap.add_argument("-v", "--verbose", action="store_true")
     args = ap.parse_args()
-    path = args.asm or compile_asm(args.verbose)
+    report = check_library(args.lib) if args.lib else check_file(args.asm or compile_asm(args.verbose))
     bad = 0
-    for sym, (hazards, truncated) in check_file(path).items():
+    for sym, (hazards, truncated) in report.items():
         print(f"{sym}: {len(hazards)} hazard(s)" + (" (path search truncated)" if truncated else ""))
         for line, text, pl, ptext in hazards[: (1000 if args.verbose else 8)]:
             print(f"    line {line}: {text}\n        touches the destination of line {pl}: {ptext}")
