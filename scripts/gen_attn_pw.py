@@ -68,6 +68,7 @@ V_E = {"A": 112, "B": 128}     # exponentials of the tile being normalised (fp32
 V_L = {"A": 144, "B": 145}     # this lane's half of the running row sums
 V_RS = {"A": 146, "B": 147}    # row sum of the current tile
 V_MX = {"A": 148, "B": 149}    # row maxima
+V_RSP = {"A": 172, "B": 174}   # --rowsum pk: the two halves of the packed row sum (aligned pairs; not in timing builds: V_ACC)
 V_T0, V_T1, V_T2, V_T3, V_T4, V_T5 = 150, 151, 152, 153, 154, 155
 V_LDSL = 156                   # LDS base + lane * 16
 V_KSADDR = 157                 # key-split items: LDS address of this wave's key block (K image; V^T image 16 KiB behind it)
@@ -141,6 +142,9 @@ def ctx_policy():
 QPOL = CPOL = None
 BALANCE = 0     # experiments (--balance N): 1 the first half of a step (K reads, exponentials, block A's row sum beside the PV MFMAs) is laid
                 # out by estimated ISSUE cost per MFMA gap instead of by instruction count; 2 the second half too
+ROWSUM = "seq"  # experiments (--rowsum pk): a tile's row sum as 7 packed adds (two exponentials per instruction, v_pk_add_f32) + 1 add
+                # instead of 15 sequential adds -- 14 VALU instructions less per wave and step; changes the summation order (the
+                # first-generation kernel's is the sequential one), so every row's low bits
 SEAM = True     # an ordinary item's last PV MFMAs / epilogue share their MFMA gaps with the NEXT item's Q move and S^T(0) (False: round 3)
 ABLATE = 0   # experiments (results WRONG): 1 no DMA pieces, 2 no barrier, 4 no row maxima / reference check, 8 no exp / sum / pack,
              # 16 no LDS operand reads
@@ -215,6 +219,16 @@ def softmax_ops(buf, blk):
     e_r = 2^s_r ; rs = ((e_0 + e_1) + e_2) + ... (sequential, as attention_kernel_bf16) ; l += rs ; P = bf16(e)."""
     S, E, P, RS = V_S[(buf, blk)], V_E[blk], V_P[blk], V_RS[blk]
     ops = [f"v_exp_f32 {vr(E + r)}, {vr(S + r)}" for r in range(16)]
+    if ROWSUM == "pk":   # (e_0 + e_2 + ... + e_14) + (e_1 + e_3 + ... + e_15), the two chains side by side in one register pair
+        assert not TIMING, "--rowsum pk uses the timing builds' accumulator register"
+        R2 = V_RSP[blk]
+        for k in range(1, 8):
+            ops.append(f"v_pk_add_f32 {vr(R2, 2)}, {vr(E, 2) if k == 1 else vr(R2, 2)}, {vr(E + 2 * k, 2)}")
+        ops.append(f"v_add_f32 {vr(RS)}, {vr(R2)}, {vr(R2 + 1)}")
+        for k in range(8):
+            ops.append(f"v_cvt_pk_bf16_f32 {vr(P + k)}, {vr(E + 2 * k)}, {vr(E + 2 * k + 1)}")
+        ops.append(f"v_add_f32 {vr(V_L[blk])}, {vr(V_L[blk])}, {vr(RS)}")
+        return ops  # 16 + 8 + 8 + 1 = 33
     for r in range(1, 16):
         ops.append(f"v_add_f32 {vr(RS)}, {vr(E) if r == 1 else vr(RS)}, {vr(E + r)}")
         if r % 2 == 1:
@@ -1577,6 +1591,10 @@ def main():
         if "--no-attach" in sys.argv:
             global ATTACH
             ATTACH = False
+        if "--rowsum" in sys.argv:
+            global ROWSUM
+            ROWSUM = sys.argv[sys.argv.index("--rowsum") + 1]
+            assert ROWSUM in ("seq", "pk")
         if "--split-max" in sys.argv:
             global SPLIT_MAX
             SPLIT_MAX = int(sys.argv[sys.argv.index("--split-max") + 1])

@@ -500,6 +500,18 @@ class Workgroup:
                      "v_min_f32": _fmin}[op](a, b)
             self.wrv(w, o[0], r.astype(np.float32))
             return None
+        if op in ("v_pk_add_f32", "v_pk_mul_f32"):   # two fp32 per lane in an aligned register pair (default op_sel: low with low, high with high)
+            for o_ in o[:3]:
+                if o_.kind != "v" or o_.n != 2 or o_.base % 2:
+                    raise SimError(f"{ins.text}: packed fp32 operands are aligned VGPR pairs here")
+            self._check_read(w, ins, o[1])
+            self._check_read(w, ins, o[2])
+            fn = np.add if op == "v_pk_add_f32" else np.multiply
+            with np.errstate(all="ignore"):
+                res = [fn(u2f(w.v[o[1].base + h]), u2f(w.v[o[2].base + h])).astype(np.float32) for h in range(2)]
+            for h in range(2):
+                self.wrv(w, o[0], res[h], idx=h)
+            return None
         if op == "v_max3_f32":
             self.wrv(w, o[0], _fmax(_fmax(F(w, ins, o[1]), F(w, ins, o[2])), F(w, ins, o[3])).astype(np.float32))
             return None

@@ -38,3 +38,23 @@ def test_generated_stream_on_the_functional_model(B, T, grid, scale, nan_pad):
         assert hits.get(".Lpw_ks_item", 0) == 4 * B        # one key-split item per sequence, four waves each
     if scale > 1:
         assert hits.get(".Lpw_coldmid_0_0_1", 0) > 0       # the key-split waves moved their references too
+
+
+@pytest.mark.parametrize("B,T,grid,scale,nan_pad", [CASES[0], CASES[3], CASES[4]])
+def test_packed_row_sum_variant_on_the_functional_model(tmp_path, B, T, grid, scale, nan_pad):
+    """`gen_attn_pw.py --rowsum pk` (an experiment that waits for its GPU A/B: a tile's row sum as 7 v_pk_add_f32 + 1 add instead of 15
+    sequential adds, 14 VALU instructions less per wave and step): the same checks as the product stream, and fewer instructions"""
+    import subprocess
+
+    import pw_sim
+
+    inc = tmp_path / "pk.inc"
+    subprocess.run([sys.executable, str(Path(pw_sim.__file__).with_name("gen_attn_pw.py")), "--rowsum", "pk", "--out", str(inc)], check=True)
+    text = inc.read_text()
+    assert text.count("v_pk_add_f32") > 200
+    r = pw_sim.simulate(B, T, grid=grid, scale=scale, seed=B + T, nan_pad=nan_pad, strict=True, inc_text=text)
+    assert r["finite"] and r["pad_zero"]
+    assert np.abs(r["ctx"] - r["ref"]).max() < 0.03
+    base = pw_sim.simulate(B, T, grid=grid, scale=scale, seed=B + T, nan_pad=nan_pad, strict=True)
+    assert np.abs(r["ctx"] - base["ctx"]).max() < 4e-3          # one bf16 ulp of a context value at most: only the summation order moved
+    assert sum(sum(s["instr"]) for s in r["stats"]) < sum(sum(s["instr"]) for s in base["stats"])
