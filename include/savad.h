@@ -191,6 +191,24 @@ int savad_overlap_merge(const float* logp, int W, int N, int T, int hop, float* 
 int savad_logmel_frames(int n_samples);
 size_t savad_logmel_workspace_bytes(int n_samples);
 int savad_logmel(const float* audio, int n_samples, float* workspace, float* features, void* stream);
+/* The same for a SPAN of the frames -- what one rank of a sharded run computes (each rank only the frames its
+ * windows cover).  audio points at sample audio_first of a signal of n_samples samples and holds audio_count of them;
+ * frames [frame_first, frame_first + frame_count) are written to features[frame_count][80].  The slice must hold the
+ * samples savad_logmel_span_samples names for these frames (160 f - 208 .. 160 f + 207 of every frame, plus the
+ * mirrored stretch when the span touches an end of the signal: centre=True, reflect padding); *first is a multiple of
+ * 4, so that a slice cut there keeps the 16-byte alignment of the direct reads (any other slice is copied first).
+ * workspace: savad_logmel_span_workspace_bytes(frame_count) bytes, 16-byte aligned. */
+int savad_logmel_span_samples(long n_samples, int frame_first, int frame_count, long* first, long* count);
+size_t savad_logmel_span_workspace_bytes(int frame_count);
+int savad_logmel_span(const float* audio, long audio_first, long audio_count, long n_samples, int frame_first,
+                      int frame_count, float* workspace, float* features, void* stream);
+/* Experiments and tests: algorithm 0 (default) = the STFT as a factored DFT (512 = 32 x 16, two small GEMMs with the
+ * twiddles folded into the second), 1 = the DFT as one GEMM (rounds 1-4; whole-signal calls only).  Process-wide.
+ * savad_logmel_tables_host copies the factored kernel's three A-operand tables (savad_logmel_table_floats(0..2)
+ * floats each) to HOST memory: the CPU suite replays the kernel's data flow on them against the oracle. */
+int savad_logmel_set_algorithm(int algorithm);
+int savad_logmel_table_floats(int which);
+int savad_logmel_tables_host(float* t1, float* t3, float* tm);
 
 /* Post-processing of the predict path (next-row 3 of the scope table); HOST pointers.
  * savad_trim_voice_activity  : vad/postprocessing/trim.py:4-66 (valley fill, hill flatten, hang before/over; the

@@ -50,6 +50,12 @@ SYMBOLS = {
     "savad_logmel_frames": (c_int, [c_int]),
     "savad_logmel_workspace_bytes": (c_size_t, [c_int]),
     "savad_logmel": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "savad_logmel_span_samples": (c_int, [c_long, c_int, c_int, POINTER(c_long), POINTER(c_long)]),
+    "savad_logmel_span_workspace_bytes": (c_size_t, [c_int]),
+    "savad_logmel_span": (c_int, [c_void_p, c_long, c_long, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "savad_logmel_set_algorithm": (c_int, [c_int]),
+    "savad_logmel_table_floats": (c_int, [c_int]),
+    "savad_logmel_tables_host": (c_int, [c_void_p, c_void_p, c_void_p]),
     "savad_trim_voice_activity": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "savad_frames_to_samples": (c_long, [c_void_p, c_int, c_int, c_double, c_double, c_void_p]),
     "savad_samples_to_segments": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int]),

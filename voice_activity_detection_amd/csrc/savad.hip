@@ -1322,11 +1322,16 @@ SAVAD_EXPORT int savad_overlap_merge(const float* logp, int W, int N, int T, int
 namespace {
 
 struct MelTables {
-    float* d_dft = nullptr;
+    float* d_dft = nullptr;  // DFT-as-GEMM kernel (algorithm 1)
     float* d_mel = nullptr;
+    float* d_t1 = nullptr;  // factored kernel (algorithm 0)
+    float* d_t3 = nullptr;
+    float* d_tm = nullptr;
+    int n_cu = 0;
 };
 std::mutex g_mel_mutex;
-std::map<int, MelTables> g_mel_by_device;  // built once per device, never freed (process lifetime, 0.9 MB)
+std::map<int, MelTables> g_mel_by_device;  // built once per device, never freed (process lifetime, 1.1 MB)
+int g_logmel_algorithm = 0;
 
 double hz_to_mel(double f) {  // Slaney scale (librosa htk=False)
     const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
@@ -1335,6 +1340,112 @@ double hz_to_mel(double f) {  // Slaney scale (librosa htk=False)
 double mel_to_hz(double mm) {
     const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
     return mm >= min_log_mel ? min_log_hz * exp(logstep * (mm - min_log_mel)) : f_sp * mm;
+}
+
+// Slaney mel filterbank (librosa.filters.mel, norm="slaney", float32): M[mel][bin], 80 x 257
+std::vector<float> mel_filterbank() {
+    using namespace mel;
+    const int NB = N_FFT / 2 + 1;
+    std::vector<double> mel_f(N_MELS + 2);
+    const double m_lo = hz_to_mel(0.0), m_hi = hz_to_mel(8000.0);
+    for (int i = 0; i < N_MELS + 2; ++i) mel_f[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (N_MELS + 1));
+    std::vector<float> M((size_t)N_MELS * NB, 0.0f);
+    for (int i = 0; i < N_MELS; ++i) {
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int b = 0; b < NB; ++b) {
+            const double fr = 8000.0 * b / (NB - 1);
+            const double lower = (fr - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+            const double upper = (mel_f[i + 2] - fr) / (mel_f[i + 2] - mel_f[i + 1]);
+            const double wgt = fmax(0.0, fmin(lower, upper));
+            M[(size_t)i * NB + b] = (float)wgt * (float)enorm;
+        }
+    }
+    return M;
+}
+
+// A operands of logmel_fft_kernel (layouts: savad_logmel.h).  Pure host code; false when a filter weight falls outside
+// the kernel's fixed (register pair -> mel block) pattern, which would be a bug in the bin ordering.
+bool build_fft_tables(std::vector<float>& t1, std::vector<float>& t3, std::vector<float>& tm) {
+    using namespace mel;
+    const double PI = 3.14159265358979323846;
+    const int NB = N_FFT / 2 + 1;
+    t1.assign(FFT_T1_FLOATS, 0.0f);
+    t3.assign(FFT_T3_FLOATS, 0.0f);
+    tm.assign(FFT_TM_FLOATS, 0.0f);
+    // step 1: row i = lane & 31 of the output tile is (k1 = 4 (i >> 3) + (i & 3), re | im = (i >> 2) & 1); k-step s of
+    // lane half h is n1 = 3 + 2 s + h; the slot of im(k1 = 0) carries re(k1 = 16)
+    for (int w = 0; w < 4; ++w)
+        for (int s = 0; s < 13; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int i = lane & 31, h = lane >> 5, n1 = 3 + 2 * s + h, n2 = 4 * w + e, n = 16 * n1 + n2;
+                    int k1 = 4 * (i >> 3) + (i & 3);
+                    bool im = (i >> 2) & 1;
+                    if (k1 == 0 && im) {
+                        k1 = 16;
+                        im = false;
+                    }
+                    float win = 0.0f;
+                    if (n >= LPAD && n < LPAD + WIN) win = (float)(0.5 - 0.5 * cos(2.0 * PI * (n - LPAD) / WIN));  // periodic Hann(400), float32 as librosa's
+                    const double ph = 2.0 * PI * (double)(n1 * k1 % 32) / 32.0;
+                    t1[(((size_t)w * 13 + s) * 64 + lane) * 4 + e] = (float)(win * (im ? -sin(ph) : cos(ph)));
+                }
+    // bins of a group, lowest first.  kind 0: bin K = 32 k2 from Y[0] (real, low lane half); kind 1: K = 16 + 32 k2 from
+    // Y[16] (real, high lane half); kind 2: K = k1 + 32 k2 from the complex Y[k1].  label = the bin below 257 with the same power.
+    struct Bin {
+        int kind, K, label;
+    };
+    std::vector<std::vector<Bin>> groups(16);
+    for (int grp = 0; grp < 16; ++grp) {
+        std::vector<Bin>& g = groups[grp];
+        if (grp == 0) {
+            for (int k2 = 1; k2 < 8; ++k2) g.push_back({0, 32 * k2, 32 * k2});
+            for (int k2 = 0; k2 < 8; ++k2) g.push_back({1, 16 + 32 * k2, 16 + 32 * k2});
+        } else {
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const int K = grp + 32 * k2;
+                g.push_back({2, K, K <= 256 ? K : 512 - K});
+            }
+        }
+        for (size_t a = 1; a < g.size(); ++a)  // insertion sort by label
+            for (size_t b = a; b > 0 && g[b].label < g[b - 1].label; --b) std::swap(g[b], g[b - 1]);
+    }
+    // step 3: row i of the output tile is (register pair p = 2 (i >> 3) + ((i & 3) >> 1), lane half hD = (i >> 2) & 1,
+    // re | im = i & 1) = bin number 2 p + hD of the group; k-step n2 of lane half h multiplies re (h = 0) / im (h = 1) of Y
+    for (int grp = 0; grp < 16; ++grp)
+        for (int n2 = 0; n2 < 16; ++n2)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5;
+                const int p = 2 * (i >> 3) + ((i & 3) >> 1), hD = (i >> 2) & 1, ro = i & 1, idx = 2 * p + hD;
+                float v = 0.0f;
+                if (idx < (int)groups[grp].size()) {
+                    const Bin& b = groups[grp][idx];
+                    const double th = 2.0 * PI * (double)((long)n2 * b.K % N_FFT) / N_FFT, c = cos(th), sn = sin(th);
+                    // X = sum (Yre + i Yim)(c - i sn):  re = Yre c + Yim sn,  im = Yim c - Yre sn
+                    if (b.kind == 2)
+                        v = (float)(h == 0 ? (ro == 0 ? c : -sn) : (ro == 0 ? sn : c));
+                    else if (b.kind == h)
+                        v = (float)(ro == 0 ? c : -sn);
+                }
+                t3[(((size_t)grp * 4 + (n2 >> 2)) * 64 + lane) * 4 + (n2 & 3)] = v;
+            }
+    // mel: entry t of a group = (pair, mel block) in the kernel's fixed order
+    static const int PAIR[10] = {0, 1, 1, 2, 3, 4, 4, 5, 6, 7}, BLOCK[10] = {0, 0, 1, 1, 1, 1, 2, 2, 2, 2};
+    const std::vector<float> M = mel_filterbank();
+    std::vector<char> covered((size_t)N_MELS * NB, 0);
+    for (int grp = 0; grp < 16; ++grp)
+        for (int t = 0; t < 10; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int j = lane & 31, h = lane >> 5, idx = 2 * PAIR[t] + h, ml = 32 * BLOCK[t] + j;
+                if (idx < (int)groups[grp].size() && ml < N_MELS) {
+                    const int label = groups[grp][idx].label;
+                    tm[(((size_t)grp * 3 + (t >> 2)) * 64 + lane) * 4 + (t & 3)] = M[(size_t)ml * NB + label];
+                    covered[(size_t)ml * NB + label] = 1;
+                }
+            }
+    for (size_t q = 0; q < M.size(); ++q)
+        if (M[q] != 0.0f && !covered[q]) return false;
+    return true;
 }
 
 int ensure_mel_tables(hipStream_t st, MelTables* out) {
@@ -1368,22 +1479,8 @@ int ensure_mel_tables(hipStream_t st, MelTables* out) {
                     const double ph = 2.0 * PI * (double)((long)bin * kp % N_FFT) / N_FFT;
                     dft[(((size_t)rb * KG + G) * 64 + lane) * 4 + e] = (float)((float)win * (im ? -sin(ph) : cos(ph)));
                 }
-    // Slaney mel filterbank (librosa.filters.mel, norm="slaney", float32)
     const int NB = N_FFT / 2 + 1;
-    std::vector<double> mel_f(N_MELS + 2);
-    const double m_lo = hz_to_mel(0.0), m_hi = hz_to_mel(8000.0);
-    for (int i = 0; i < N_MELS + 2; ++i) mel_f[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (N_MELS + 1));
-    std::vector<float> M((size_t)N_MELS * NB, 0.0f);
-    for (int i = 0; i < N_MELS; ++i) {
-        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
-        for (int b = 0; b < NB; ++b) {
-            const double fr = 8000.0 * b / (NB - 1);
-            const double lower = (fr - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
-            const double upper = (mel_f[i + 2] - fr) / (mel_f[i + 2] - mel_f[i + 1]);
-            const double wgt = fmax(0.0, fmin(lower, upper));
-            M[(size_t)i * NB + b] = (float)wgt * (float)enorm;
-        }
-    }
+    const std::vector<float> M = mel_filterbank();
     // mel fragments [pass 4][mel block 3][row block 4][g pair 2][lane 64][4]; element e -> g = 2gp + (e>>1), bin
     // 64 pass + 16 rbl + 4 g + 2 h + (e&1).  Bins 0 and 256 have zero weight in every filter (fmin 0, fmax 8 kHz).
     std::vector<float> melf((size_t)MEL_FRAG_FLOATS, 0.0f);
@@ -1400,23 +1497,135 @@ int ensure_mel_tables(hipStream_t st, MelTables* out) {
                             if (ml_ < N_MELS && bin >= 1 && bin < 256) v = M[(size_t)ml_ * NB + bin];
                             melf[(((((size_t)pass * 3 + mb) * 4 + rbl) * 2 + gp) * 64 + lane) * 4 + e] = v;
                         }
-    HIP_TRY(hipMalloc(&g_mel.d_dft, dft.size() * sizeof(float)));
-    HIP_TRY(hipMalloc(&g_mel.d_mel, melf.size() * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(g_mel.d_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(g_mel.d_mel, melf.data(), melf.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    std::vector<float> t1, t3, tm;
+    if (!build_fft_tables(t1, t3, tm)) return fail(SAVAD_E_STATE, "log-mel tables: a filter weight falls outside the kernel's pair -> mel block pattern");
+    HIP_TRY(hipDeviceGetAttribute(&g_mel.n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mel::logmel_fft_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, mel::FFT_LDS_BYTES));
+    float* base = nullptr;  // one allocation: every table starts 256-byte aligned
+    auto up = [](size_t n) { return (n + 63) / 64 * 64; };
+    const size_t total = up(dft.size()) + up(melf.size()) + up(t1.size()) + up(t3.size()) + up(tm.size());
+    HIP_TRY(hipMalloc(&base, total * sizeof(float)));
+    size_t off = 0;
+    auto put = [&](const std::vector<float>& v, float** d) -> hipError_t {
+        *d = base + off;
+        off += up(v.size());
+        return hipMemcpyAsync(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, st);
+    };
+    HIP_TRY(put(dft, &g_mel.d_dft));
+    HIP_TRY(put(melf, &g_mel.d_mel));
+    HIP_TRY(put(t1, &g_mel.d_t1));
+    HIP_TRY(put(t3, &g_mel.d_t3));
+    HIP_TRY(put(tm, &g_mel.d_tm));
     HIP_TRY(hipStreamSynchronize(st));
     g_mel_by_device[dev] = g_mel;
     *out = g_mel;
     return SAVAD_OK;
 }
 
+// samples [first, first + count) of the signal that frames [frame_first, frame_first + frame_count) read, reflections
+// at the signal's ends included; first is rounded down to a multiple of 4 (16-byte alignment of the direct reads)
+void span_samples(long n, int frame_first, int frame_count, long* first, long* count) {
+    const long lo = (long)mel::HOP * frame_first - 208, hi = (long)mel::HOP * (frame_first + frame_count - 1) + 208;  // [lo, hi)
+    long a = lo < 0 ? 0 : lo, b = hi > n ? n : hi;
+    if (lo < 0 && -lo + 1 > b) b = -lo + 1;
+    if (hi > n && 2 * (n - 1) - (hi - 1) < a) a = 2 * (n - 1) - (hi - 1);
+    if (a < 0) a = 0;
+    if (b > n) b = n;
+    a &= ~3L;
+    *first = a;
+    *count = b - a;
+}
+
 }  // namespace
 
 SAVAD_EXPORT int savad_logmel_frames(int n_samples) { return n_samples < 0 ? fail(SAVAD_E_INVALID, "n_samples") : 1 + n_samples / mel::HOP; }
 SAVAD_EXPORT size_t savad_logmel_workspace_bytes(int n_samples) { return ((size_t)n_samples + mel::N_FFT + 64) * sizeof(float); }
+SAVAD_EXPORT size_t savad_logmel_span_workspace_bytes(int frame_count) {
+    return ((size_t)mel::HOP * (frame_count > 0 ? frame_count : 0) + mel::N_FFT + 64 + 2048) * sizeof(float);
+}
+SAVAD_EXPORT int savad_logmel_set_algorithm(int algorithm) {
+    if (algorithm < 0 || algorithm > 1) return fail(SAVAD_E_INVALID, "log-mel algorithm %d (0 = factored DFT, 1 = DFT as one GEMM)", algorithm);
+    g_logmel_algorithm = algorithm;
+    return SAVAD_OK;
+}
+SAVAD_EXPORT int savad_logmel_table_floats(int which) {
+    return which == 0 ? mel::FFT_T1_FLOATS : which == 1 ? mel::FFT_T3_FLOATS : which == 2 ? mel::FFT_TM_FLOATS : fail(SAVAD_E_INVALID, "table %d", which);
+}
+SAVAD_EXPORT int savad_logmel_tables_host(float* t1, float* t3, float* tm) {
+    if (!t1 || !t3 || !tm) return fail(SAVAD_E_INVALID, "null argument");
+    std::vector<float> a, b, c;
+    if (!build_fft_tables(a, b, c)) return fail(SAVAD_E_STATE, "log-mel tables: a filter weight falls outside the kernel's pair -> mel block pattern");
+    memcpy(t1, a.data(), a.size() * sizeof(float));
+    memcpy(t3, b.data(), b.size() * sizeof(float));
+    memcpy(tm, c.data(), c.size() * sizeof(float));
+    return SAVAD_OK;
+}
+SAVAD_EXPORT int savad_logmel_span_samples(long n_samples, int frame_first, int frame_count, long* first, long* count) {
+    if (!first || !count || n_samples < 1 || frame_first < 0 || frame_count < 1 || frame_first + (long)frame_count > 1 + n_samples / mel::HOP)
+        return fail(SAVAD_E_INVALID, "bad frame span [%d, +%d) of %ld samples", frame_first, frame_count, n_samples);
+    span_samples(n_samples, frame_first, frame_count, first, count);
+    return SAVAD_OK;
+}
+
+SAVAD_EXPORT int savad_logmel_span(const float* audio, long audio_first, long audio_count, long n_samples, int frame_first,
+                                   int frame_count, float* workspace, float* features, void* stream) {
+    if (!audio || !workspace || !features || n_samples < 1 || n_samples > 2000000000L || audio_first < 0 || audio_count < 1 ||
+        audio_first + audio_count > n_samples)
+        return fail(SAVAD_E_INVALID, "bad argument");
+    if (frame_first < 0 || frame_count < 1 || frame_first + (long)frame_count > 1 + n_samples / mel::HOP)
+        return fail(SAVAD_E_INVALID, "frames [%d, +%d) outside the %ld frames of %ld samples", frame_first, frame_count, 1 + n_samples / mel::HOP, n_samples);
+    if (((uintptr_t)workspace | (uintptr_t)features) & 15) return fail(SAVAD_E_INVALID, "workspace and features must be 16-byte aligned");
+    long need_first, need_count;
+    span_samples(n_samples, frame_first, frame_count, &need_first, &need_count);
+    if (audio_first > need_first + 3 || audio_first + audio_count < need_first + need_count)  // (+3: need_first was rounded down)
+        return fail(SAVAD_E_INVALID, "frames [%d, +%d) read samples [%ld, +%ld); the audio slice holds [%ld, +%ld)", frame_first, frame_count,
+                    need_first, need_count, audio_first, audio_count);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    MelTables g_mel;
+    if ((rc = ensure_mel_tables(st, &g_mel))) return rc;
+    const float* y0 = audio - audio_first;  // y0[i] = sample i (only indices inside the slice are ever read)
+    const int f_end = frame_first + frame_count;
+    mel::FftSrc src{};
+    mel::PadSeg A{workspace, 0, 0}, B{workspace + 1024, 0, 0};
+    src.y0 = y0;
+    const bool direct = n_samples >= 4096 && (((uintptr_t)audio - (uintptr_t)audio_first * 4u) & 15) == 0;
+    if (direct) {
+        src.f_lo = 2;
+        src.f_hi = (int)((n_samples - 207 + mel::HOP - 1) / mel::HOP);  // first frame that reads past the last sample
+        if (frame_first < 2) A.count = mel::HOP + mel::N_FFT + mel::HOP;  // padded indices [0, 832): frames 0 and 1
+        const int fb = frame_first > src.f_hi ? frame_first : src.f_hi;
+        if (fb < f_end) {
+            B.j0 = (long)mel::HOP * fb;
+            B.count = mel::HOP * (f_end - 1 - fb) + mel::N_FFT;  // at most 3 frames
+        }
+    } else {  // the whole span from a padded copy
+        src.f_lo = 0x7fffffff;
+        src.f_hi = 0x7fffffff;
+        A.j0 = (long)mel::HOP * frame_first;
+        A.count = mel::HOP * (frame_count - 1) + mel::N_FFT;
+    }
+    src.padA = A.dst;
+    src.jA0 = A.j0;
+    src.padB = B.dst;
+    src.jB0 = B.j0;
+    if (A.count + B.count > 0) {
+        const long total = (long)A.count + B.count;
+        const int g1 = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(mel::reflect_pad_segments_kernel, dim3(g1), dim3(256), 0, st, y0, n_samples, A, B);
+    }
+    const int tiles = (frame_count + 31) / 32;
+    const int grid = tiles < g_mel.n_cu ? tiles : g_mel.n_cu;
+    hipLaunchKernelGGL(mel::logmel_fft_kernel, dim3(grid), dim3(256), mel::FFT_LDS_BYTES, st, src, frame_first, frame_count, tiles, g_mel.d_t1,
+                       g_mel.d_t3, g_mel.d_tm, features);
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
 
 SAVAD_EXPORT int savad_logmel(const float* audio, int n_samples, float* workspace, float* features, void* stream) {
     if (!audio || !workspace || !features || n_samples < 1) return fail(SAVAD_E_INVALID, "bad argument");
+    if (g_logmel_algorithm == 0)
+        return savad_logmel_span(audio, 0, n_samples, n_samples, 0, 1 + n_samples / mel::HOP, workspace, features, stream);
     if (((uintptr_t)workspace | (uintptr_t)features) & 15) return fail(SAVAD_E_INVALID, "workspace and features must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     int rc;

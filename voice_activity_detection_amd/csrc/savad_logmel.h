@@ -45,6 +45,27 @@ __global__ void reflect_pad_kernel(const float* __restrict__ y, int n, float* __
     }
 }
 
+// dst[i] = y[reflect(j0 + i - 256)], i in [0, count), for up to two stretches of the padded signal (the edge frames of the
+// factored kernel); y0[i] = sample i of the whole signal, n = its length
+struct PadSeg {
+    float* dst;
+    long j0;
+    int count;
+};
+__global__ void reflect_pad_segments_kernel(const float* __restrict__ y0, long n, PadSeg a, PadSeg b) {
+    const long total = (long)a.count + b.count;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const bool second = t >= a.count;
+        const long k = second ? t - a.count : t;
+        long i = (second ? b.j0 : a.j0) + k - N_FFT / 2;
+        if (i < 0) i = -i;
+        if (i >= n) i = 2L * (n - 1) - i;
+        if (i < 0) i = 0;
+        if (i >= n) i = n - 1;
+        (second ? b.dst : a.dst)[k] = y0[i];
+    }
+}
+
 // One WORKGROUP = 32 frames; wave w runs pass w (64 of the 256 bins: 800 DFT MFMAs + its 96 mel MFMAs) and the four
 // partial mel accumulators are summed through LDS in a fixed order.  (First version: one wave ran all four passes of
 // its tile -- 3584 dependent-issue MFMAs = 100 us of latency for a 10 s clip, whose 32 tiles occupied 8 CUs.)
@@ -163,6 +184,169 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void logmel_kernel(cons
             st4(op + mel0, t);
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Round 5: the STFT as a FACTORED DFT (512 = 32 x 16) on the same exact-fp32 MFMA -- 624 MFMAs per 32 frames
+// instead of 3584 (the DFT-as-GEMM above is kept for A/B and as an on-device cross-check).
+//
+//   n = 16 n1 + n2,  k = k1 + 32 k2:   X[k] = sum_n2 W512^(n2 k) * Y[k1][n2],   Y[k1][n2] = sum_n1 w[n] y[n] W32^(n1 k1)
+//
+//   step 1  (52 MFMAs / wave)  Y^T[k1 re|im][frame] for one n2: A = window-folded W32 rows (only n1 = 3..28 lie under
+//           the 400-sample window: 13 k-steps), B = the frames' samples, a float4 per lane and k-step = four n2 at once.
+//           The input is real, so k1 = 0..16 suffices; re(k1) sits in the low lane half, im(k1) in the high one
+//           (im(0) = 0: its slot carries re(16)), which is exactly the k-pair a step-3 MFMA consumes.
+//   exchange through LDS: [k1][frame][re|im][n2]; wave w wrote n2 = 4w..4w+3 and reads k1 = 4w..4w+3.
+//   step 3  (64 MFMAs / wave)  per k1: X[k1 + 32 k2], k2 = 0..15, A = W512^(n2 (k1 + 32 k2)) (twiddle folded in: 16
+//           different 32x32 matrices, no VALU work), B = Y from LDS.  Bins above 256 are the mirror images of the bins
+//           32 - k1 + 32 k2' that no wave computes (|X[512-k]| = |X[k]|).  k1 = 0 and 16 (both real) share one pass:
+//           bins 32..224 step 32 and 16..240 step 32; bins 0 and 256 have zero weight in every filter.
+//   power   re / im of a bin are adjacent registers: lane-local.
+//   mel     (40 MFMAs / wave)  the rows of step 3 are ordered so that register pair p holds the 2p-th and (2p+1)-th
+//           lowest bins of the group: pair 0 only meets mel block 0 (mels 0..31), pairs 2, 3 block 1, pairs 5..7
+//           block 2, pairs 1 and 4 two blocks -- 10 MFMAs per group instead of 24 (checked when the tables are built).
+//   the four waves' partial mel tiles are summed through LDS in a fixed order; log; store (one tile late, so that the
+//   loop's vmcnt(0) for the NEXT tile's samples never waits for a store acknowledgement).
+//
+// One persistent workgroup per CU (all A operands of a wave -- 164 registers -- are loaded once), samples are read
+// straight from the caller's audio (reflect padding is materialised for the edge frames only).
+constexpr int FFT_T1_FLOATS = 4 * 13 * 256;   // [wave 4][k-step 13][lane 64][n2 & 3]
+constexpr int FFT_T3_FLOATS = 16 * 4 * 256;   // [group 16][n2 >> 2][lane 64][n2 & 3]
+constexpr int FFT_TM_FLOATS = 16 * 3 * 256;   // [group 16][t >> 2][lane 64][t & 3], t = 0..9 (10, 11 unused)
+constexpr int FFT_YLD = 36;                   // LDS floats per (k1, frame): [re|im][n2 16] + 4 (conflict-free b128)
+constexpr int FFT_LDS_FLOATS = 16 * 32 * FFT_YLD + 4 * 3 * 4 * 256;
+constexpr int FFT_LDS_BYTES = FFT_LDS_FLOATS * 4;  // 122 880
+
+struct FftSrc {
+    const float* y0;    // y0[i] = sample i of the whole signal (frames f_lo <= f < f_hi read it directly)
+    const float* padA;  // padA[j - jA0] = reflect-padded signal at padded index j, for frames f < f_lo
+    const float* padB;  // the same for frames f >= f_hi
+    long jA0, jB0;
+    int f_lo, f_hi;
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(256, 1) void logmel_fft_kernel(FftSrc src, int frame_first, int frame_count, int n_tiles,
+                                                            const float* __restrict__ t1, const float* __restrict__ t3,
+                                                            const float* __restrict__ tm, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float fft_lds[];
+    float* Yl = fft_lds;                       // [k1 16][frame 32][FFT_YLD]
+    float* part = fft_lds + 16 * 32 * FFT_YLD;  // [wave 4][mel block 3][g 4][lane 64][4]
+    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // this wave's A operands, for the whole launch
+    f32x4 a1[13], a3[4][4], am[4][3];
+#pragma unroll
+    for (int s = 0; s < 13; ++s) a1[s] = ld4(t1 + ((size_t)(wv * 13 + s) * 64 + lane) * 4);
+#pragma unroll
+    for (int gl = 0; gl < 4; ++gl) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a3[gl][c] = ld4(t3 + ((size_t)((wv * 4 + gl) * 4 + c) * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) am[gl][q] = ld4(tm + ((size_t)((wv * 4 + gl) * 3 + q) * 64 + lane) * 4);
+    }
+    f32x4 x[13];
+    auto issue_x = [&](int tile) {
+        int f = frame_first + tile * 32 + m;
+        const int f_last = frame_first + frame_count - 1;
+        if (f > f_last) f = f_last;  // such lanes recompute the last frame and store the same values to the same place
+        const long j0 = (long)HOP * f;
+        const float* p = (f < src.f_lo) ? src.padA + (j0 - src.jA0) : (f >= src.f_hi) ? src.padB + (j0 - src.jB0) : src.y0 + (j0 - N_FFT / 2);
+        p += 48 + 16 * h + 4 * wv;  // n = 16 (3 + 2s + h) + 4 wv + e
+#define SAVAD_FFT_LDX(s) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(x[s]) : "v"(p), "n"(128 * (s)))
+        SAVAD_FFT_LDX(0); SAVAD_FFT_LDX(1); SAVAD_FFT_LDX(2); SAVAD_FFT_LDX(3); SAVAD_FFT_LDX(4); SAVAD_FFT_LDX(5); SAVAD_FFT_LDX(6);
+        SAVAD_FFT_LDX(7); SAVAD_FFT_LDX(8); SAVAD_FFT_LDX(9); SAVAD_FFT_LDX(10); SAVAD_FFT_LDX(11); SAVAD_FFT_LDX(12);
+#undef SAVAD_FFT_LDX
+    };
+    f32x4 held[3];
+    float* held_p = nullptr;
+    bool have_held = false;  // wave-uniform
+    // pieces (mel block, g) of a frame's 80 mels: 10 of them, wave w finishes pieces w, w+4, w+8
+    auto store_held = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int piece = wv + 4 * i;
+            if (piece < 10) st4(held_p + 8 * piece, held[i]);  // 32 mb + 8 g = 8 piece
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < n_tiles) issue_x(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+                       "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]));
+        // ---- step 1
+        f32x16 acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = zero16();
+#pragma unroll
+        for (int s = 0; s < 13; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = SAVAD_MFMA(a1[s][e], x[s][e], acc[e]);
+        if (have_held) store_held();  // the PREVIOUS tile's mels
+        if (tile + (int)gridDim.x < n_tiles) issue_x(tile + gridDim.x);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            st4(Yl + (r * 32 + m) * FFT_YLD + 16 * h + 4 * wv, f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]});
+        lds_barrier();
+        // ---- step 3, power, mel
+        f32x16 macc[3];
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb) macc[mb] = zero16();
+#pragma unroll
+        for (int gl = 0; gl < 4; ++gl) {
+            const float* yp = Yl + ((wv * 4 + gl) * 32 + m) * FFT_YLD + 16 * h;
+            f32x16 d = zero16();
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 yb = ld4(yp + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d = SAVAD_MFMA(a3[gl][c][e], yb[e], d);
+            }
+            float pw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pw[i] = d[2 * i] * d[2 * i] + d[2 * i + 1] * d[2 * i + 1];
+            // pair -> mel blocks: 0:{0} 1:{0,1} 2:{1} 3:{1} 4:{1,2} 5:{2} 6:{2} 7:{2}
+            macc[0] = SAVAD_MFMA(am[gl][0][0], pw[0], macc[0]);
+            macc[0] = SAVAD_MFMA(am[gl][0][1], pw[1], macc[0]);
+            macc[1] = SAVAD_MFMA(am[gl][0][2], pw[1], macc[1]);
+            macc[1] = SAVAD_MFMA(am[gl][0][3], pw[2], macc[1]);
+            macc[1] = SAVAD_MFMA(am[gl][1][0], pw[3], macc[1]);
+            macc[1] = SAVAD_MFMA(am[gl][1][1], pw[4], macc[1]);
+            macc[2] = SAVAD_MFMA(am[gl][1][2], pw[4], macc[2]);
+            macc[2] = SAVAD_MFMA(am[gl][1][3], pw[5], macc[2]);
+            macc[2] = SAVAD_MFMA(am[gl][2][0], pw[6], macc[2]);
+            macc[2] = SAVAD_MFMA(am[gl][2][1], pw[7], macc[2]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                st4(part + (((wv * 3 + mb) * 4 + g) * 64 + lane) * 4, f32x4{macc[mb][4 * g], macc[mb][4 * g + 1], macc[mb][4 * g + 2], macc[mb][4 * g + 3]});
+        lds_barrier();
+        // ---- sum of the four partial tiles, log
+        {
+            int f = tile * 32 + m;
+            if (f > frame_count - 1) f = frame_count - 1;
+            held_p = out + (size_t)f * N_MELS + 4 * h;
+            have_held = true;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int piece = wv + 4 * i;  // = 4 mb + g
+                if (piece < 10) {
+                    f32x4 t = ld4(part + ((0 * 12 + piece) * 64 + lane) * 4);
+#pragma unroll
+                    for (int w2 = 1; w2 < 4; ++w2) t += ld4(part + ((w2 * 12 + piece) * 64 + lane) * 4);
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) t[s2] = logf(t[s2] + 1e-6f);
+                    held[i] = t;
+                }
+            }
+        }
+    }
+    if (have_held) store_held();
 }
 
 }  // namespace mel

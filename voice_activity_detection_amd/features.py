@@ -139,3 +139,29 @@ def log_mel(audio, device="cuda") -> torch.Tensor:
                                 ctypes.c_void_p(out.data_ptr()),
                                 ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)))
     return out
+
+
+def log_mel_span(audio, audio_first: int, n_samples: int, frame_first: int, frame_count: int) -> torch.Tensor:
+    """Frames [frame_first, frame_first + frame_count) of the log-mel matrix of an n_samples-long signal, from a device
+    slice `audio` that starts at sample `audio_first` (savad_logmel_span; `span_samples` names the slice a frame span
+    needs).  What one rank of a sharded run computes: the same bits as the rows of log_mel(whole signal)."""
+    lib = _lib.load()
+    if not (isinstance(audio, torch.Tensor) and audio.dtype == torch.float32 and audio.dim() == 1 and audio.device.type == "cuda"
+            and audio.is_contiguous()):
+        raise ValueError("audio must be a contiguous 1-D float32 tensor on a HIP device")
+    with torch.cuda.device(audio.device):
+        buf = torch.empty(lib.savad_logmel_span_workspace_bytes(int(frame_count)) // 4, dtype=torch.float32, device=audio.device)
+        out = torch.empty((int(frame_count), 80), dtype=torch.float32, device=audio.device)
+        _lib.check(lib.savad_logmel_span(ctypes.c_void_p(audio.data_ptr()), int(audio_first), audio.numel(), int(n_samples),
+                                         int(frame_first), int(frame_count), ctypes.c_void_p(buf.data_ptr()),
+                                         ctypes.c_void_p(out.data_ptr()),
+                                         ctypes.c_void_p(torch.cuda.current_stream(audio.device).cuda_stream)))
+    return out
+
+
+def span_samples(n_samples: int, frame_first: int, frame_count: int):
+    """(first, count): the samples frames [frame_first, +frame_count) of an n_samples-long signal read (first % 4 == 0)."""
+    lib = _lib.load()
+    first, count = ctypes.c_long(), ctypes.c_long()
+    _lib.check(lib.savad_logmel_span_samples(int(n_samples), int(frame_first), int(frame_count), ctypes.byref(first), ctypes.byref(count)))
+    return first.value, count.value
