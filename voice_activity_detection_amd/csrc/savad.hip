@@ -1590,20 +1590,27 @@ SAVAD_EXPORT int savad_logmel_span(const float* audio, long audio_first, long au
     mel::PadSeg A{workspace, 0, 0}, B{workspace + 1024, 0, 0};
     src.y0 = y0;
     const bool direct = n_samples >= 4096 && (((uintptr_t)audio - (uintptr_t)audio_first * 4u) & 15) == 0;
+    // a frame reads padded indices [160 f + 48, 160 f + 464) (n1 = 3..28): the padded copies hold exactly those stretches, so
+    // that nothing outside the samples savad_logmel_span_samples names is ever read
+    constexpr int FIRST = 48, SPAN = 416;
     if (direct) {
         src.f_lo = 2;
         src.f_hi = (int)((n_samples - 207 + mel::HOP - 1) / mel::HOP);  // first frame that reads past the last sample
-        if (frame_first < 2) A.count = mel::HOP + mel::N_FFT + mel::HOP;  // padded indices [0, 832): frames 0 and 1
+        const int fa_end = f_end < 2 ? f_end : 2;
+        if (frame_first < fa_end) {  // frames 0 and 1 read before the first sample
+            A.j0 = (long)mel::HOP * frame_first + FIRST;
+            A.count = mel::HOP * (fa_end - 1 - frame_first) + SPAN;
+        }
         const int fb = frame_first > src.f_hi ? frame_first : src.f_hi;
         if (fb < f_end) {
-            B.j0 = (long)mel::HOP * fb;
-            B.count = mel::HOP * (f_end - 1 - fb) + mel::N_FFT;  // at most 3 frames
+            B.j0 = (long)mel::HOP * fb + FIRST;
+            B.count = mel::HOP * (f_end - 1 - fb) + SPAN;  // at most 3 frames
         }
     } else {  // the whole span from a padded copy
         src.f_lo = 0x7fffffff;
         src.f_hi = 0x7fffffff;
-        A.j0 = (long)mel::HOP * frame_first;
-        A.count = mel::HOP * (frame_count - 1) + mel::N_FFT;
+        A.j0 = (long)mel::HOP * frame_first + FIRST;
+        A.count = mel::HOP * (frame_count - 1) + SPAN;
     }
     src.padA = A.dst;
     src.jA0 = A.j0;
