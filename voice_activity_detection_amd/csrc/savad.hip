@@ -1585,37 +1585,35 @@ SAVAD_EXPORT int savad_logmel_span(const float* audio, long audio_first, long au
     MelTables g_mel;
     if ((rc = ensure_mel_tables(st, &g_mel))) return rc;
     const float* y0 = audio - audio_first;  // y0[i] = sample i (only indices inside the slice are ever read)
-    const int f_end = frame_first + frame_count;
+    // the frames read padded indices [j_first, j_last + 4), in 16-byte chunks (savad_logmel.h: sample stage)
+    const long j_first = (long)mel::HOP * frame_first + 48, j_last = (long)mel::HOP * (frame_first + frame_count - 1) + 460;
+    constexpr long NEVER = 1L << 40;
     mel::FftSrc src{};
-    mel::PadSeg A{workspace, 0, 0}, B{workspace + 1024, 0, 0};
+    mel::PadSeg A{workspace, 0, 0}, B{workspace + 256, 0, 0};
     src.y0 = y0;
-    const bool direct = n_samples >= 4096 && (((uintptr_t)audio - (uintptr_t)audio_first * 4u) & 15) == 0;
-    // a frame reads padded indices [160 f + 48, 160 f + 464) (n1 = 3..28): the padded copies hold exactly those stretches, so
-    // that nothing outside the samples savad_logmel_span_samples names is ever read
-    constexpr int FIRST = 48, SPAN = 416;
+    src.jA_end = -NEVER;
+    src.jB0 = NEVER;
+    const bool direct = (((uintptr_t)audio - (uintptr_t)audio_first * 4u) & 15) == 0;
     if (direct) {
-        src.f_lo = 2;
-        src.f_hi = (int)((n_samples - 207 + mel::HOP - 1) / mel::HOP);  // first frame that reads past the last sample
-        const int fa_end = f_end < 2 ? f_end : 2;
-        if (frame_first < fa_end) {  // frames 0 and 1 read before the first sample
-            A.j0 = (long)mel::HOP * frame_first + FIRST;
-            A.count = mel::HOP * (fa_end - 1 - frame_first) + SPAN;
+        if (j_first < mel::N_FFT / 2) {  // the stretch that mirrors the head of the signal
+            A.j0 = j_first;
+            A.count = (int)((j_last + 4 < mel::N_FFT / 2 ? j_last + 4 : mel::N_FFT / 2) - j_first);
+            src.jA_end = mel::N_FFT / 2;
         }
-        const int fb = frame_first > src.f_hi ? frame_first : src.f_hi;
-        if (fb < f_end) {
-            B.j0 = (long)mel::HOP * fb + FIRST;
-            B.count = mel::HOP * (f_end - 1 - fb) + SPAN;  // at most 3 frames
+        const long jb = (n_samples + 253 + 3) & ~3L;  // first chunk that runs past the last sample
+        if (j_last >= jb) {
+            B.j0 = jb;
+            B.count = (int)(j_last + 4 - jb);  // <= 212
+            src.jB0 = jb;
         }
-    } else {  // the whole span from a padded copy
-        src.f_lo = 0x7fffffff;
-        src.f_hi = 0x7fffffff;
-        A.j0 = (long)mel::HOP * frame_first + FIRST;
-        A.count = mel::HOP * (frame_count - 1) + SPAN;
+    } else {  // unaligned audio: the whole span from a padded (and thereby aligned) copy
+        A.j0 = j_first;
+        A.count = (int)(j_last + 4 - j_first);
+        src.jA_end = NEVER;
     }
     src.padA = A.dst;
     src.jA0 = A.j0;
     src.padB = B.dst;
-    src.jB0 = B.j0;
     if (A.count + B.count > 0) {
         const long total = (long)A.count + B.count;
         const int g1 = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

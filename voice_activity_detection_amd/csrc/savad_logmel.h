@@ -197,7 +197,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void logmel_kernel(cons
 //           the 400-sample window: 13 k-steps), B = the frames' samples, a float4 per lane and k-step = four n2 at once.
 //           The input is real, so k1 = 0..16 suffices; re(k1) sits in the low lane half, im(k1) in the high one
 //           (im(0) = 0: its slot carries re(16)), which is exactly the k-pair a step-3 MFMA consumes.
-//   exchange through LDS: [k1][frame][re|im][n2]; wave w wrote n2 = 4w..4w+3 and reads k1 = 4w..4w+3.
+//   exchange through LDS: [k1 >> 2][frame][re|im][n2][k1 & 3]; wave w writes n2 = 4w..4w+3 (a float4 = four consecutive
+//           accumulator registers, no moves) and reads k1 = 4w..4w+3 (a float4 = one k-step's B operands of its four groups).
 //   step 3  (64 MFMAs / wave)  per k1: X[k1 + 32 k2], k2 = 0..15, A = W512^(n2 (k1 + 32 k2)) (twiddle folded in: 16
 //           different 32x32 matrices, no VALU work), B = Y from LDS.  Bins above 256 are the mirror images of the bins
 //           32 - k1 + 32 k2' that no wave computes (|X[512-k]| = |X[k]|).  k1 = 0 and 16 (both real) share one pass:
@@ -214,16 +215,27 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void logmel_kernel(cons
 constexpr int FFT_T1_FLOATS = 4 * 13 * 256;   // [wave 4][k-step 13][lane 64][n2 & 3]
 constexpr int FFT_T3_FLOATS = 16 * 4 * 256;   // [group 16][n2 >> 2][lane 64][n2 & 3]
 constexpr int FFT_TM_FLOATS = 16 * 3 * 256;   // [group 16][t >> 2][lane 64][t & 3], t = 0..9 (10, 11 unused)
-constexpr int FFT_YLD = 36;                   // LDS floats per (k1, frame): [re|im][n2 16] + 4 (conflict-free b128)
-constexpr int FFT_LDS_FLOATS = 16 * 32 * FFT_YLD + 4 * 3 * 4 * 256;
-constexpr int FFT_LDS_BYTES = FFT_LDS_FLOATS * 4;  // 122 880
+constexpr int FFT_YLD = 132;                  // LDS floats per (reader wave, frame): [re|im][n2 16][k1 & 3] + 4 (conflict-free b128)
+constexpr int FFT_Y_FLOATS = 4 * 32 * FFT_YLD;
+constexpr int FFT_PART_FLOATS = 4 * 3 * 4 * 256;
+// Sample stage: the tile's stretch of the padded signal, padded indices [160 f0 + 48, 160 f0 + 48 + 5376), as 34 blocks of
+// 160 samples, each followed by 4 unused floats: frame m's float4 for k-step s then sits at 164 m + 16 h + 4 w +
+// (164 (s / 5) + 32 (s % 5)) -- lane stride 164 = 36 mod 64 banks (conflict-free ds_read_b128), the rest an immediate.
+// Filled by global -> LDS DMA: 24 instructions of 64 x 16 bytes, 6 per wave (chunk q = 64 i + lane of the stage is
+// sample chunk 40 (q / 41) + min(q % 41, 39) of the stretch); every 128-byte line of the audio is requested once per tile.
+constexpr int FFT_SBLK = 164, FFT_STAGE_CHUNKS = 24 * 64, FFT_STAGE_FLOATS = FFT_STAGE_CHUNKS * 4;
+constexpr int FFT_LDS_FLOATS = FFT_Y_FLOATS + FFT_PART_FLOATS + FFT_STAGE_FLOATS;
+constexpr int FFT_LDS_BYTES = FFT_LDS_FLOATS * 4;  // 147 456
 
+// Where the padded signal ypad[j] = y[reflect(j - 256)] is read from: padded indices below jA_end from a padded copy
+// (padA[j - jA0]: the stretch that mirrors the signal's head, or the whole span when the audio pointer is unaligned), from
+// jB0 on from padB[j - jB0] (the stretch that runs past the last sample), everything between straight from the audio
+// (y0[j - 256]).  jA_end, jB0, jA0 are multiples of 4 and every pointer is 16-byte aligned.
 struct FftSrc {
-    const float* y0;    // y0[i] = sample i of the whole signal (frames f_lo <= f < f_hi read it directly)
-    const float* padA;  // padA[j - jA0] = reflect-padded signal at padded index j, for frames f < f_lo
-    const float* padB;  // the same for frames f >= f_hi
-    long jA0, jB0;
-    int f_lo, f_hi;
+    const float* y0;
+    const float* padA;
+    const float* padB;
+    long jA0, jA_end, jB0;
 };
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -232,8 +244,9 @@ __global__ __launch_bounds__(256, 1) void logmel_fft_kernel(FftSrc src, int fram
                                                             const float* __restrict__ t1, const float* __restrict__ t3,
                                                             const float* __restrict__ tm, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float fft_lds[];
-    float* Yl = fft_lds;                       // [k1 16][frame 32][FFT_YLD]
-    float* part = fft_lds + 16 * 32 * FFT_YLD;  // [wave 4][mel block 3][g 4][lane 64][4]
+    float* Yl = fft_lds;                                     // [k1 >> 2][frame 32][FFT_YLD]
+    float* part = fft_lds + FFT_Y_FLOATS;                    // [wave 4][mel block 3][g 4][lane 64][4]
+    float* stage = fft_lds + FFT_Y_FLOATS + FFT_PART_FLOATS;  // see FFT_SBLK
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // this wave's A operands, for the whole launch
@@ -247,64 +260,122 @@ __global__ __launch_bounds__(256, 1) void logmel_fft_kernel(FftSrc src, int fram
 #pragma unroll
         for (int q = 0; q < 3; ++q) am[gl][q] = ld4(tm + ((size_t)((wv * 4 + gl) * 3 + q) * 64 + lane) * 4);
     }
-    f32x4 x[13];
-    auto issue_x = [&](int tile) {
-        int f = frame_first + tile * 32 + m;
-        const int f_last = frame_first + frame_count - 1;
-        if (f > f_last) f = f_last;  // such lanes recompute the last frame and store the same values to the same place
-        const long j0 = (long)HOP * f;
-        const float* p = (f < src.f_lo) ? src.padA + (j0 - src.jA0) : (f >= src.f_hi) ? src.padB + (j0 - src.jB0) : src.y0 + (j0 - N_FFT / 2);
-        p += 48 + 16 * h + 4 * wv;  // n = 16 (3 + 2s + h) + 4 wv + e
-#define SAVAD_FFT_LDX(s) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(x[s]) : "v"(p), "n"(128 * (s)))
-        SAVAD_FFT_LDX(0); SAVAD_FFT_LDX(1); SAVAD_FFT_LDX(2); SAVAD_FFT_LDX(3); SAVAD_FFT_LDX(4); SAVAD_FFT_LDX(5); SAVAD_FFT_LDX(6);
-        SAVAD_FFT_LDX(7); SAVAD_FFT_LDX(8); SAVAD_FFT_LDX(9); SAVAD_FFT_LDX(10); SAVAD_FFT_LDX(11); SAVAD_FFT_LDX(12);
-#undef SAVAD_FFT_LDX
-    };
-    f32x4 held[3];
-    float* held_p = nullptr;
-    bool have_held = false;  // wave-uniform
-    // pieces (mel block, g) of a frame's 80 mels: 10 of them, wave w finishes pieces w, w+4, w+8
-    auto store_held = [&]() {
+    // DMA instruction i = wv + 4 k of this wave fills stage chunks 64 i + lane: offsets (floats) inside the tile's stretch
+    int rel[6];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int piece = wv + 4 * i;
-            if (piece < 10) st4(held_p + 8 * piece, held[i]);  // 32 mb + 8 g = 8 piece
+    for (int k = 0; k < 6; ++k) {
+        const int q = 64 * (wv + 4 * k) + lane, b = q / 41, c = q % 41;
+        rel[k] = 160 * b + 4 * (c < 39 ? c : 39);
+    }
+    const long j_last = (long)HOP * (frame_first + frame_count - 1) + 460;  // the last chunk any frame of the launch reads
+    const unsigned stage_m0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)stage) + 1024u * (unsigned)wv;
+    // sources as integers: address of padded index j = base + 4 j
+    const uintptr_t srcA = (uintptr_t)src.padA - 4 * (uintptr_t)src.jA0, srcB = (uintptr_t)src.padB - 4 * (uintptr_t)src.jB0,
+                    srcY = (uintptr_t)src.y0 - 4 * (uintptr_t)(N_FFT / 2);
+    // the six source addresses of this wave's part of a tile's stage
+    const float* sptr[6];
+    auto stage_ptrs = [&](int tile) {
+        const long J0 = (long)HOP * (frame_first + tile * 32) + 48;
+        const long J1 = J0 + 160 * 37 + 160;  // one past the last chunk the 24 instructions touch
+        if (J0 >= src.jA_end && J1 <= src.jB0 && J1 <= j_last + 4) {  // wave-uniform: every chunk straight from the audio
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sptr[k] = (const float*)(srcY + 4 * (uintptr_t)(J0 + rel[k]));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                long j = J0 + rel[k];
+                if (j > j_last) j = j_last;
+                const uintptr_t b = (j < src.jA_end) ? srcA : (j >= src.jB0) ? srcB : srcY;
+                sptr[k] = (const float*)(b + 4 * (uintptr_t)j);
+            }
         }
     };
-    int tile = blockIdx.x;
-    if (tile < n_tiles) issue_x(tile);
-    for (; tile < n_tiles; tile += gridDim.x) {
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
-                       "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]));
-        // ---- step 1
-        f32x16 acc[4];
+    // one DMA instruction (64 x 16 bytes -> stage + 1 KiB * (wv + 4 k)); separate statements, so that they can sit between
+    // MFMAs (issued back to back they hold the wave ~100 cycles each); the M0 offset is an immediate (as SGPR operands the
+    // six values ran the loop out of SGPRs, and hipcc then hands an "s" operand a VGPR)
+    unsigned keep_m0;
+#define SAVAD_FFT_DMA(k)                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, " #k "*4096\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_m0) : "v"(sptr[k]), "s"(stage_m0) : "memory", "scc")
+    f32x16 acc[4];
+    // lanes past the launch's last frame redo that frame: they store the same values to the same place, unpredicated
+    auto step1 = [&](int tile) {
+        const int room = frame_count - 1 - 32 * tile, mm = m < room ? m : (room > 0 ? room : 0);
+        const float* sp = stage + FFT_SBLK * mm + 16 * h + 4 * wv;
+        f32x4 x[13];
+#pragma unroll
+        for (int s = 0; s < 13; ++s) x[s] = ld4(sp + FFT_SBLK * (s / 5) + 32 * (s % 5));
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = zero16();
 #pragma unroll
         for (int s = 0; s < 13; ++s)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = SAVAD_MFMA(a1[s][e], x[s][e], acc[e]);
-        if (have_held) store_held();  // the PREVIOUS tile's mels
-        if (tile + (int)gridDim.x < n_tiles) issue_x(tile + gridDim.x);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            st4(Yl + (r * 32 + m) * FFT_YLD + 16 * h + 4 * wv, f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]});
+    };
+#ifdef SAVAD_TIMING
+    long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fp = __builtin_readcyclecounter(), fn;
+#define SAVAD_FACC(i) do { fn = __builtin_readcyclecounter(); facc[i] += fn - fp; fp = fn; } while (0)
+#else
+#define SAVAD_FACC(i) do {} while (0)
+#endif
+    int tile = blockIdx.x;
+    if (tile < n_tiles) {
+        stage_ptrs(tile);
+        SAVAD_FFT_DMA(0); SAVAD_FFT_DMA(1); SAVAD_FFT_DMA(2); SAVAD_FFT_DMA(3); SAVAD_FFT_DMA(4); SAVAD_FFT_DMA(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
-        // ---- step 3, power, mel
+        step1(tile);
+    }
+    SAVAD_FACC(0);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        // ---- exchange: acc[e][r] = Y[k1 = r][re|im = h][n2 = 4 wv + e][frame m]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                st4(Yl + (g * 32 + m) * FFT_YLD + 64 * h + 4 * (4 * wv + e), f32x4{acc[e][4 * g], acc[e][4 * g + 1], acc[e][4 * g + 2], acc[e][4 * g + 3]});
+        SAVAD_FACC(1);
+        lds_barrier();  // Y is complete; every wave has finished reading the stage and last tile's partial sums
+        SAVAD_FACC(2);
+        const int next = tile + gridDim.x;
+        const bool have_next = next < n_tiles;  // wave-uniform
+        if (have_next) stage_ptrs(next);
+        // ---- step 3, power, mel: group gl + 1's DFT runs in front of group gl's power and mel work
         f32x16 macc[3];
 #pragma unroll
         for (int mb = 0; mb < 3; ++mb) macc[mb] = zero16();
+        f32x4 yb[16];  // yb[n2][gl]
 #pragma unroll
-        for (int gl = 0; gl < 4; ++gl) {
-            const float* yp = Yl + ((wv * 4 + gl) * 32 + m) * FFT_YLD + 16 * h;
+        for (int n2 = 0; n2 < 16; ++n2) yb[n2] = ld4(Yl + (wv * 32 + m) * FFT_YLD + 64 * h + 4 * n2);
+        auto dft3 = [&](int gl, auto&& between) {
             f32x16 d = zero16();
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x4 yb = ld4(yp + 4 * c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d = SAVAD_MFMA(a3[gl][c][e], yb[e], d);
+                for (int e = 0; e < 4; ++e) d = SAVAD_MFMA(a3[gl][c][e], yb[4 * c + e][gl], d);
+                between(c);
             }
+            return d;
+        };
+        // the next tile's stage is requested between the MFMAs of the first two groups
+        f32x16 d = dft3(0, [&](int c) {
+            if (have_next) {
+                if (c == 0) SAVAD_FFT_DMA(0);
+                if (c == 1) SAVAD_FFT_DMA(1);
+                if (c == 2) SAVAD_FFT_DMA(2);
+                if (c == 3) SAVAD_FFT_DMA(3);
+            }
+        });
+#pragma unroll
+        for (int gl = 0; gl < 4; ++gl) {
+            f32x16 dn;
+            if (gl < 3)
+                dn = dft3(gl + 1, [&](int c) {
+                    if (have_next && gl == 0) {
+                        if (c == 0) SAVAD_FFT_DMA(4);
+                        if (c == 1) SAVAD_FFT_DMA(5);
+                    }
+                });
             float pw[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) pw[i] = d[2 * i] * d[2 * i] + d[2 * i + 1] * d[2 * i + 1];
@@ -319,34 +390,43 @@ __global__ __launch_bounds__(256, 1) void logmel_fft_kernel(FftSrc src, int fram
             macc[2] = SAVAD_MFMA(am[gl][1][3], pw[5], macc[2]);
             macc[2] = SAVAD_MFMA(am[gl][2][0], pw[6], macc[2]);
             macc[2] = SAVAD_MFMA(am[gl][2][1], pw[7], macc[2]);
+            if (gl < 3) d = dn;
         }
 #pragma unroll
         for (int mb = 0; mb < 3; ++mb)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 st4(part + (((wv * 3 + mb) * 4 + g) * 64 + lane) * 4, f32x4{macc[mb][4 * g], macc[mb][4 * g + 1], macc[mb][4 * g + 2], macc[mb][4 * g + 3]});
+        SAVAD_FACC(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next stage has landed (and the last tile's stores are acknowledged)
+        SAVAD_FACC(4);
         lds_barrier();
-        // ---- sum of the four partial tiles, log
+        SAVAD_FACC(5);
+        // ---- the next tile's step 1 (MFMA) in one basic block with this tile's sums, log and stores (LDS, VALU): no branch in
+        // here (after the last tile step 1 reruns on the stale stage; nobody reads its result)
         {
-            int f = tile * 32 + m;
-            if (f > frame_count - 1) f = frame_count - 1;
-            held_p = out + (size_t)f * N_MELS + 4 * h;
-            have_held = true;
+            const int room = frame_count - 1 - 32 * tile, fl = tile * 32 + (m < room ? m : room);  // frame inside the launch
+            float* op = out + (size_t)fl * N_MELS + 4 * h;
+            step1(next);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int piece = wv + 4 * i;  // = 4 mb + g
-                if (piece < 10) {
-                    f32x4 t = ld4(part + ((0 * 12 + piece) * 64 + lane) * 4);
+                // piece = 4 (mel block) + g: mels 8 piece + 4 h .. + 3; 10 pieces, wave w takes w, w + 4 and w + 8 (waves 2, 3: piece 9 again)
+                const int piece = wv + 4 * i < 10 ? wv + 4 * i : 9;
+                f32x4 t = ld4(part + ((0 * 12 + piece) * 64 + lane) * 4);
 #pragma unroll
-                    for (int w2 = 1; w2 < 4; ++w2) t += ld4(part + ((w2 * 12 + piece) * 64 + lane) * 4);
+                for (int w2 = 1; w2 < 4; ++w2) t += ld4(part + ((w2 * 12 + piece) * 64 + lane) * 4);
 #pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) t[s2] = logf(t[s2] + 1e-6f);
-                    held[i] = t;
-                }
+                for (int s2 = 0; s2 < 4; ++s2) t[s2] = logf(t[s2] + 1e-6f);
+                st4(op + 8 * piece, t);
             }
         }
+        SAVAD_FACC(7);
     }
-    if (have_held) store_held();
+#ifdef SAVAD_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_savad_dbg[24 + i] = facc[i];
+#endif
+#undef SAVAD_FFT_DMA
 }
 
 }  // namespace mel
