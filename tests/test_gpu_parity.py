@@ -595,6 +595,63 @@ def test_bf16_close_to_fp32_oracle(torch_cuda, model, state1234, shape):
         assert err > 1e-5
 
 
+def _run_bf16_mode(torch, model, x, row_mode):
+    model.row_mode = row_mode
+    try:
+        return run_bf16(torch, model, x)
+    finally:
+        model.row_mode = 0
+
+
+@pytest.mark.parametrize("shape", [(4, 7, 80), (1000, 7, 80), (37, 20, 80), (5, 32, 80), (3, 1, 80), (100, 10, 80), (9, 31, 80), (4099, 7, 80)])
+def test_bf16_single_launch_is_the_per_layer_launches_bit_for_bit(torch_cuda, model, state1234, shape):
+    """T <= 32 with bf16 operands (round 5, savad_packed_bf16.h): the whole forward in ONE launch -- a wave per packed block,
+    attention in registers, the residual stream parked as fp16 -- against the per-layer launches it replaces (row_mode 1:
+    input_qkv_kernel_bf16 -> attention_packed_kernel_bf16 -> row_kernel_bf16, which round-trip q / k / v^T / ctx / h through
+    HBM): the same bits, for 4-wave (automatic) and 8-wave (row_mode 5) workgroups; and within the bf16 bound of the oracle."""
+    from oracle import oracle
+
+    torch = torch_cuda
+    x = feats(17 + sum(shape), shape)
+    y0 = _run_bf16_mode(torch, model, x, 0)
+    y1 = _run_bf16_mode(torch, model, x, 1)
+    y5 = _run_bf16_mode(torch, model, x, 5)
+    assert np.isfinite(y0).all() and np.array_equal(y0, y1) and np.array_equal(y0, y5)
+    if shape[0] <= 1000:
+        assert np.abs(y0 - oracle.forward(state1234, x)).max() < BF16_TOL
+
+
+def test_bf16_single_launch_against_the_reference_goldens(torch_cuda, model, golden):
+    """The reference's own outputs (tests/golden/golden.npz: the pipeline shape g1, every edge length up to 32 frames, the
+    [1000,7,80] chunk) through the bf16 single launch, at the bf16 bound."""
+    torch = torch_cuda
+    assert np.abs(run_bf16(torch, model, feats(101, (4, 7, 80))) - golden["g1_out"]).max() < BF16_TOL
+    assert np.abs(run_bf16(torch, model, feats(77, (1, 7, 80))) - golden["g4_B1T7"]).max() < BF16_TOL
+    for T in (1, 2, 5, 10, 11, 16, 17, 31, 32):
+        assert np.abs(run_bf16(torch, model, feats(400 + T, (3, T, 80))) - golden[f"g4_T{T}"]).max() < BF16_TOL, T
+    y = run_bf16(torch, model, feats(78, (1000, 7, 80)))
+    assert np.abs(y[:8] - golden["g4_B1000T7_head"]).max() < BF16_TOL and np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < BF16_TOL
+
+
+@pytest.mark.parametrize("tag,n,seed", [("g5", 1022, 500), ("g5b", 2100, 501), ("g5c", 39, 502)])
+def test_bf16_predictor_against_the_reference_goldens(torch_cuda, model, golden, tag, n, seed):
+    """vad/predictor.py:159-262 run by the reference itself on seeded weights (goldens g5, g5b, g5c) against the bf16 predictor
+    (windows read in place by the single launch): probabilities within 6e-3 (the bf16 log-prob bound through a softmax), the
+    0.5 placeholders of the unfilled slots exact."""
+    from voice_activity_detection_amd import VADFromScratchPredictor
+
+    torch = torch_cuda
+    feat = feats(seed, (n, 80))
+    model.precision = "bf16"
+    try:
+        probs = VADFromScratchPredictor(model, "cuda").predict_probabilities(feat)
+    finally:
+        model.precision = "fp32"
+    want = golden[f"{tag}_probs"]
+    assert probs.shape == want.shape and np.abs(probs - want).max() < 6e-3
+    assert np.array_equal(probs == 0.5, want == 0.5)
+
+
 def test_bf16_input_tensor(torch_cuda, model, state1234):
     from oracle import oracle
 

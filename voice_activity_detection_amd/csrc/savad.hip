@@ -4,6 +4,7 @@
 #include "savad_kernels.h"
 #include "savad_kernels_bf16.h"
 #include "savad_attn_pw_bf16.h"
+#include "savad_packed_bf16.h"
 #include "savad_generic.h"
 #include <type_traits>
 #include "savad_logmel.h"
@@ -784,8 +785,45 @@ int prepare_bf16_launch(savad_model* m) {
     if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::attention_pw_kernel_bf16, bf::PW_LDS_BYTES))) return rc;
+    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4>, r4 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
+    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<8>, r8 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
     m->lds_attrs_set = true;
     return SAVAD_OK;
+}
+
+// T <= 32 with bf16 operands: the whole forward in one launch (savad_packed_bf16.h); a wave per packed block, NW blocks per
+// workgroup.  Weights, fragments, the PE table and the kernels' LDS attributes must be ready.
+bool packed_bf16_applies(const savad_model* m, int T) {
+    // row_mode 0 (automatic) and 4: 4-wave workgroups, two per CU; 5: 8-wave workgroups with the 4-deep ring (a tuning knob
+    // at T <= 32, where the persistent attention kernel it selects for long sequences does not exist); 1 - 3 keep the
+    // per-layer launches (the cross-check of the tests)
+    return T <= 32 && m->cfg.num_layers <= bf::PACKED_BF16_MAX_LAYERS && (m->row_mode == 0 || m->row_mode == 4 || m->row_mode == 5);
+}
+void launch_packed_forward_bf16(savad_model* m, hipStream_t st, const float* x, int B, int T, int F, float* out, const WindowOffsets& wo,
+                                int win_base) {
+    const int L = m->cfg.num_layers;
+    const char* Fr = m->d_frag;
+    const int G = 32 / T, nblk = (B + G - 1) / G;
+    bf::PackedBf16Model pm;
+    for (int l = 0; l < bf::PACKED_BF16_MAX_LAYERS; ++l) {
+        const auto& f = m->lf[l < L ? l : 0];
+        pm.layer[l] = bf::PackedBf16Layer{Fr + f.wqkv, Fr + f.wo, Fr + f.w1, Fr + f.w2};
+    }
+    pm.win = Fr + m->f_win;
+    pm.bin = m->d_raw + m->r_bin;
+    pm.pe = m->d_pe;
+    pm.bias = m->d_packed + m->p_bias;
+    pm.wc = m->d_packed + m->p_wc;
+    pm.bc = m->d_packed + m->p_bc;
+    pm.L = L;
+    const float c = (float)(1.4426950408889634 / sqrt((double)D));
+    const size_t bias_bytes = (size_t)L * LBIAS * 4;
+    if (m->row_mode == 5)
+        hipLaunchKernelGGL((bf::packed_forward_kernel_bf16<8>), dim3((nblk + 7) / 8), dim3(512), bf::Ring<8>::NRING * bf::RING_BYTES + bias_bytes, st, x, B,
+                           T, F, nblk, pm, c, out, wo, win_base, m->d_sat);
+    else
+        hipLaunchKernelGGL((bf::packed_forward_kernel_bf16<4>), dim3((nblk + 3) / 4), dim3(256), bf::Ring<4>::NRING * bf::RING_BYTES + bias_bytes, st, x, B,
+                           T, F, nblk, pm, c, out, wo, win_base, m->d_sat);
 }
 
 // bf16-operand forward: input_qkv -> [attention -> row] x L on fragment-major buffers
@@ -825,6 +863,15 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     const bool wide = m->row_mode == 2;
     if ((rc = prepare_bf16_launch(m))) return rc;
     Prof prof(m, st);
+    if (!x_is_bf16 && packed_bf16_applies(m, T)) {
+        WindowOffsets none;
+        none.w = 0;
+        launch_packed_forward_bf16(m, st, (const float*)x, B, T, F, out, none, 0);
+        prof.mark("packed_forward_bf16");
+        prof.done();
+        HIP_TRY(hipGetLastError());
+        return SAVAD_OK;
+    }
     const bool automatic_bf16 = m->row_mode == 0 || m->row_mode == 4;
     // The persistent attention kernel (one 4 x 64-row workgroup per CU walking (sequence, 8 query blocks) items) against the
     // first-generation one: a cost model of both, from the sweep scripts/ubench/pw_sweep.py (round 4, us per launch, first-generation /
@@ -1215,12 +1262,16 @@ int plan_predict(savad_model* m, int N, int half, int jump, int chunk, PredictPl
     // windowed: the whole clip in ONE single-launch forward (up to 1024 packed tiles = 4096 windows of 7 frames, ~41 s of
     // audio: savad_forward's own limit for that kernel); longer inputs go through `chunk`-sized M-split forwards, which
     // are ~9 % faster per window than 4096-window launches (5.27 vs 5.36 ms for 10 min of audio)
-    p->windowed = !m->generic && m->precision == 0 && p->W <= 32 && m->cfg.num_layers <= PACKED_MAX_LAYERS && m->FP == F &&
-                  (m->row_mode == 4 || (m->row_mode == 0 && p->n_items <= 1024 * (32 / p->W)));
+    // (bf16 operands: the single launch amortises the weight stream over the workgroup's blocks, so it takes any number of windows)
+    if (m->precision == 1)
+        p->windowed = !m->generic && p->W <= 32 && m->FP == F && packed_bf16_applies(m, p->W);
+    else
+        p->windowed = !m->generic && p->W <= 32 && m->cfg.num_layers <= PACKED_MAX_LAYERS && m->FP == F &&
+                      (m->row_mode == 4 || (m->row_mode == 0 && p->n_items <= 1024 * (32 / p->W)));
     // chunk-sized forwards write their log-probs at logp + first*W*2 floats and savad_forward wants 16-byte aligned
     // pointers: an even chunk keeps every offset a multiple of 16 bytes whatever W is (windows are independent, so the
     // chunking never changes a result beyond fp32 summation order)
-    p->chunk = p->windowed ? 1024 * (32 / p->W) : chunk + (chunk & 1);
+    p->chunk = p->windowed ? (m->precision == 1 ? (1 << 22) : 1024 * (32 / p->W)) : chunk + (chunk & 1);
     if (p->chunk > p->n_items) p->chunk = p->n_items > 0 ? p->n_items : 1;
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     size_t off = 0;
@@ -1273,11 +1324,17 @@ SAVAD_EXPORT int savad_predict_probabilities(savad_handle m, const float* featur
     if (p.windowed && p.n_items > 0) {
         if ((rc = prepare_weights(m, st))) return rc;
         if ((rc = ensure_pe(m, W, st))) return rc;
+        if (m->precision == 1) {
+            if ((rc = prepare_frags(m, st))) return rc;
+            if ((rc = prepare_bf16_launch(m))) return rc;
+        }
     }
     for (int first = 0; first < p.n_items; first += p.chunk) {
         const int count = p.n_items - first < p.chunk ? p.n_items - first : p.chunk;
         float* out = logp + (size_t)first * W * 2;
-        if (p.windowed) {
+        if (p.windowed && m->precision == 1) {
+            launch_packed_forward_bf16(m, st, feature, count, W, F, out, wo, half + first);
+        } else if (p.windowed) {
             launch_packed_forward(m, st, feature, count, W, F, out, wo, half + first);
         } else {
             float* win = (float*)(ws + p.windows);
