@@ -75,6 +75,7 @@ struct savad_model {
     size_t frag_bytes = 0;
     bool frag_dirty = true;
     bool lds_attrs_set = false;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the bf16 kernels
+    int n_cu = 256;              // compute units of the handle's device (launch-shape decisions)
     size_t f_win = 0;
     struct LayerFrag {
         size_t wqkv, wo, w1, w2;
@@ -576,6 +577,10 @@ SAVAD_EXPORT int savad_create(const savad_config* cfg, savad_handle* out) {
     if (cfg->num_layers < 1 || cfg->num_layers > 64) return fail(SAVAD_E_INVALID, "num_layers=%d", cfg->num_layers);
     savad_model* m = new savad_model();
     m->cfg = *cfg;
+    {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) m->n_cu = n;
+    }
     const int F = cfg->feature_size, L = cfg->num_layers;
     // state_dict inventory: SURVEY.md section 8a / vad/models/self_attention.py:7-21
     m->r_win = add_param(m, "input_layer.0.weight", (size_t)D * F);
@@ -695,7 +700,7 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
-    if (!m || mode < 0 || mode > 5) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 7) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -785,8 +790,9 @@ int prepare_bf16_launch(savad_model* m) {
     if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::attention_pw_kernel_bf16, bf::PW_LDS_BYTES))) return rc;
-    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4>, r4 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
-    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<8>, r8 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
+    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 2, 0>, r4 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
+    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 4, 4>, r8 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
+    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<8, 4, 0>, r8 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
     m->lds_attrs_set = true;
     return SAVAD_OK;
 }
@@ -794,10 +800,10 @@ int prepare_bf16_launch(savad_model* m) {
 // T <= 32 with bf16 operands: the whole forward in one launch (savad_packed_bf16.h); a wave per packed block, NW blocks per
 // workgroup.  Weights, fragments, the PE table and the kernels' LDS attributes must be ready.
 bool packed_bf16_applies(const savad_model* m, int T) {
-    // row_mode 0 (automatic) and 4: 4-wave workgroups, two per CU; 5: 8-wave workgroups with the 4-deep ring (a tuning knob
-    // at T <= 32, where the persistent attention kernel it selects for long sequences does not exist); 1 - 3 keep the
-    // per-layer launches (the cross-check of the tests)
-    return T <= 32 && m->cfg.num_layers <= bf::PACKED_BF16_MAX_LAYERS && (m->row_mode == 0 || m->row_mode == 4 || m->row_mode == 5);
+    // row_mode 0 (automatic) and 4: picked by the number of blocks; 5 - 7: a fixed variant (launch_packed_forward_bf16; tuning
+    // knobs at T <= 32, where the persistent attention kernel that 5 selects for long sequences does not exist); 1 - 3 keep
+    // the per-layer launches (the cross-check of the tests)
+    return T <= 32 && m->cfg.num_layers <= bf::PACKED_BF16_MAX_LAYERS && (m->row_mode == 0 || m->row_mode >= 4);
 }
 void launch_packed_forward_bf16(savad_model* m, hipStream_t st, const float* x, int B, int T, int F, float* out, const WindowOffsets& wo,
                                 int win_base) {
@@ -818,12 +824,19 @@ void launch_packed_forward_bf16(savad_model* m, hipStream_t st, const float* x, 
     pm.L = L;
     const float c = (float)(1.4426950408889634 / sqrt((double)D));
     const size_t bias_bytes = (size_t)L * LBIAS * 4;
-    if (m->row_mode == 5)
-        hipLaunchKernelGGL((bf::packed_forward_kernel_bf16<8>), dim3((nblk + 7) / 8), dim3(512), bf::Ring<8>::NRING * bf::RING_BYTES + bias_bytes, st, x, B,
-                           T, F, nblk, pm, c, out, wo, win_base, m->d_sat);
+    // variant: row_mode 5 = 8-wave workgroups, 6 = 4 waves + 4 that move the weight stream through a 4-slot ring, 7 = 4 waves +
+    // 2 slots; automatic: 6 while there are fewer 4-block workgroups than twice the CUs (savad_packed_bf16.h)
+    const int variant = m->row_mode >= 5 ? m->row_mode : ((nblk + 3) / 4 <= 2 * m->n_cu ? 6 : 7);
+    const size_t ring2 = (size_t)2 * bf::RING_BYTES, ring4 = (size_t)4 * bf::RING_BYTES;
+    if (variant == 5)
+        hipLaunchKernelGGL((bf::packed_forward_kernel_bf16<8, 4, 0>), dim3((nblk + 7) / 8), dim3(512), ring4 + bias_bytes, st, x, B, T, F, nblk, pm, c, out,
+                           wo, win_base, m->d_sat);
+    else if (variant == 6)
+        hipLaunchKernelGGL((bf::packed_forward_kernel_bf16<4, 4, 4>), dim3((nblk + 3) / 4), dim3(512), ring4 + bias_bytes, st, x, B, T, F, nblk, pm, c, out,
+                           wo, win_base, m->d_sat);
     else
-        hipLaunchKernelGGL((bf::packed_forward_kernel_bf16<4>), dim3((nblk + 3) / 4), dim3(256), bf::Ring<4>::NRING * bf::RING_BYTES + bias_bytes, st, x, B,
-                           T, F, nblk, pm, c, out, wo, win_base, m->d_sat);
+        hipLaunchKernelGGL((bf::packed_forward_kernel_bf16<4, 2, 0>), dim3((nblk + 3) / 4), dim3(256), ring2 + bias_bytes, st, x, B, T, F, nblk, pm, c, out,
+                           wo, win_base, m->d_sat);
 }
 
 // bf16-operand forward: input_qkv -> [attention -> row] x L on fragment-major buffers

@@ -17,9 +17,19 @@
 //   weights   : [n-block][ks][lane 64][8 bf16], packed once by pack_weight_frags_kernel
 #pragma once
 #include "savad_kernels.h"
+#include <type_traits>
 
 namespace savad {
 namespace bf {
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_c(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for_c<B + 1, E>(f);
+    }
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -188,21 +198,64 @@ struct Ring {
     }
 };
 
-// acc[nbl] += W[ring n-block nbl] . x   (transposed form: lane = data row, registers = output features)
-__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[4], const char* ringblk, const bf16x8 (&xp)[8], int lane) {
+// acc[nbl] += W[ring n-block nbl] . x   (transposed form: lane = data row, registers = output features); SWAP: operands
+// swapped (lane = output feature, registers = data rows: V^T).
+// The 32 weight fragments of a ring block are read from LDS by HAND-issued ds_read_b128 with counted lgkmcnt waits, RING_PIPE
+// fragments ahead of the MFMA that consumes them (round 5).  Left to the compiler, the reads run two fragments ahead whatever
+// the register budget (ds_read, ds_read, wait, MFMA, wait, MFMA, ...): every pair of MFMAs (64 cycles) then waits out an LDS
+// round trip, and a wave alone on its SIMD kept the matrix pipe ~40 % busy (scripts/ubench/phase_timing_packed_bf16.py).
+// Counting is safe against LDS / scalar-memory operations the compiler issues in between: LDS data returns in order, so
+// "at most k operations outstanding" can only be reached once everything older than the last k has landed -- extra
+// operations make the wait longer, never shorter.  The same order of accumulation as before: the same bits.
+#ifndef SAVAD_RING_PIPE
+#define SAVAD_RING_PIPE 6
+#endif
+template <bool SWAP>
+__device__ __forceinline__ void gemm_ring_t(f32x16 (&acc)[4], const char* ringblk, const bf16x8 (&xp)[8], int lane) {
+#if SAVAD_RING_PIPE > 0
+    constexpr int P = SAVAD_RING_PIPE;
+    const unsigned a = (unsigned)(size_t)ringblk + (unsigned)lane * 16u;  // LDS byte address (low half of the flat address)
+    u32x4 f[P];
+    // (macros, not a compile-time loop over a generic lambda: clang rejects asm operands that name captured variables there)
+#define SAVAD_RING_LOAD(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[(i) % P]) : "v"(a), "n"((i) * FRAG_BYTES))
+#define SAVAD_RING_STEP(i)                                                                                              \
+    {                                                                                                                   \
+        constexpr int newer_ = 31 - (i) < P - 1 ? 31 - (i) : P - 1; /* of this statement's reads; anything else only adds */ \
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[(i) % P]) : "n"(newer_));                                         \
+        const bf16x8 w_ = __builtin_bit_cast(bf16x8, f[(i) % P]);                                                       \
+        acc[(i) / 8] = SWAP ? SAVAD_MFMA_BF16(xp[(i) % 8], w_, acc[(i) / 8]) : SAVAD_MFMA_BF16(w_, xp[(i) % 8], acc[(i) / 8]); \
+        if constexpr ((i) + P < 32) SAVAD_RING_LOAD((i) + P);                                                           \
+    }
+#define SAVAD_RING_STEP4(i) SAVAD_RING_STEP(i) SAVAD_RING_STEP((i) + 1) SAVAD_RING_STEP((i) + 2) SAVAD_RING_STEP((i) + 3)
+    SAVAD_RING_LOAD(0);
+    SAVAD_RING_LOAD(1);
+    if constexpr (P > 2) SAVAD_RING_LOAD(2);
+    if constexpr (P > 3) SAVAD_RING_LOAD(3);
+    if constexpr (P > 4) SAVAD_RING_LOAD(4);
+    if constexpr (P > 5) SAVAD_RING_LOAD(5);
+    if constexpr (P > 6) SAVAD_RING_LOAD(6);
+    if constexpr (P > 7) SAVAD_RING_LOAD(7);
+    static_assert(P >= 2 && P <= 8, "SAVAD_RING_PIPE");
+    SAVAD_RING_STEP4(0) SAVAD_RING_STEP4(4) SAVAD_RING_STEP4(8) SAVAD_RING_STEP4(12) SAVAD_RING_STEP4(16) SAVAD_RING_STEP4(20)
+    SAVAD_RING_STEP4(24) SAVAD_RING_STEP4(28)
+#undef SAVAD_RING_STEP4
+#undef SAVAD_RING_STEP
+#undef SAVAD_RING_LOAD
+#else
 #pragma unroll
     for (int nbl = 0; nbl < 4; ++nbl)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            acc[nbl] = SAVAD_MFMA_BF16(ldfrag(ringblk + ((nbl * 8 + ks) * 64 + lane) * 16), xp[ks], acc[nbl]);
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 w = ldfrag(ringblk + ((nbl * 8 + ks) * 64 + lane) * 16);
+            acc[nbl] = SWAP ? SAVAD_MFMA_BF16(xp[ks], w, acc[nbl]) : SAVAD_MFMA_BF16(w, xp[ks], acc[nbl]);
+        }
+#endif
 }
-// operands swapped: lane = output feature, registers = data rows (used for V^T)
+__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[4], const char* ringblk, const bf16x8 (&xp)[8], int lane) {
+    gemm_ring_t<false>(acc, ringblk, xp, lane);
+}
 __device__ __forceinline__ void gemm_ring_swapped(f32x16 (&acc)[4], const char* ringblk, const bf16x8 (&xp)[8], int lane) {
-#pragma unroll
-    for (int nbl = 0; nbl < 4; ++nbl)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            acc[nbl] = SAVAD_MFMA_BF16(xp[ks], ldfrag(ringblk + ((nbl * 8 + ks) * 64 + lane) * 16), acc[nbl]);
+    gemm_ring_t<true>(acc, ringblk, xp, lane);
 }
 
 // One of the three QKV ring blocks (rb = 0 query, 1 key: transposed form; 2 value: swapped form -> V^T)

@@ -73,18 +73,25 @@ __device__ __forceinline__ void unpark_h(f32x16 (&x)[4], const u32x4 (&hp)[8]) {
         }
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void packed_forward_kernel_bf16(
+// NR = ring slots (the DMA runs NR - 1 blocks ahead); DW = waves that do nothing but move the weight stream.
+//   <4, 2, 0>  two 4-wave workgroups per CU cover for each other's ring steps: the throughput regime
+//   <4, 4, 4>  fewer workgroups than CUs (the reference's own 1000-window chunks: 250 blocks): a block's chain is alone on its
+//              SIMD, and the 288 DMA instructions per forward it would issue itself (~66 cycles each, 15 % of its time:
+//              scripts/ubench/phase_timing_packed_bf16.py) go to four extra waves, three ring slots ahead
+//   <8, 4, 0>  8-wave workgroups (tuning knob)
+template <int NW, int NR, int DW>
+__global__ __launch_bounds__(64 * (NW + DW), (NW + DW == 8) ? 1 : 2) void packed_forward_kernel_bf16(
     const float* __restrict__ x, int B, int T, int F, int nblk, PackedBf16Model M, float qscale, float* __restrict__ out,
     WindowOffsets wo, int win_base, unsigned* __restrict__ satcnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using R = Ring<NW>;
+    using R = Ring<NW, NR>;
     float* lbias = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = blockIdx.x * NW + w;
     const bool live = blk < nblk;  // wave-uniform; a wave without a block still moves its share of the weight stream
-    const R ring{smem, w, lane};
+    const bool mover = DW > 0 && w >= NW;                 // a wave that only moves the weight stream
+    const R ring{smem, DW > 0 ? (w >= NW ? w - NW : w) : w, lane};
     const int L = M.L, NB = 12 * L;
     auto issue = [&](int t) {
         const int l = t / 12, i = t - 12 * l;
@@ -97,14 +104,29 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void packed_forward_kerne
                                  : Lw.w1 + (size_t)c * RING_BYTES + sgm * BLK_BYTES;
         });
     };
+#ifdef SAVAD_TIMING
+    long long pacc[4] = {0, 0, 0, 0}, pp = __builtin_readcyclecounter(), pn;
+#define SAVAD_PACC(i) do { pn = __builtin_readcyclecounter(); pacc[i] += pn - pp; pp = pn; } while (0)
+#else
+#define SAVAD_PACC(i) do {} while (0)
+#endif
     // acquire block t (wave-uniform), then keep the DMA DEPTH blocks ahead
     auto advance = [&](int t) {
+        SAVAD_PACC(0);  // compute since the last ring step
         ring.acquire(NB - 1 - t < R::DEPTH - 1 ? NB - 1 - t : R::DEPTH - 1);
-        if (t + R::DEPTH < NB) issue(t + R::DEPTH);
+        SAVAD_PACC(1);  // waiting for the block and the other waves
+        if ((DW == 0 || mover) && t + R::DEPTH < NB) issue(t + R::DEPTH);
+        SAVAD_PACC(2);  // issuing the DMA
     };
+    if (DW == 0 || mover) {
 #pragma unroll
-    for (int t = 0; t < R::DEPTH; ++t) issue(t);
-    for (int i = threadIdx.x * 4; i < L * LBIAS; i += 64 * NW * 4) st4(lbias + i, ld4(M.bias + i));  // published by the first ring barrier
+        for (int t = 0; t < R::DEPTH; ++t) issue(t);
+    }
+    for (int i = threadIdx.x * 4; i < L * LBIAS; i += 64 * (NW + DW) * 4) st4(lbias + i, ld4(M.bias + i));  // published by the first ring barrier
+    if (mover) {  // one barrier per ring block, like the waves that compute
+        for (int t = 0; t < NB; ++t) advance(t);
+        return;
+    }
 
     // ---- slots of the block: sequence blk * G + m / T, frame m % T
     const int G = 32 / T, seq = blk * G + m / T, t_frame = m % T;
@@ -270,6 +292,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void packed_forward_kerne
     const float mx = fmaxf(z0, z1);
     const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
     if (h == 0 && valid) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+#ifdef SAVAD_TIMING
+    SAVAD_PACC(0);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 4; ++i) g_savad_dbg[32 + i] = pacc[i];
+#endif
 }
 
 }  // namespace bf
