@@ -21,6 +21,18 @@ code passes because it waits before it touches a destination -- with stores in t
 tests/test_async_load_hazards.py runs the --lib form on the library in the tree; both forms report the same 531 / 56 / 464
 accesses for `row_kernel<true>` / `row_kernel<false>` / `packed_forward_kernel` as they were before the fix.
 
+Round 5 added two more rules, same data flow:
+  * LDS reads issued by hand (`ds_read_b128` in asm statements with counted `s_waitcnt lgkmcnt(N)`: the weight fragments of the bf16
+    ring GEMMs, savad_kernels_bf16.h: gemm_ring_t).  The queue holds the DS operations only: scalar-memory loads share the counter
+    and may return out of order, but an extra outstanding operation can only make the hardware's wait retire MORE of the (in-order)
+    DS operations than the model does -- the model is the conservative side.
+  * LDS-DMA destinations (`global_load_lds_*`): a workgroup's waves read an LDS block while another wave may already be
+    re-targeting it.  The protocol everywhere in csrc/ is "barrier, then DMA": the barrier a wave passes before it issues a DMA is
+    the one every wave reaches only after its last read of the block being replaced.  Rule: on no path may a wave issue a DMA,
+    access LDS (ds_read / ds_write) and issue a DMA again without an `s_barrier` in between (a removed or misplaced ring barrier
+    shows as exactly that).  Kernels in which one logical request is several statements with LDS reads of OTHER buffers scheduled
+    between them are listed in DMA_DISJOINT with the reason.
+
     python scripts/check_async_loads.py             # compiles csrc/savad.hip to assembly (cached by source hash) and checks it
     python scripts/check_async_loads.py --asm f.s   # checks an assembly file
     python scripts/check_async_loads.py --lib voice_activity_detection_amd/libsavad.so   # the device code of the built library itself
@@ -42,6 +54,18 @@ _REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 _LOAD = re.compile(r"^(global_load|buffer_load|flat_load|scratch_load)")
 _STORE = re.compile(r"^(global_store|buffer_store|flat_store|scratch_store|global_atomic|buffer_atomic|flat_atomic)")
 _LABEL = re.compile(r"^([.\w$]+):")
+_DSREAD = re.compile(r"^ds_read")
+_DSOP = re.compile(r"^ds_")
+# kernels whose LDS-DMA target cannot be what the wave reads between its last barrier and the DMA (substring of the symbol -> why)
+DMA_DISJOINT = {
+    "logmel_fft_kernel": "the DMA fills the sample stage; between barrier 1 and the DMA statements the wave only reads the exchange "
+                         "buffer Yl (its reads of the stage lie before barrier 1, the stage's next readers behind barrier 2)",
+    "5savad16attention_kernelE": "the next tile's 16 KiB are four dma_piece statements placed between the MFMAs of the tile being "
+                                 "computed on purpose (savad_kernels.h): one request, ordered by the barrier at the head of the tile",
+    "5savad20attention_row_kernelI": "as attention_kernel (the same tile loop)",
+    "attention_pw_kernel_bf16": "a generated instruction stream that interleaves each stage's DMA with the LDS reads of the stage in "
+                                "use; its barriers are modelled instruction by instruction in scripts/gfx950_sim.py",
+}
 
 
 def regs(text: str) -> frozenset:
@@ -55,7 +79,8 @@ def regs(text: str) -> frozenset:
 
 
 class Insn:
-    __slots__ = ("line", "text", "op", "in_asm", "is_load", "is_store", "dst", "touched", "vmcnt", "target", "kind")
+    __slots__ = ("line", "text", "op", "in_asm", "is_load", "is_store", "dst", "touched", "vmcnt", "target", "kind", "is_dsread", "is_ds",
+                 "dsdst", "lgkmcnt", "is_dma", "is_barrier")
 
     def __init__(self, line: int, text: str, in_asm: bool):
         self.line, self.text, self.in_asm = line, text, in_asm
@@ -71,6 +96,20 @@ class Insn:
             self.touched = regs(",".join(args.split(",")[1:]))
         else:
             self.touched = regs(args)
+        self.is_ds = bool(_DSOP.match(self.op))
+        self.is_dsread = bool(_DSREAD.match(self.op))
+        self.dsdst = regs(args.split(",")[0]) if self.is_dsread else frozenset()
+        if self.is_dsread:
+            self.touched = regs(",".join(args.split(",")[1:]))
+        self.is_dma = self.is_load and ("lds" in self.op or " lds" in args)
+        self.is_barrier = self.op == "s_barrier"
+        self.lgkmcnt = None
+        if self.op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", text)
+            if m:
+                self.lgkmcnt = int(m.group(1))
+            elif re.fullmatch(r"s_waitcnt\s+(0|0x0)", text):
+                self.lgkmcnt = 0
         self.vmcnt = None
         if self.op == "s_waitcnt":
             m = re.search(r"vmcnt\((\d+)\)", text)
@@ -166,7 +205,7 @@ def disassemble_library(lib: Path) -> str:
                               capture_output=True, text=True).stdout
 
 
-def check_kernel(blocks, count_stores: bool = False):
+def check_kernel(blocks, count_stores: bool = False, domain: str = "vm", all_loads: bool = False):
     """-> (hazards, truncated = False); a hazard is (line, text, line of the pending load, its text).
 
     Data flow over the control-flow graph.  The state is, for every load that may be in flight, the number of vector-memory
@@ -176,6 +215,10 @@ def check_kernel(blocks, count_stores: bool = False):
     result exact per load over all paths of the graph (infeasible ones included: conservative).
     count_stores: stores and atomics take their place in the queue (gfx9 has one counter for both and the compiler's own waits
     rely on their retiring in issue order); without it they are ignored, which is the stricter reading for hand-placed waits."""
+    if domain == "dma":
+        return check_dma_after_access(blocks), False
+    lds = domain == "lgkm"   # the same flow over the DS queue: hand-issued ds_read against s_waitcnt lgkmcnt(N)
+    cap = 16 if lds else 64  # the counter's range: anything older has returned
     index = {label: k for k, (label, _) in enumerate(blocks)}
     loads, hazards = {}, {}
     state_in = [None] * len(blocks)
@@ -201,15 +244,21 @@ def check_kernel(blocks, count_stores: bool = False):
         st = dict(state_in[k])
         ended = False
         for ins in blocks[k][1]:
-            if ins.vmcnt is not None:
-                st = {key: r for key, r in st.items() if r < ins.vmcnt}
-                continue
+            cnt = ins.lgkmcnt if lds else ins.vmcnt
+            if cnt is not None:
+                st = {key: r for key, r in st.items() if r < cnt}
+                if (ins.vmcnt is not None or ins.lgkmcnt is not None):
+                    continue
             for pl in st:
-                if ins.touched & loads[pl].dst:
+                if ins.touched & (loads[pl].dsdst if lds else loads[pl].dst):
                     hazards.setdefault((ins.line, pl), (ins.line, ins.text, pl, loads[pl].text))
-            if ins.is_load or (count_stores and ins.is_store):
-                st = {key: r + 1 for key, r in st.items() if r + 1 < 64}   # (the counter holds 63: older ones have returned)
-                if ins.is_load and ins.in_asm and ins.dst:
+                elif lds and not ins.is_dsread and (regs(ins.text[len(ins.op):]) & loads[pl].dsdst):
+                    hazards.setdefault((ins.line, pl), (ins.line, ins.text, pl, loads[pl].text))
+            queued = ins.is_ds if lds else (ins.is_load or (count_stores and ins.is_store))
+            if queued:
+                st = {key: r + 1 for key, r in st.items() if r + 1 < cap}   # (older ones have returned: the counter's range)
+                mine = (ins.is_dsread and (ins.in_asm or all_loads) and ins.dsdst) if lds else (ins.is_load and ins.in_asm and ins.dst)
+                if mine:
                     loads[ins.line] = ins
                     st[ins.line] = 0
             if ins.kind == "jump":
@@ -225,6 +274,52 @@ def check_kernel(blocks, count_stores: bool = False):
         if not ended and k + 1 < len(blocks):
             merge_into(k + 1, st)
     return sorted(hazards.values()), False
+
+
+def check_dma_after_access(blocks):
+    """LDS-DMA rule.  Per path a three-state machine: clear -(DMA)-> issued -(ds_read / ds_write)-> issued + accessed; `s_barrier`
+    returns to clear; a DMA in the third state is reported: the wave has requested a block, worked on LDS, and requests again without
+    having met the other waves in between -- the second request may land on a block they still read.  (A read the compiler hoists
+    between a barrier and the first DMA behind it is not reported: the machine is still clear there.)  Forward data flow; where
+    paths meet the more advanced state wins."""
+    index = {label: k for k, (label, _) in enumerate(blocks)}
+    seen = {0: (0, None, None)}
+    work = [0]
+    hazards = {}
+
+    def merge_into(k, st):
+        cur = seen.get(k)
+        if cur is None or st[0] > cur[0]:
+            seen[k] = st
+            work.append(k)
+
+    while work:
+        k = work.pop()
+        state, dma, acc = seen[k]
+        ended = False
+        for ins in blocks[k][1]:
+            if ins.is_barrier:
+                state, dma, acc = 0, None, None
+            elif ins.is_dma:
+                if state == 2:
+                    hazards.setdefault(ins.line, (ins.line, ins.text, acc.line, acc.text + f"   (behind the DMA of line {dma.line}, no s_barrier since)"))
+                elif state == 0:
+                    state, dma = 1, ins
+            elif ins.is_ds and state == 1:
+                state, acc = 2, ins
+            if ins.kind == "jump":
+                if ins.target in index:
+                    merge_into(index[ins.target], (state, dma, acc))
+                ended = True
+                break
+            if ins.kind == "cond" and ins.target in index:
+                merge_into(index[ins.target], (state, dma, acc))
+            if ins.kind == "end":
+                ended = True
+                break
+        if not ended and k + 1 < len(blocks):
+            merge_into(k + 1, (state, dma, acc))
+    return sorted(hazards.values())
 
 
 def source_hash() -> str:
@@ -263,11 +358,20 @@ def check_library(lib: Path):
 
 
 def _check(kernel_iter, count_stores):
+    """{symbol: (hazards, truncated)}: vector-memory loads, hand-issued LDS reads and LDS-DMA destinations together (a hazard's text
+    says which: the pending instruction is a global_load, a ds_read, or -- for the DMA rule -- the LDS access not yet fenced)"""
     report = {}
     for sym, blocks in kernel_iter:
-        if not any(i.is_load and i.in_asm for _, b in blocks for i in b):
-            continue
-        report[sym] = check_kernel(blocks, count_stores=count_stores)
+        insns = [i for _, b in blocks for i in b]
+        hazards = []
+        if any(i.is_load and i.in_asm and not i.is_dma for i in insns):
+            hazards += check_kernel(blocks, count_stores=count_stores)[0]
+        if any(i.is_dsread and i.in_asm for i in insns):
+            hazards += check_kernel(blocks, domain="lgkm", all_loads=count_stores)[0]   # (library form: the compiler's own reads too)
+        if any(i.is_dma for i in insns) and not any(key in sym for key in DMA_DISJOINT):
+            hazards += check_kernel(blocks, domain="dma")[0]
+        if hazards or any((i.is_load and i.in_asm) or (i.is_dsread and i.in_asm) for i in insns):
+            report[sym] = (sorted(hazards), False)
     return report
 
 

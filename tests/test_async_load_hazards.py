@@ -99,3 +99,95 @@ def test_no_kernel_of_the_built_library_touches_a_register_with_a_load_in_flight
     assert len(report) >= 40
     bad = {sym: (h[:4], t) for sym, (h, t) in report.items() if h or t}
     assert not bad, f"registers touched while their load is in flight: {bad}"
+
+
+ASM_LDS = """
+_Z4ringPf:                              ; @_Z4ringPf
+; %bb.0:
+	ds_read_b128 v[20:23], v2 offset:64
+	;;#ASMSTART
+	ds_read_b128 v[4:7], v1 offset:0
+	;;#ASMEND
+	;;#ASMSTART
+	ds_read_b128 v[8:11], v1 offset:1024
+	;;#ASMEND
+	s_load_dwordx2 s[4:5], s[0:1], 0x0
+	;;#ASMSTART
+	s_waitcnt lgkmcnt({n})
+	;;#ASMEND
+	v_mfma_f32_32x32x16_bf16 v[32:47], v[4:7], v[12:15], v[32:47]
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_hand_issued_lds_reads_are_tracked(tmp_path):
+    """round 5: ds_read_b128 in asm statements against counted lgkmcnt waits (the bf16 ring GEMMs).  One read may stay in flight
+    behind lgkmcnt(1) -- the younger one; with lgkmcnt(2) the MFMA reads a fragment that has not landed.  The scalar load in
+    between is not part of the queue (it can only make the hardware's wait retire more)."""
+    chk = _checker()
+    f = tmp_path / "lds.s"
+    f.write_text(ASM_LDS.format(n=1))
+    (_, (hazards, _)), = chk.check_file(f).items()
+    assert hazards == []
+    f.write_text(ASM_LDS.format(n=2))
+    (_, (hazards, _)), = chk.check_file(f).items()
+    assert len(hazards) == 1 and hazards[0][1].startswith("v_mfma") and hazards[0][3].startswith("ds_read_b128 v[4:7]")
+
+
+ASM_DMA = """
+_Z4ringPf:                              ; @_Z4ringPf
+; %bb.0:
+	global_load_lds_dwordx4 v1, s[2:3]
+.LBB0_1:
+	s_waitcnt vmcnt(0)
+	{barrier}
+	global_load_lds_dwordx4 v1, s[2:3] offset:1024
+	ds_read_b128 v[4:7], v2
+	s_waitcnt lgkmcnt(0)
+	v_mfma_f32_32x32x16_bf16 v[32:47], v[4:7], v[12:15], v[32:47]
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_a_ring_without_its_barrier_is_reported(tmp_path):
+    """round 5: LDS-DMA destinations.  barrier -> request -> read -> barrier -> request is the protocol; without the barrier the
+    second request follows the wave's own LDS read directly, and may land on a block other waves still read."""
+    chk = _checker()
+    f = tmp_path / "dma.s"
+    f.write_text(ASM_DMA.format(barrier="s_barrier"))
+    assert all(h == [] for h, _ in chk.check_file(f).values())
+    f.write_text(ASM_DMA.format(barrier="s_nop 0"))
+    (_, (hazards, _)), = chk.check_file(f).items()
+    assert len(hazards) == 1 and hazards[0][1].startswith("global_load_lds") and hazards[0][3].startswith("ds_read_b128")
+
+
+@pytest.fixture(scope="module")
+def fault_asm(tmp_path_factory):
+    """csrc/savad.hip compiled to assembly with every fault of SAVAD_FAULT_INJECT switched on (savad_kernels.h)"""
+    import subprocess
+
+    from voice_activity_detection_amd.build import hipcc
+
+    out = tmp_path_factory.mktemp("fault") / "fault7.s"
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "--cuda-device-only", "-S", "-DSAVAD_FAULT_INJECT=7",
+                    str(REPO / "voice_activity_detection_amd" / "csrc" / "savad.hip"), "-o", str(out)], check=True)
+    return out
+
+
+def test_deliberately_broken_builds_fail_the_check(fault_asm):
+    """NEGATIVE test on the real sources: one wwait removed from the single-launch fp32 forward (bit 1), the bf16 ring GEMMs waiting
+    for one LDS fragment too few (bit 2), the bf16 weight ring without its workgroup barrier (bit 4).  Each must show up, in the
+    kernel it was planted in and as the kind of hazard it is."""
+    chk = _checker()
+    report = chk.check_file(fault_asm)
+    by = lambda key: [h for sym, (hz, _) in report.items() if key in sym for h in hz]
+    fp32 = by("21packed_forward_kernelE")
+    assert fp32 and all(h[3].startswith("global_load_dwordx4") for h in fp32)             # registers of a block still in flight
+    row = by("15row_kernel_bf16ILb0ELi4E")
+    assert any(h[1].startswith("v_mfma") and h[3].startswith("ds_read_b128") for h in row)   # a fragment used before it landed
+    assert any(h[1].startswith("global_load_lds") for h in row)                              # a ring slot re-targeted without the barrier
+    packed = by("26packed_forward_kernel_bf16ILi4ELi2ELi0E")
+    assert any(h[1].startswith("v_mfma") and h[3].startswith("ds_read_b128") for h in packed) and any(h[1].startswith("global_load_lds") for h in packed)

@@ -36,5 +36,23 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def build_variant(out: Path, defines=(), force: bool = False, verbose: bool = False) -> Path:
+    """The same sources with extra -D switches into `out` (experiments and the fault-injected library of the negative tests:
+    tests/fault/; never the product)."""
+    out = Path(out)
+    if not force and out.exists() and all(d.stat().st_mtime <= out.stat().st_mtime for d in DEPS):
+        return out
+    out.parent.mkdir(parents=True, exist_ok=True)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value",
+           *[f"-D{d}" for d in defines], str(SRC), "-o", str(out)]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
+
+
+FAULT_LIB = PKG.parent / "tests" / "fault" / "libsavad_fault1.so"  # SAVAD_FAULT_INJECT=1: tests/test_gpu_cache_pressure.py
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -298,6 +298,13 @@ __device__ long long g_savad_dbg[64];
     do {               \
     } while (0)
 #endif
+// Fault injection for the NEGATIVE tests of the hazard checkers (tests/test_async_load_hazards.py, tests/test_gpu_cache_pressure.py;
+// never defined in the product build): bit 1 = the single-launch fp32 forward uses layer 0's query block without waiting
+// for it (requested one LayerNorm earlier: an L2 hit usually makes it, a miss does not), bit 2 = the bf16
+// ring GEMMs wait for one LDS fragment too few, bit 4 = the bf16 weight ring skips its workgroup barrier.
+#ifndef SAVAD_FAULT_INJECT
+#define SAVAD_FAULT_INJECT 0
+#endif
 #ifndef SAVAD_ABLATE
 #define SAVAD_ABLATE 0  // experiment switch (scripts/ablate.sh): 1 = no DMA, 2 = no ring barrier, 4 = no softmax, 8 = no LDS operand reads (bf16 attention)
 #endif
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
         SAVAD_STAMP(50);
         wload_frag(wb, frag, 4 + w, voff);
         f32x16 qb = bias_block(lbn + 32 * w, h);
-        wwait<16>(wa);
+        if (!(SAVAD_FAULT_INJECT & 1) || l > 0) wwait<16>(wa);
         wmma_k128(qb, wa, xg);
         wload_frag(wa, frag, 8 + w, voff);
         f32x16 kb = bias_block(lbn + D + 32 * w, h);

@@ -194,7 +194,7 @@ struct Ring {
         else
             __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         asm volatile("" ::: "memory");
-        __syncthreads();
+        if (!(SAVAD_FAULT_INJECT & 4)) __syncthreads();
     }
 };
 
@@ -220,7 +220,7 @@ __device__ __forceinline__ void gemm_ring_t(f32x16 (&acc)[4], const char* ringbl
 #define SAVAD_RING_LOAD(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[(i) % P]) : "v"(a), "n"((i) * FRAG_BYTES))
 #define SAVAD_RING_STEP(i)                                                                                              \
     {                                                                                                                   \
-        constexpr int newer_ = 31 - (i) < P - 1 ? 31 - (i) : P - 1; /* of this statement's reads; anything else only adds */ \
+        constexpr int newer_ = (31 - (i) < P - 1 ? 31 - (i) : P - 1) + ((SAVAD_FAULT_INJECT & 2) ? 1 : 0); /* of this statement's reads */ \
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[(i) % P]) : "n"(newer_));                                         \
         const bf16x8 w_ = __builtin_bit_cast(bf16x8, f[(i) % P]);                                                       \
         acc[(i) / 8] = SWAP ? SAVAD_MFMA_BF16(xp[(i) % 8], w_, acc[(i) / 8]) : SAVAD_MFMA_BF16(w_, xp[(i) % 8], acc[(i) / 8]); \
