@@ -8,9 +8,10 @@
 One "step" = one pass of the hot path over one batch of synthetic mel frames: forward of
 SelfAttentiveVAD on a device-resident [B, T, F] tensor -> device-resident [B, T, 2] log-probs
 (N > 1: every rank runs its own B-sequence shard through voice_activity_detection_amd.distributed.ShardedPipeline, which issues every
-collective of the run: by default one RCCL all_gather of [B,T,2] per forward, lagging behind the forwards in flight (--gather step, what
-`value` is quoted on); with --gather final every forward writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block --
-north_star's "single RCCL gather at the end".  Both are measured on every N > 1 run.  `--backend gloo --stub-forward` runs the same control
+collective of the run: by default (--gather final, what `value` is quoted on) every forward writes into a [K,B,T,2] send buffer and ONE
+RCCL all_gather closes the K-step block -- north_star's "single RCCL gather at the end"; --gather step issues one all_gather of [B,T,2]
+per forward, lagging behind the forwards in flight.  Both are measured on every N > 1 run.  `python bench.py --gpus N` without a
+launcher starts N ranks itself (torch.distributed.run, one per GPU).  `--backend gloo --stub-forward` runs the same control
 flow on CPU ranks with a stand-in forward: a dry run for tests/test_dist_gloo.py, never a measurement.)
 Default workload = BASELINE.json configs[1]: [32, 800, 80] fp32 per GPU, seeded weights.
 
@@ -80,7 +81,7 @@ def launch_work(name: str, B: int, T: int, e: int):
     if base == "input_qkv":
         return 118784.0 * frames, frames * (F * e + D * hres + 3 * D * e)
     if base == "packed_forward":  # whole forward in one launch (T <= 32): features in, log-probs out
-        return flops_per_frame(T) * frames, frames * (F * e + 8)
+        return flops_per_frame(T) * frames, frames * (F * 4 + 8)   # (the windows are fp32 features in both precisions)
     return 0.0, 0
 
 
@@ -301,7 +302,8 @@ class Runner:
         self.stub = stub
         # each rank gets its own shard of the global batch (weak scaling: B per GPU fixed)
         x = torch.from_numpy(np.random.default_rng(rank).uniform(-13.8, 4.2, (B, T, F_MEL)).astype(np.float32)).to(dev)
-        self.x = x.to(torch.bfloat16) if (precision == "bf16" and not stub) else x
+        # bf16 features for the long-sequence configs; the reference pipeline's windows (T <= 32) are cut out of an fp32 log-mel matrix
+        self.x = x.to(torch.bfloat16) if (precision == "bf16" and not stub and T > 32) else x
         self.in_flight_request = in_flight
         if stub:
             self.model = None
@@ -443,6 +445,34 @@ class Runner:
         kt = self.model.kernel_times()
         self.model.set_profiling(0)
         return kt
+
+
+    def kernel_profile_in_flight(self, steps, ms_hint=None):
+        """the per-launch durations in the mode `value` is quoted in: `in_flight` forwards on their own streams, every replica's
+        launches bracketed by HIP events on ITS stream -> {label: mean ms over replicas and launches} (stretched by the overlap)"""
+        pipe = getattr(self.sp, "pipe", None)
+        if self.stub or pipe is None or pipe.active < 2:
+            return None
+        settle = max(steps, int(0.15 / (ms_hint * 1e-3))) if ms_hint else 200
+        self.drain()
+        torch.cuda.synchronize()
+        reps = pipe._replicas[:pipe.active]
+        outs = [torch.empty((self.B, self.T, 2), dtype=torch.float32, device=self.dev) for _ in reps]
+        for rep in reps:
+            pipe._follow(rep)
+            rep.set_profiling(steps, skip=settle)
+        with torch.no_grad():
+            for _ in range(settle + steps):
+                for k in range(len(reps)):
+                    pipe.submit(self.x, out=outs[k])
+            pipe.join()
+        torch.cuda.synchronize()
+        acc = {}
+        for rep in reps:
+            for n, t in rep.kernel_times():
+                acc.setdefault(n, []).append(t)
+            rep.set_profiling(0)
+        return {n: round(sum(ts) / len(ts), 4) for n, ts in acc.items()}
 
 
 def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False, ms_one_forward=None):
@@ -608,6 +638,69 @@ def config3_global_one_gpu(state, dev, min_seconds):
             "finite": bool(torch.isfinite(y).all().item()), "blocks": blocks, "unit": "frames/s"}
 
 
+def logmel_roofline(n_samples, n_frames, ms):
+    """The log-mel kernel against both roofs.  SURVEY.md section 8f#1 classifies it HBM-bound: algorithmic bytes = the samples read
+    once + the [N,80] fp32 matrix written (4 B/sample + 320 B/frame).  Round 5's factored DFT (512 = 32 x 16) issues 624
+    v_mfma_f32_32x32x2_f32 per 32 frames (4096 FLOP each) instead of 3584: what binds it now is the fp32 MFMA rate."""
+    by = 4.0 * n_samples + 320.0 * n_frames
+    fl = ((n_frames + 31) // 32) * 624 * 4096.0
+    t = ms * 1e-3
+    return {"algorithmic_bytes": by, "hbm_achieved_TBps": round(by / t / 1e12, 3), "hbm_frac": round(by / t / 1e12 / PEAK_HBM_TBPS, 4),
+            "issued_flops": fl, "mfma_achieved_TFLOPs": round(fl / t / 1e12, 1), "mfma_frac": round(fl / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "bound": "mfma (fp32)", "traffic": profile_traffic("logmel", "logmel_fft_kernel")}
+
+
+def profile_traffic(tag, kernel):
+    """HBM-side bytes per launch of `kernel` from profiles/*_{tag}_traffic.json, quoted only when taken on the running sources"""
+    want = kernel_source_hash()
+    for f in reversed(sorted((REPO / "profiles").glob(f"*_{tag}_traffic.json"))):
+        try:
+            data = json.loads(f.read_text())
+        except Exception:
+            continue
+        if data.get("csrc_hash") != want:
+            continue
+        for key, entry in data.items():
+            if isinstance(entry, dict) and key.startswith(kernel):
+                return round(entry["hbm_bytes_per_launch"])
+    return None
+
+
+def reference_mode_hour(state, dev, min_seconds):
+    """The reference's OWN mode at configs[4]'s size: an hour of audio = 360 001 feature frames -> 359 963 windows of 7 frames
+    (vad/predictor.py:169-224 cuts N - 38 of them, 1000 per forward) -> forward -> boosted probabilities [N,7] (:238-258), one
+    library call (savad_predict_probabilities) on a device-resident feature matrix; fp32 and bf16 operands."""
+    from voice_activity_detection_amd import SelfAttentiveVAD, VADFromScratchPredictor
+    from voice_activity_detection_amd.features import log_mel
+
+    seconds = 3600
+    model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(dev).eval()
+    rng = np.random.default_rng(0)
+    audio = torch.from_numpy((rng.standard_normal(16000 * seconds, dtype=np.float32) * 0.1)).to(dev)
+    feat = log_mel(audio, dev)
+    N = int(feat.shape[0])
+    windows = N - 38
+    res = {"workload": f"reference mode, {seconds} s of audio on ONE GPU: feature matrix [{N},80] -> {windows} windows of 7 frames "
+                       "(vad/predictor.py:169-224) -> forward -> boosted probabilities [N,7] (:238-258)", "audio_seconds": seconds,
+           "frames": N, "windows": windows, "flops": windows * 7 * flops_per_frame(7)}
+    for prec in ("fp32", "bf16"):
+        model.precision = prec
+        pred = VADFromScratchPredictor(model, dev)
+        med, mn, blocks, out = _event_blocks(lambda: pred.predict_probabilities_device(feat), 1 if prec == "fp32" else 4, min_seconds, warm=2)
+        probs = out[0]
+        peak = PEAK_BF16_MFMA_TFLOPS if prec == "bf16" else PEAK_FP32_MFMA_TFLOPS
+        tf = res["flops"] / (med * 1e-3) / 1e12
+        res[prec] = {"ms_per_hour_of_audio": round(med, 4), "ms_min": round(mn, 4), "blocks": blocks, "rtf": round(med * 1e-3 / seconds, 10),
+                     "windows_per_s": round(windows / (med * 1e-3), 1), "window_frames_per_s": round(windows * 7 / (med * 1e-3), 1),
+                     "audio_frames_per_s": round(N / (med * 1e-3), 1),
+                     "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
+                     "finite": bool(torch.isfinite(probs).all().item())}
+    model.precision = "fp32"
+    return res
+
+
 def stream_one_hour(state, dev, min_seconds):
     """BASELINE configs[4] at its full size on one GPU: 1 h of synthetic 16 kHz audio resident on the device -> log-mel
     [360001, 80] -> 900 sliding windows T=800 hop=400 -> forward -> overlap merge -> per-frame probabilities; fp32 and
@@ -625,7 +718,7 @@ def stream_one_hour(state, dev, min_seconds):
     N = int(feat.shape[0])
     res = {"workload": f"BASELINE configs[4] on ONE GPU: {seconds} s of 16 kHz audio -> log-mel [{N},80] -> 900 windows T=800 hop=400 -> "
                        "forward -> overlap merge -> probabilities", "audio_seconds": seconds, "frames": N,
-           "logmel_ms": round(mel_med, 4), "logmel_ms_min": round(mel_min, 4)}
+           "logmel_ms": round(mel_med, 4), "logmel_ms_min": round(mel_min, 4), "logmel_roofline": logmel_roofline(audio.numel(), N, mel_med)}
     for prec in ("fp32", "bf16"):
         model.precision = prec
         sp = StreamingPredictor(model, dev, 800, 400, max_batch=256)
@@ -678,11 +771,11 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="independent forwards kept in flight (own HIP stream / library handle / workspace each): 0 = pick the fastest "
                          "of 1, 2, 3 for the shape during warm-up (default), N = exactly N")
-    ap.add_argument("--gather", default="step", choices=["step", "final"],
-                    help="multi-GPU: which gather mode `value` is quoted on (both are always measured and printed): 'step' (default) = "
-                         "one all_gather of the [B,T,2] log-probs per forward, issued while the newer forwards run; 'final' = every forward "
-                         "writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block -- north_star's 'a single RCCL "
-                         "gather over xGMI at the end' (both: voice_activity_detection_amd.distributed.ShardedPipeline)")
+    ap.add_argument("--gather", default="final", choices=["step", "final"],
+                    help="multi-GPU: which gather mode `value` is quoted on (both are always measured and printed): 'final' (default) = every "
+                         "forward writes into a [K,B,T,2] send buffer and ONE all_gather closes the K-step block -- north_star's 'a single RCCL "
+                         "gather over xGMI at the end'; 'step' = one all_gather of the [B,T,2] log-probs per forward, issued while the newer "
+                         "forwards run (both: voice_activity_detection_amd.distributed.ShardedPipeline)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend: nccl (= RCCL, default); gloo only together with --stub-forward")
     ap.add_argument("--stub-forward", action="store_true",
@@ -695,8 +788,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` on its own: become the launcher (one rank per GPU under torch.distributed.run, this file again)
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                      "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]])
         args.gpus = world
     stub = args.stub_forward
     if args.backend == "gloo" and not stub:
@@ -757,6 +857,7 @@ def main():
         main_run.drain()
         main_run.sp.set_in_flight(tuned)
     ktimes = [] if (args.no_events or stub) else main_run.kernel_profile(min(K, 20), (one or head)["ms_per_step"])
+    ktimes_in_flight = None if (args.no_events or stub) else main_run.kernel_profile_in_flight(min(K, 20), head["ms_per_step"])
     clocks1 = None if stub else gpu_state()
 
     # ---- secondary legs, measured in the same run so that they are driver-witnessed
@@ -801,7 +902,8 @@ def main():
                       "finite": r.delivered(),
                       "roofline": roofline_block(kt, prec, b2, t2, s["ms_per_step"], profiled_shape=True, ms_one_forward=s1["ms_per_step"])})
             if gm:
-                s["parallelism"] = f"batch-shard x{world} + 1 RCCL all_gather of [{b2},{t2},2] f32 per forward"
+                s["parallelism"] = (f"batch-shard x{world} + 1 RCCL all_gather of [{b2},{t2},2] f32 per forward" if gm == "step" else
+                                    f"batch-shard x{world} + 1 RCCL all_gather of all K batches' [{b2},{t2},2] f32 per block")
             return s
         return run
 
@@ -811,6 +913,9 @@ def main():
                 leg("configs2_bf16_b256_t800", shape_leg("bf16", 256, 800, None))
             if (args.precision, B, T) != ("fp32", 1000, 7):
                 leg("pipeline_fp32_b1000_t7", shape_leg("fp32", 1000, 7, None))
+            if (args.precision, B, T) != ("bf16", 1000, 7):
+                leg("pipeline_bf16_b1000_t7", shape_leg("bf16", 1000, 7, None))
+            leg("reference_mode_1h", lambda: reference_mode_hour(state, dev, args.min_seconds))
             leg("configs0_clip10s_audio_to_probabilities", lambda: clip_pipeline(state, dev, 10.0, args.min_seconds))
             leg("configs3_global_b2048_one_gpu", lambda: config3_global_one_gpu(state, dev, args.min_seconds))
             leg("configs4_stream_1h", lambda: stream_one_hour(state, dev, args.min_seconds))
@@ -854,6 +959,12 @@ def main():
             "clocks": {"start": clocks0, "end": clocks1},
             "collective_counts": all_counts,
         }
+        if ktimes_in_flight:   # the launches' durations in the mode `value` is quoted in (stretched by the overlap; sum / in_flight ~ ms_per_step)
+            line["roofline"]["kernels_ms_in_flight"] = ktimes_in_flight
+            line["roofline"]["kernels_ms_in_flight_note"] = (f"mean launch durations with {main_run.sp.in_flight} forwards in flight, HIP events on each "
+                                                            "forward's own stream; per_kernel / kernels_ms / frac are one forward at a time")
+        if os.environ.get("SAVAD_LIB"):   # a kernel experiment: never to be mistaken for the product library
+            line["library_override"] = os.environ["SAVAD_LIB"]
         if stub:
             line.update({"stub_forward": True, "data": "STUB forward on the CPU (control-flow dry run): no number in this line is a measurement",
                          "dtype": "none (stub)"})

@@ -194,6 +194,29 @@ def test_bench_runs_with_two_gloo_ranks(tmp_path):
     assert c0 == c1 and c0["all_gather"] > 0 and c0["barrier"] > 0
 
 
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` invoked PLAINLY (no launcher, no WORLD_SIZE): the file re-executes itself under
+    torch.distributed.run with one rank per GPU -- the form the driver used for its 1-GPU line; with N > 1 it used to exit with a
+    usage message.  The headline of an N > 1 run is the single gather that closes the block (north_star), and the line says so."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(repo / "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-forward", "--steps", "3", "--warmup", "1",
+           "--min-seconds", "0.01", "--batch", "2", "--frames", "40", "--config3-shape", "3,24"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["finite"] is True and d["config"]["global_batch"] == 4
+    assert "per block" in d["config"]["parallelism"] and d["gather_final_ms"] == d["ms_per_step"]   # value = the single-gather mode
+    assert "gather_step_ms" in d and "`value` is quoted on gather_final" in d["note"]
+
+
 def test_sharded_pipeline_without_a_process_group():
     """no process group: the plain pipeline (world 1, no collective), with its argument checks"""
     from voice_activity_detection_amd.distributed import ShardedPipeline, collective_counts, forward_sharded_many
