@@ -703,8 +703,9 @@ def reference_mode_hour(state, dev, min_seconds):
 
 def stream_one_hour(state, dev, min_seconds):
     """BASELINE configs[4] at its full size on one GPU: 1 h of synthetic 16 kHz audio resident on the device -> log-mel
-    [360001, 80] -> 900 sliding windows T=800 hop=400 -> forward -> overlap merge -> per-frame probabilities; fp32 and
-    bf16 operands; real-time factor with and without the log-mel front-end."""
+    [360001, 80] -> 900 sliding windows T=800 hop=400 (read in place: savad_forward_strided) -> forward -> overlap merge ->
+    per-frame probabilities; fp32 and bf16 operands; real-time factor with and without the log-mel front-end, and through the
+    audio-level entry point of the sharded run (StreamingPredictor.predict_audio_device)."""
     from voice_activity_detection_amd import SelfAttentiveVAD, StreamingPredictor
     from voice_activity_detection_amd.features import log_mel
 
@@ -723,7 +724,11 @@ def stream_one_hour(state, dev, min_seconds):
         model.precision = prec
         sp = StreamingPredictor(model, dev, 800, 400, max_batch=256)
         med, mn, blocks, probs = _event_blocks(lambda: sp.predict_device(feat), 2 if prec == "fp32" else 8, min_seconds, warm=2)
+        e2e, e2e_min, _, probs2 = _event_blocks(lambda: sp.predict_audio_device(audio), 2 if prec == "fp32" else 8, min_seconds / 2, warm=1)
         res[prec] = {"ms_per_hour_of_audio": round(med, 4), "ms_min": round(mn, 4), "blocks": blocks,
+                     # the audio-level entry point (what a rank of the sharded run executes for its span): log-mel + windows in place + merge
+                     "from_audio_ms": round(e2e, 4), "from_audio_ms_min": round(e2e_min, 4), "rtf_from_audio": round(e2e * 1e-3 / seconds, 10),
+                     "from_audio_equals_two_steps": bool(torch.equal(probs2, probs)),
                      "rtf_without_logmel": round(med * 1e-3 / seconds, 10), "rtf_with_logmel": round((med + mel_med) * 1e-3 / seconds, 10),
                      "frames_per_s": round(N / (med * 1e-3), 1), "finite": bool(torch.isfinite(probs).all().item()),
                      "in_unit_interval": bool(((probs >= 0) & (probs <= 1)).all().item())}

@@ -105,6 +105,11 @@ int savad_residual_saturations(savad_handle h, unsigned long long* count, void* 
  * precision only).  Output is always fp32 log-probabilities. */
 int savad_forward_ex(savad_handle h, const void* x, int x_dtype, int B, int T, float* out, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The same with sequences that OVERLAP in memory: sequence b starts x_batch_stride elements behind sequence b-1
+ * (x_batch_stride = T * feature_size is savad_forward_ex).  The streaming mode reads its windows [hop w, hop w + T) in place out of
+ * the feature matrix with x_batch_stride = hop * feature_size -- no window copies (T > 32, feature_size a multiple of 16). */
+int savad_forward_strided(savad_handle h, const void* x, int x_dtype, int B, int T, long x_batch_stride, float* out,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* Tuning knob: number of key-range splits of the attention stage (0 = automatic). */
 int savad_set_attention_splits(savad_handle h, int splits);

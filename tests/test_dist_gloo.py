@@ -121,6 +121,60 @@ def test_two_rank_streaming_shard_and_merge(tmp_path, n_frames):
     assert covered[0][0] == 0 and covered[-1][1] == W and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
 
 
+def _audio_worker(rank, world, rendezvous, n_samples, out_dir):
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
+    from oracle import logmel, torch_port
+    from voice_activity_detection_amd import StreamingPredictor
+    from voice_activity_detection_amd.distributed import all_gather_rows
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    T, hop = 24, 12
+    state = {k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()}
+    audio = (np.random.default_rng(4).standard_normal(n_samples) * 0.1).astype(np.float32)
+    W, lo, hi, f0, f1, first, count = StreamingPredictor.audio_shard_plan(n_samples, T, hop, dist.get_rank(), world)
+    # CPU stand-ins with the contracts of log_mel_span (frames [f0, f1) of the recording's log-mel: the device kernel computes them
+    # from the slice alone, GPU test) and of _windows_logp (forwards on LOCAL frame indices)
+    if hi > lo:
+        feat = logmel.log_mel(audio)[f0:f1]
+        assert first <= max(0, 160 * f0 - 208) and first + count >= min(n_samples, 160 * (f1 - 1) + 208)
+        win = np.zeros((hi - lo, T, 80), np.float32)
+        for w in range(lo, hi):
+            seg = feat[hop * (w - lo): hop * (w - lo) + T]
+            win[w - lo, : len(seg)] = seg
+        local = torch_port.forward(state, torch.from_numpy(win))
+    else:
+        local = torch.zeros((0, T, 2))
+    logp = all_gather_rows(local, W)
+    np.save(os.path.join(out_dir, f"alogp{rank}.npy"), logp.numpy())
+    np.save(os.path.join(out_dir, f"aplan{rank}.npy"), np.array([W, lo, hi, f0, f1, first, count]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_samples", [160 * (24 + 12 * 6), 160 * (24 + 12 * 5) + 1234, 160 * 30])
+def test_two_rank_audio_level_sharding(tmp_path, n_samples):
+    """configs[4] sharded from the AUDIO (StreamingPredictor.predict_audio_device): each of two gloo ranks takes the plan of
+    audio_shard_plan -- its windows, their frames, the samples those frames read -- computes features for ITS frames only, forwards
+    its windows on local frame indices, and one all_gather gives both ranks what the unsharded oracle computes.  (The device halves
+    of the contract -- savad_logmel_span == rows of the whole log-mel, windows in place == window copies -- are GPU tests.)"""
+    from oracle import logmel, oracle
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    world, T, hop = 2, 24, 12
+    mp.spawn(_audio_worker, args=(world, str(tmp_path / "rendezvous"), n_samples, str(tmp_path)), nprocs=world, join=True)
+    audio = (np.random.default_rng(4).standard_normal(n_samples) * 0.1).astype(np.float32)
+    feat = logmel.log_mel(audio)
+    _, ref_logp = oracle.predict_streaming(seeded_state_dict(1234), feat, T=T, hop=hop)
+    plans = [np.load(tmp_path / f"aplan{r}.npy") for r in range(world)]
+    assert plans[0][1] == 0 and plans[0][2] == plans[1][1] and plans[1][2] == plans[0][0] == ref_logp.shape[0]
+    for r in range(world):
+        logp = np.load(tmp_path / f"alogp{r}.npy")
+        assert logp.shape == ref_logp.shape and np.abs(logp - ref_logp).max() < 2e-5
+        W, lo, hi, f0, f1, first, count = plans[r]
+        if hi > lo and world > 1 and len(feat) > 2 * T:
+            assert count < n_samples   # a rank's share of the samples, not the recording
+
+
 # ---- the multi-batch form: ShardedPipeline / forward_sharded_many ------------------------------------------------------------
 def _pipeline_worker(rank, world, rendezvous, batch, gather, depth, out_dir):
     torch.set_num_threads(1)

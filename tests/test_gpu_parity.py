@@ -1007,6 +1007,59 @@ def test_logmel_one_hour_matches_oracle_on_stretches(torch_cuda):
         assert d.max() < 5e-4 and np.median(d) < 2e-6, (f0, d.max(), np.median(d))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_streaming_windows_in_place_and_audio_sharding(torch_cuda, model, precision):
+    """configs[4], round 5: (a) the streaming windows are read IN PLACE out of the feature matrix (savad_forward_strided: sequences
+    hop * F elements apart) -- the same bits as the window copies of savad_gather_strided + savad_forward; (b) the audio-level entry
+    point: every rank's share (windows [lo, hi) -> frames -> the samples savad_logmel_span_samples names -> log-mel of those frames
+    only -> forwards in place), evaluated here for both ranks of a world of 2 and all ranks of a world of 8 on one GPU, gives the bits of
+    the same windows forwarded as copies; predict_audio_device == predict_device(log_mel(audio)).  Recordings that end on a window
+    boundary and ones that need the zero-padded last window."""
+    import ctypes
+
+    from voice_activity_detection_amd import StreamingPredictor, _lib
+    from voice_activity_detection_amd.features import log_mel
+
+    torch = torch_cuda
+    lib = _lib.load()
+    model.precision = precision
+    try:
+        for n in (160 * (800 + 400 * 5), 160 * (800 + 400 * 5) + 160 * 173 + 55, 160 * 500 + 7):
+            audio = _chirp(n, n % 97)
+            feat = log_mel(torch.from_numpy(audio).cuda())
+            N, F = feat.shape
+            sp = StreamingPredictor(model, "cuda", 800, 400, max_batch=3, in_flight=2)
+            W = lib.savad_stream_window_count(N, 800, 400)
+            # (a) in place against the copies
+            win = torch.empty((W, 800, F), dtype=torch.float32, device="cuda")
+            _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), N, F, 800, 400, 0, W, ctypes.c_void_p(win.data_ptr()),
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            with torch.no_grad():
+                want = model(features=win)
+            full = (N - 800) // 400 + 1 if N >= 800 else 0
+            if full:
+                got = model.forward_windows(feat, 800, 400, 0, full)
+                assert torch.equal(got, want[:full])
+            whole = sp.predict_device(feat)
+            # (b) the audio-level shares
+            for world in (2, 8):
+                parts = [sp.audio_span_logp(audio, r, world) for r in range(world)]
+                plans = [sp.audio_shard_plan(n, 800, 400, r, world) for r in range(world)]
+                for r, (part, plan) in enumerate(zip(parts, plans)):   # bit for bit: the same windows as copies, in the same batches of max_batch
+                    lo, hi = plan[1], plan[2]
+                    with torch.no_grad():
+                        ref = [model(features=win[b:min(b + 3, hi)]) for b in range(lo, hi, 3)]
+                    assert part.shape[0] == hi - lo and (hi == lo or torch.equal(part, torch.cat(ref))), (n, world, r)
+                # against ONE batch of all windows: equal up to the batch-size dependent launch shapes (key splits: fp32 summation order)
+                assert float((torch.cat(parts) - want).abs().max()) < (1e-5 if precision == "fp32" else 1e-2), (n, world)
+                assert plans[0][1] == 0 and plans[-1][2] == W and all(a[2] == b[1] for a, b in zip(plans, plans[1:]))
+                assert all(p[6] <= 160 * (p[4] - p[3]) + 512 + 3 for p in plans)   # a rank's samples: its frames + the halo, not the recording
+            assert torch.equal(sp.predict_audio_device(audio), whole)
+            assert torch.equal(sp.predict_audio_device(torch.from_numpy(audio).cuda()), whole)
+    finally:
+        model.precision = "fp32"
+
+
 def test_wav_to_probabilities_plumbing(torch_cuda, model, state1234, tmp_path):
     """configs[0]-style plumbing on the GPU: WAV -> log-mel -> windows -> model -> boosted probabilities."""
     import wave

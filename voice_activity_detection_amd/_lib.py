@@ -34,6 +34,7 @@ SYMBOLS = {
     "savad_set_precision": (c_int, [c_void_p, c_int]),
     "savad_residual_saturations": (c_int, [c_void_p, POINTER(ctypes.c_ulonglong), c_void_p]),
     "savad_forward_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "savad_forward_strided": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "savad_set_attention_splits": (c_int, [c_void_p, c_int]),
     "savad_set_row_mode": (c_int, [c_void_p, c_int]),
     "savad_set_profiling": (c_int, [c_void_p, c_int]),

@@ -76,6 +76,7 @@ struct savad_model {
     bool frag_dirty = true;
     bool lds_attrs_set = false;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the bf16 kernels
     int n_cu = 256;              // compute units of the handle's device (launch-shape decisions)
+    long xbs_override = 0;       // savad_forward_strided: elements between consecutive sequences of x (0: T * F)
     size_t f_win = 0;
     struct LayerFrag {
         size_t wqkv, wo, w1, w2;
@@ -865,6 +866,7 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
         x_is_bf16 = 0;
         F = m->FP;
     }
+    const long xbs = m->xbs_override > 0 ? m->xbs_override : (long)T * F;  // (strided input and padding exclude each other: savad_forward_strided)
     const float c = (float)(1.4426950408889634 / sqrt((double)D));
     const float* R = m->d_raw;
     const float* P = m->d_packed;
@@ -921,11 +923,11 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
         const int grid_rows = bp.nblk_pad / NW;
         const dim3 wg(64 * NW);
         if (x_is_bf16)
-            hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<__bf16, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const __bf16*)x,
+            hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<__bf16, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const __bf16*)x, xbs,
                                B, T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb,
                                qf, kf, vtf, c, m->d_sat);
         else
-            hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<float, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const float*)x, B,
+            hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<float, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const float*)x, xbs, B,
                                T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf,
                                kf, vtf, c, m->d_sat);
         prof.mark("input_qkv_bf16");
@@ -1036,6 +1038,21 @@ SAVAD_EXPORT int savad_forward_ex(savad_handle m, const void* x, int x_dtype, in
     return forward_bf16(m, x, x_dtype, B, T, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+SAVAD_EXPORT int savad_forward_strided(savad_handle m, const void* x, int x_dtype, int B, int T, long x_batch_stride, float* out,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m) return fail(SAVAD_E_INVALID, "null handle");
+    if (m->generic) return fail(SAVAD_E_UNSUPPORTED, "strided input needs the d_model=128 kernels");
+    if (T <= 32) return fail(SAVAD_E_UNSUPPORTED, "strided input is for sequences longer than 32 frames (windows of T <= 32 are read in place by savad_predict_probabilities)");
+    if (m->FP != m->cfg.feature_size) return fail(SAVAD_E_UNSUPPORTED, "strided input needs feature_size %% 16 == 0 (no padding copy)");
+    const long F = m->cfg.feature_size;
+    if (x_batch_stride <= 0 || x_batch_stride % 4 || x_batch_stride % F)
+        return fail(SAVAD_E_INVALID, "x_batch_stride=%ld (a positive multiple of feature_size and of 4 elements)", x_batch_stride);
+    m->xbs_override = x_batch_stride;
+    const int rc = savad_forward_ex(m, x, x_dtype, B, T, out, workspace, workspace_bytes, stream);
+    m->xbs_override = 0;
+    return rc;
+}
+
 SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, float* out, void* workspace,
                                size_t workspace_bytes, void* stream) {
     if (!m) return fail(SAVAD_E_INVALID, "null handle");
@@ -1066,6 +1083,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
         x = xp;
         F = m->FP;
     }
+    const long xbs = m->xbs_override > 0 ? m->xbs_override : (long)T * F;
     const int tiles = (int)(ws.rows_pad / TILE);
     const float c = (float)(1.4426950408889634 / sqrt((double)D));  // log2(e) / sqrt(d_head)
     const float* R = m->d_raw;
@@ -1098,10 +1116,10 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
         return SAVAD_OK;
     }
     if (msplit)
-        hipLaunchKernelGGL(input_qkv_kernel_m, dim3(tiles_m), dim3(256), 0, st, x, (int)ws.rows, T, F, win_fp32(m),
+        hipLaunchKernelGGL(input_qkv_kernel_m, dim3(tiles_m), dim3(256), 0, st, x, xbs, (int)ws.rows, T, F, win_fp32(m),
                            R + m->r_bin, m->d_pe, P + m->lp[0].wqkv, P + m->lp[0].bqkv, hb, q, k, v);
     else
-        hipLaunchKernelGGL(input_qkv_kernel, dim3(tiles), dim3(256), 0, st, x, (int)ws.rows, T, F, win_fp32(m),
+        hipLaunchKernelGGL(input_qkv_kernel, dim3(tiles), dim3(256), 0, st, x, xbs, (int)ws.rows, T, F, win_fp32(m),
                            R + m->r_bin, m->d_pe, P + m->lp[0].frag, P + m->lp[0].bqkv, hb, q, k, v);
     prof.mark("input_qkv");
     if (ws.fused) {

@@ -81,6 +81,12 @@ __device__ __forceinline__ void add_bias(f32x16& acc, const float* __restrict__ 
     }
 }
 
+// element offset of flat row r = b T + t of the features: sequences xbs elements apart (xbs = T F: the contiguous [B,T,F]
+// tensor; smaller: overlapping windows read in place out of a feature matrix -- the streaming mode, savad_forward_strided)
+__device__ __forceinline__ size_t x_row_offset(size_t r, int T, int F, long xbs) {
+    return xbs == (long)T * F ? r * (size_t)F : (r / (size_t)T) * (size_t)xbs + (r % (size_t)T) * (size_t)F;
+}
+
 // row-layout 32-feature block <-> memory row (global or LDS): 4 x 16-byte pieces at 8g + 4h
 __device__ __forceinline__ void store_block(float* rowp /* &X[row][n0] */, const f32x16& v, int h) {
 #pragma unroll
@@ -622,7 +628,7 @@ __device__ __forceinline__ void combine_splits(f32x4 (&xg)[16], const float* __r
 // One workgroup (4 waves) per 32 data rows; wave w owns output features [32w, 32w+32).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void input_qkv_kernel(
-    const float* __restrict__ x, int rows, int T, int F, const float* __restrict__ Win, const float* __restrict__ bin,
+    const float* __restrict__ x, long xbs, int rows, int T, int F, const float* __restrict__ Win, const float* __restrict__ bin,
     const float* __restrict__ pe /* [T][D], already / sqrt(D) */, const float* __restrict__ frag0 /* layer 0, fragment order */,
     const float* __restrict__ bqkv, float* __restrict__ hbuf, float* __restrict__ q, float* __restrict__ k,
     float* __restrict__ v) {
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(256, 1) void input_qkv_kernel(
     const int voff = lane * 16;
     const size_t row = (size_t)blockIdx.x * TILE + m;
     const bool valid = row < (size_t)rows;
-    const float* xp = x + (valid ? row : 0) * (size_t)F + 4 * h;
+    const float* xp = x + x_row_offset(valid ? row : 0, T, F, xbs) + 4 * h;
     const float* wp = Win + (size_t)(32 * w + n) * F + 4 * h;
     WBlock wa, wb;
     stage_bias(lbn, bqkv, 3 * D);
@@ -1173,7 +1179,7 @@ __device__ __forceinline__ void qkv_tail_m(const f32x4 (&xg)[16], const float* _
 }
 
 __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
-    const float* __restrict__ x, int rows, int T, int F, const float* __restrict__ Win, const float* __restrict__ bin,
+    const float* __restrict__ x, long xbs, int rows, int T, int F, const float* __restrict__ Win, const float* __restrict__ bin,
     const float* __restrict__ pe, const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
     float* __restrict__ hbuf, float* __restrict__ q, float* __restrict__ k, float* __restrict__ v) {
     __shared__ __attribute__((aligned(16))) float lds[2 * WBLK + 3 * D];
@@ -1187,7 +1193,7 @@ __global__ __launch_bounds__(256, 2) void input_qkv_kernel_m(
     const DmaLanes LA = dma_lanes_rows32(D, true, w, lane);
     dma_block(Wqkv, LA, ring, w);  // first QKV block flies while the input projection runs
     stage_bias(bq, bqkv, 3 * D);
-    const float* xp = x + (valid ? row : 0) * (size_t)F + 4 * h;
+    const float* xp = x + x_row_offset(valid ? row : 0, T, F, xbs) + 4 * h;
     const float* wp = Win + (size_t)n * F + 4 * h;
     const int t = (int)((valid ? row : 0) % (size_t)T);
     f32x16 h0[4];

@@ -316,7 +316,7 @@ __device__ __forceinline__ bf16x8 load_x_frag(const __bf16* p, bool valid) {
 // ---------------------------------------------------------------------------------------------
 template <typename XT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf16(
-    const XT* __restrict__ x, int B, int T, int F, int nblk, const char* __restrict__ win_frag,
+    const XT* __restrict__ x, long xbs, int B, int T, int F, int nblk, const char* __restrict__ win_frag,
     const float* __restrict__ bin, const float* __restrict__ pe, const char* __restrict__ wqkv_frag,
     const float* __restrict__ bqkv, hres_t* __restrict__ hbuf, char* __restrict__ qf, char* __restrict__ kf,
     char* __restrict__ vtf, float qscale, unsigned* __restrict__ satcnt) {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf1
         add_block(h0[nb], pe + (size_t)t_frame * D + 32 * nb, h);
     }
     const int KS = F / 16;
-    const XT* xr = x + row * (size_t)F;
+    const XT* xr = x + x_row_offset(row, T, F, xbs);
     for (int ks = 0; ks < KS; ++ks) {
         const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
         const bf16x8 xf = load_x_frag(xr + f0, valid);

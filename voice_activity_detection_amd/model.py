@@ -308,6 +308,33 @@ class SelfAttentiveVAD(nn.Module):
                                         ws.numel(), ctypes.c_void_p(stream)))
 
     @torch.no_grad()
+    def forward_windows(self, feature: Tensor, T: int, hop: int, first: int, count: int, out: Optional[Tensor] = None) -> Tensor:
+        """Log-probs [count, T, 2] of the sliding windows first .. first + count - 1 of a device feature matrix [N, F] -- window w
+        = frames [hop w, hop w + T) -- read IN PLACE (savad_forward_strided: sequences hop * F elements apart), no window copies.
+        Every window must lie inside the matrix (hop (first + count - 1) + T <= N); the streaming mode's zero-padded last window
+        goes through a copy (StreamingPredictor)."""
+        device = feature.device
+        if device.type != "cuda":
+            self._prepare_call(device)  # raises: no CPU fallback
+        if feature.dim() != 2 or feature.shape[1] != self.feature_size or feature.dtype != torch.float32 or not feature.is_contiguous():
+            raise ValueError(f"feature must be a contiguous float32 [N, {self.feature_size}] tensor, got {tuple(feature.shape)} {feature.dtype}")
+        N, F = feature.shape
+        if count < 1 or first < 0 or hop < 1 or T < 1 or hop * (first + count - 1) + T > N:
+            raise ValueError(f"windows [{first}, {first + count}) of {T} frames every {hop} do not lie inside {N} frames")
+        if out is None:
+            out = torch.empty((count, T, 2), dtype=torch.float32, device=device)
+        elif tuple(out.shape) != (count, T, 2) or out.dtype != torch.float32 or out.device != device or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous float32 [{count}, {T}, 2] tensor on {device}")
+        with torch.cuda.device(device):
+            lib = self._prepare_call(device)
+            ws = self._workspace_for(self._workspace_bytes(lib, count, T), device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            x = feature.data_ptr() + 4 * first * hop * F
+            _lib.check(lib.savad_forward_strided(self._handle, ctypes.c_void_p(x), 0, count, T, hop * F, ctypes.c_void_p(out.data_ptr()),
+                                                 ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(stream)))
+        return out
+
+    @torch.no_grad()
     def predict_windows(self, feature: Tensor, half: int, jump: int, chunk: int):
         """The whole of VADFromScratchPredictor.predict_probabilities (vad/predictor.py:159-262) in ONE library call
         (savad_predict_probabilities): feature [N, F] fp32 on the device -> (probs [N, W], mean [N]); the windows are

@@ -53,7 +53,10 @@ class PipelinedVAD:
         self.active, self._next = int(n), 0
 
     def _ensure_streams(self, device: torch.device) -> List[torch.cuda.Stream]:
+        if device.type == "cuda" and device.index is None:   # "cuda" -> the indexed device the streams report
+            device = torch.device("cuda", torch.cuda.current_device())
         if self._streams is None or self._streams[0].device != device:
+            self.join()   # forwards still in flight belong to the streams about to be replaced
             self._streams = [torch.cuda.Stream(device) for _ in range(self.depth)]
         return self._streams
 
@@ -82,6 +85,29 @@ class PipelinedVAD:
         self._busy[k] = True
         return y
 
+    @torch.no_grad()
+    def submit_windows(self, feature: Tensor, T: int, hop: int, first: int, count: int, out: Optional[Tensor] = None) -> Tensor:
+        """``submit`` for ``model.forward_windows``: windows read in place out of a feature matrix"""
+        device = feature.device
+        if device.type != "cuda" or self.active == 1:
+            if device.type == "cuda":
+                self.join()
+            self.last_replica = 0
+            return self.model.forward_windows(feature, T, hop, first, count, out=out)
+        streams = self._ensure_streams(device)
+        k = self._next
+        self._next = (k + 1) % self.active
+        self.last_replica = k
+        rep, s = self._replicas[k], streams[k]
+        self._follow(rep)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            y = rep.forward_windows(feature, T, hop, first, count, out=out)
+        feature.record_stream(s)
+        y.record_stream(s)
+        self._busy[k] = True
+        return y
+
     def _follow(self, rep: SelfAttentiveVAD) -> None:
         """knobs set on the base module after construction apply to every replica, and so does a declared weight change
         (model.sync_weights(force=True), a .train() / .eval() switch, .to()): the replica re-pushes at its next forward"""
@@ -91,6 +117,8 @@ class PipelinedVAD:
         for name in _KNOBS:
             if getattr(rep, name) != getattr(base, name):
                 setattr(rep, name, getattr(base, name))
+        if rep._weights_generation != base._weights_generation:
+            rep._pdev = None   # (the base may have moved: the replica re-reads its parameters' device at its next forward)
         rep._weights_generation = base._weights_generation
 
     def wait_for_replica(self, k: int) -> None:

@@ -292,19 +292,100 @@ class StreamingPredictor:
                 self._pipe = PipelinedVAD(self.model, depth=max(self.in_flight, 1))
 
             def windows_logp(lo, hi):  # this rank's contiguous span of windows -> [hi - lo, T, 2] log-probs
-                local = torch.empty((hi - lo, T, 2), dtype=torch.float32, device=self.device)
-                for first in range(lo, hi, self.max_batch):
-                    count = min(self.max_batch, hi - first)
-                    win = torch.empty((count, T, F), dtype=torch.float32, device=self.device)
-                    _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), N, F, T, hop, first, count,
-                                                        ctypes.c_void_p(win.data_ptr()), stream))
-                    self._pipe.submit(win, out=local[first - lo:first - lo + count])
-                self._pipe.join()
-                return local
+                return self._windows_logp(feat, 0, N, lo, hi, stream)
 
             logp = sharded_rows(W, windows_logp, (T, 2), torch.float32, self.device).contiguous()
             probs = torch.empty((N,), dtype=torch.float32, device=self.device)
             _lib.check(lib.savad_overlap_merge(ctypes.c_void_p(logp.data_ptr()), W, N, T, hop,
+                                               ctypes.c_void_p(probs.data_ptr()), stream))
+        return probs
+
+    def _windows_logp(self, feat, frame0, n_total, lo, hi, stream):
+        """log-probs [hi - lo, T, 2] of windows [lo, hi) of an n_total-frame recording, from `feat` = its frames [frame0,
+        frame0 + len(feat)): windows that lie inside the recording are read IN PLACE (model.forward_windows, sequences hop * F
+        elements apart: no copies); the last window of a recording that does not end on a window boundary is zero-padded
+        through savad_gather_strided (one window's copy)."""
+        lib = _lib.load()
+        T, hop, F = self.T, self.hop, feat.shape[1]
+        n_local = feat.shape[0]
+        local = torch.empty((hi - lo, T, 2), dtype=torch.float32, device=self.device)
+        full_end = min(hi, (n_total - T) // hop + 1 if n_total >= T else 0)   # windows [lo, full_end) end inside the recording
+        for first in range(lo, full_end, self.max_batch):
+            count = min(self.max_batch, full_end - first)
+            self._pipe.submit_windows(feat, T, hop, first - frame0 // hop, count, out=local[first - lo:first - lo + count])
+        for w in range(max(lo, full_end), hi):   # at most one: the padded tail
+            win = torch.empty((1, T, F), dtype=torch.float32, device=self.device)
+            _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), n_local, F, T, hop, w - frame0 // hop, 1,
+                                                ctypes.c_void_p(win.data_ptr()), stream))
+            self._pipe.submit(win, out=local[w - lo:w - lo + 1])
+        self._pipe.join()
+        return local
+
+    @staticmethod
+    def audio_shard_plan(n_samples: int, T: int, hop: int, rank: int, world: int):
+        """What rank `rank` of `world` needs of an n_samples-long recording: (W, lo, hi, f0, f1, first, count) -- its windows [lo, hi)
+        of the W in all (contiguous split, voice_activity_detection_amd.distributed.shard_bounds), the feature frames [f0, f1)
+        they cover, and the samples [first, first + count) those frames read (savad_logmel_span_samples: 208 samples of halo
+        per side, the mirrored stretch at an end of the recording; first % 4 == 0).  Host-side arithmetic only."""
+        from .distributed import shard_bounds
+        from .features import span_samples
+
+        lib = _lib.load()
+        N = 1 + n_samples // 160
+        W = lib.savad_stream_window_count(N, T, hop)
+        if W < 0:
+            _lib.check(W)
+        lo, hi = shard_bounds(W, rank, world)
+        if hi <= lo:
+            return W, lo, hi, 0, 0, 0, 0
+        f0, f1 = hop * lo, min(N, hop * (hi - 1) + T)
+        first, count = span_samples(n_samples, f0, f1 - f0)
+        return W, lo, hi, f0, f1, first, count
+
+    @torch.no_grad()
+    def audio_span_logp(self, audio, rank: int, world: int):
+        """rank-local half of predict_audio_device: log-probs [hi - lo, T, 2] of this rank's windows, from the audio -- only its
+        slice of the samples is uploaded (when `audio` is a host array), only its frames' log-mel is computed"""
+        from .features import log_mel_span
+
+        n = int(audio.shape[0])
+        W, lo, hi, f0, f1, first, count = self.audio_shard_plan(n, self.T, self.hop, rank, world)
+        if hi <= lo:
+            return torch.zeros((0, self.T, 2), dtype=torch.float32, device=self.device)
+        self.model.eval()
+        with torch.cuda.device(self.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            if self._pipe is None or self._pipe.model is not self.model or self._pipe.depth != max(self.in_flight, 1):
+                from .pipeline import PipelinedVAD
+                self._pipe = PipelinedVAD(self.model, depth=max(self.in_flight, 1))
+            sl = audio[first:first + count]
+            if not isinstance(sl, torch.Tensor):
+                sl = torch.from_numpy(np.ascontiguousarray(sl, dtype=np.float32))
+            sl = sl.to(self.device, torch.float32).contiguous()
+            feat = log_mel_span(sl, first, n, f0, f1 - f0)
+            return self._windows_logp(feat, f0, 1 + n // 160, lo, hi, stream)
+
+    @torch.no_grad()
+    def predict_audio_device(self, audio):
+        """configs[4] from the AUDIO: `audio` = the whole recording, float32 mono 16 kHz, on the HOST (numpy) or the device.  With
+        torch.distributed initialised every rank computes the log-mel features of ITS window span only (audio_shard_plan), runs
+        its windows in place on them, and ONE all_gather of the log-probs + the overlap merge give every rank the per-frame
+        probabilities.  Same bits as predict_device(log_mel(audio)) on one GPU (tests/test_gpu_parity.py)."""
+        import torch.distributed as dist
+
+        from .distributed import all_gather_rows
+
+        lib = _lib.load()
+        n = int(audio.shape[0])
+        N = 1 + n // 160
+        world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+        local = self.audio_span_logp(audio, rank, world)
+        W = lib.savad_stream_window_count(N, self.T, self.hop)
+        with torch.cuda.device(self.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            logp = (all_gather_rows(local, W) if world > 1 else local).contiguous()
+            probs = torch.empty((N,), dtype=torch.float32, device=self.device)
+            _lib.check(lib.savad_overlap_merge(ctypes.c_void_p(logp.data_ptr()), W, N, self.T, self.hop,
                                                ctypes.c_void_p(probs.data_ptr()), stream))
         return probs
 
