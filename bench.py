@@ -104,11 +104,13 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     bench line) or bf16 [256,800] -- and (b) the profile was taken on exactly the kernel sources that are
     running now (`csrc_hash` stored in the file); otherwise null."""
     if (precision, B, T) == ("fp32", 32, 800):
-        files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if "bf16" not in f.name and "t7" not in f.name]
+        files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if not any(t in f.name for t in ("bf16", "t7", "t50", "logmel"))]
     elif (precision, B, T) == ("bf16", 256, 800):
         files = sorted((REPO / "profiles").glob("*bf16_b256_traffic.json"))
     elif (precision, B, T) == ("fp32", 1000, 7):
         files = sorted((REPO / "profiles").glob("*t7_traffic.json"))
+    elif (precision, B, T) == ("bf16", 1000, 7):
+        files = sorted((REPO / "profiles").glob("*t7_bf16_traffic.json"))
     else:
         return None
     want = kernel_source_hash()
@@ -120,7 +122,8 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     stem = name.replace("_last", "")
     prefix = {"attention": "attention_kernel", "attention_row": "attention_row_kernel", "row": "row_kernel", "input_qkv": "input_qkv_kernel",
               "attention_bf16": "attention", "row_bf16": "row_kernel_bf16", "input_qkv_bf16": "input_qkv_kernel_bf16",
-              "attention_row_bf16": "attention_row_kernel_bf16", "packed_forward": "packed_forward_kernel"}.get(stem)
+              "attention_row_bf16": "attention_row_kernel_bf16", "packed_forward": "packed_forward_kernel",
+              "packed_forward_bf16": "packed_forward_kernel_bf16"}.get(stem)
     if prefix is None:
         return None
     for key, entry in data.items():
@@ -136,7 +139,7 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
 
 def traffic_note(name, precision, B, T):
     """what the measured HBM-side bytes of the dominant kernel are made of, where they are far from the algorithmic ones"""
-    if name == "packed_forward":
+    if name in ("packed_forward", "packed_forward_bf16"):
         return ("the whole forward in one launch reads x and writes the log-probs (algorithmic) -- and every one of the 8 XCD L2s fetches the "
                 "2.4 MB of packed weights once: 8 x 2.4 MB + x is the measured figure, 0.3 % of the HBM roof at this launch's duration; benign")
     if name == "attention_bf16" and (B, T) == (256, 800):
@@ -177,11 +180,13 @@ def rocprof_averages(precision, B, T):
     """{kernel short name: average ns} of the committed rocprofv3 --kernel-trace --stats run of this workload
     (profiles/*_kernel_avg.json, written by scripts/summarize_profile.py), only when taken on the running kernel sources."""
     if (precision, B, T) == ("fp32", 32, 800):
-        files = [f for f in sorted((REPO / "profiles").glob("*_kernel_avg.json")) if not any(t in f.name for t in ("bf16", "_t7_", "_t50_"))]
+        files = [f for f in sorted((REPO / "profiles").glob("*_kernel_avg.json")) if not any(t in f.name for t in ("bf16", "_t7_", "_t50_", "logmel"))]
     elif (precision, B, T) == ("bf16", 256, 800):
         files = sorted((REPO / "profiles").glob("*bf16_kernel_avg.json"))
     elif (precision, B, T) == ("fp32", 1000, 7):
         files = sorted((REPO / "profiles").glob("*t7_kernel_avg.json"))
+    elif (precision, B, T) == ("bf16", 1000, 7):
+        files = sorted((REPO / "profiles").glob("*t7_bf16_kernel_avg.json"))
     else:
         return {}, None
     want = kernel_source_hash()
@@ -200,6 +205,7 @@ ROCPROF_NAMES = {  # bench launch label -> kernel short name in the rocprofv3 st
     "input_qkv": "input_qkv_kernel_m", "packed_forward": "packed_forward_kernel",
     "attention_bf16": ("attention_pw_kernel_bf16", "attention_kernel_bf16<4>"), "row_bf16": "row_kernel_bf16<false, 4>", "row_last_bf16": "row_kernel_bf16<true, 4>",
     "input_qkv_bf16": "input_qkv_kernel_bf16<__bf16, 4>",
+    "packed_forward_bf16": ("packed_forward_kernel_bf16<4, 4, 4>", "packed_forward_kernel_bf16<4, 2, 0>"),
 }
 
 

@@ -6,7 +6,7 @@
 set -u
 BUDGET=${1:-600}
 T0=$(date +%s)
-OUT=$PWD/gpurun_out/r4final; mkdir -p $OUT
+OUT=$PWD/gpurun_out/r5final; mkdir -p $OUT
 if [ "${SKIP_TESTS:-0}" != 1 ]; then
     ( timeout 300 python -m pytest tests -m gpu -q 2>&1 | tail -12 ) | tee $OUT/pytest.log
     # (the summary is not always the last line: RCCL's banner can follow it on stderr)
@@ -14,11 +14,14 @@ if [ "${SKIP_TESTS:-0}" != 1 ]; then
         echo "GPU tests did not pass: nothing else is run"; timeout 200 python -m pytest tests -m gpu -q -x 2>&1 | tail -60 > $OUT/pytest_fail.log; exit 1
     fi
 fi
-timeout 100 bash scripts/profile_gpu.sh r4_bf16 --precision bf16 --batch 256 --no-secondary > $OUT/prof_r4_bf16.log 2>&1; grep "rc=" $OUT/prof_r4_bf16.log | tr '\n' ' '
-timeout 100 bash scripts/profile_gpu.sh r4 > $OUT/prof_r4.log 2>&1; grep "rc=" $OUT/prof_r4.log | tr '\n' ' '
-timeout 100 bash scripts/profile_gpu.sh r4_t7 --batch 1000 --frames 7 --no-secondary > $OUT/prof_r4_t7.log 2>&1; grep "rc=" $OUT/prof_r4_t7.log | tr '\n' ' '
-timeout 100 bash scripts/profile_gpu.sh r4_t50 --batch 512 --frames 50 --no-secondary > $OUT/prof_r4_t50.log 2>&1; grep "rc=" $OUT/prof_r4_t50.log | tr '\n' ' '
-for t in "r4_bf16 r4_bf16_b256" r4 r4_t7 r4_t50; do bash scripts/collect_profiles.sh $t > /dev/null 2>&1 || echo "collect $t failed"; done
+timeout 150 bash scripts/profile_gpu.sh r5_bf16 --precision bf16 --batch 256 --no-secondary > $OUT/prof_r5_bf16.log 2>&1; grep "rc=" $OUT/prof_r5_bf16.log | tr '\n' ' '
+timeout 150 bash scripts/profile_gpu.sh r5 > $OUT/prof_r5.log 2>&1; grep "rc=" $OUT/prof_r5.log | tr '\n' ' '
+timeout 150 bash scripts/profile_gpu.sh r5_t7 --batch 1000 --frames 7 --no-secondary > $OUT/prof_r5_t7.log 2>&1; grep "rc=" $OUT/prof_r5_t7.log | tr '\n' ' '
+timeout 150 bash scripts/profile_gpu.sh r5_t7_bf16 --precision bf16 --batch 1000 --frames 7 --no-secondary > $OUT/prof_r5_t7_bf16.log 2>&1; grep "rc=" $OUT/prof_r5_t7_bf16.log | tr '\n' ' '
+timeout 150 bash scripts/profile_gpu.sh r5_t7_bf16_big --precision bf16 --batch 65536 --frames 7 --no-secondary --steps 4 > $OUT/prof_r5_t7_bf16_big.log 2>&1; grep "rc=" $OUT/prof_r5_t7_bf16_big.log | tr '\n' ' '
+timeout 150 bash scripts/profile_logmel.sh r5_logmel > $OUT/prof_r5_logmel.log 2>&1; grep "rc=" $OUT/prof_r5_logmel.log | tr '\n' ' '
+for t in "r5_bf16 r5_bf16_b256" r5 r5_t7 r5_t7_bf16 r5_t7_bf16_big r5_logmel; do bash scripts/collect_profiles.sh $t > /dev/null 2>&1 || echo "collect $t failed"; done
+timeout 200 bash scripts/profile_overlap.sh r5 > $OUT/overlap.log 2>&1; cp gpurun_out/overlap_r5.txt profiles/r5_inflight_overlap.txt 2>/dev/null
 ( timeout 200 python bench.py 2>$OUT/bench.err | grep "^{" ) > $OUT/bench.json; wc -c $OUT/bench.json
 ( SAVAD_BENCH_FORCE_DIST=1 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | grep "^{" ) > $OUT/bench_dist1.json; wc -c $OUT/bench_dist1.json
 find gpurun_out -name "*.csv" -size +1M -delete

@@ -105,6 +105,23 @@ def test_roc_auc_matches_definition():
     assert abs(roc_auc(y, s) - roc_auc_score(y, s)) < 1e-12
 
 
+def test_weight_changes_the_fast_walk_must_see():
+    """the per-forward change detection walks cached `_parameters` dicts (model.py: _param_versions): a replaced SUBMODULE and a
+    `p.data = tensor` (same Parameter object, same _version, new storage) must both register"""
+    import torch
+
+    from voice_activity_detection_amd import SelfAttentiveVAD
+
+    m = SelfAttentiveVAD(80, 1, 128, 0.5)
+    v0 = m._param_versions()
+    assert m._param_dicts is not None and m._param_versions() == v0
+    m.classifier.weight.data = torch.zeros_like(m.classifier.weight)
+    v1 = m._param_versions()
+    assert v1 != v0 and v1[0] == v0[0] and v1[1] == v0[1]          # identity and version unchanged: only the storage moved
+    m.classifier = torch.nn.Linear(128, 2)
+    assert m._param_dicts is None and m._param_versions() != v1     # the walk is rebuilt and sees the new module's parameters
+
+
 def test_module_copies_and_pickles_drop_runtime_state(state1234):
     """copy.deepcopy / pickle of the module (the ctypes handle and the cached workspace are per-process runtime state and
     are recreated lazily), and the weight re-push triggers that do not need a GPU to check."""

@@ -264,10 +264,8 @@ __global__ __launch_bounds__(64 * (NW + DW), (NW + DW == 8) ? 1 : 2) void packed
             bf16x8 ap[8];
 #pragma unroll
             for (int nbl = 0; nbl < 4; ++nbl) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a[nbl][r] = fmaxf(a[nbl][r], 0.0f);
-                ap[2 * nbl] = pack_half(a[nbl], 0);
-                ap[2 * nbl + 1] = pack_half(a[nbl], 1);
+                ap[2 * nbl] = relu_frag(pack_half(a[nbl], 0));
+                ap[2 * nbl + 1] = relu_frag(pack_half(a[nbl], 1));
             }
             advance(t0 + 5 + 2 * ch);  // W2 chunk
             gemm_ring(o, ring.slot(t0 + 5 + 2 * ch), ap, lane);

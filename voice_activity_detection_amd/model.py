@@ -184,7 +184,16 @@ class SelfAttentiveVAD(nn.Module):
         if dicts is None:
             dicts = self._param_dicts = [m._parameters for m in self.modules() if m._parameters]
         ps = [p for d in dicts for p in d.values()]
-        return tuple(map(id, ps)), [p._version for p in ps]
+        # data_ptr: `p.data = other_tensor` keeps identity and version but moves the storage (cheap once the dicts are cached: ~5 us)
+        return tuple(map(id, ps)), [p._version for p in ps], [p.data_ptr() for p in ps]
+
+    def __setattr__(self, name, value):
+        # a replaced SUBMODULE (model.classifier = nn.Linear(...)) after the first forward: the cached walk above would keep serving
+        # the old module's parameters
+        if isinstance(value, nn.Module) and "_param_dicts" in self.__dict__:
+            self.__dict__["_param_dicts"] = None
+            self.__dict__["_synced_versions"] = None
+        super().__setattr__(name, value)
 
     def sync_weights(self, force: bool = False):
         """Push the module's parameters into the library's packed weight store when they changed.  Changes are detected

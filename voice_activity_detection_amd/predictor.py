@@ -95,13 +95,17 @@ class VADFromScratchPredictor:
                 continue
         import pickle
 
+        trusted = trust or os.environ.get("SAVAD_TRUST_CHECKPOINT") == "1"
         if not hasattr(torch.serialization, "safe_globals"):
-            raise RuntimeError("this torch build has no torch.serialization.safe_globals: checkpoints cannot be loaded with weights_only=True")
+            if trusted:   # an older torch: the explicit opt-in still loads (what the reference's plain torch.load does)
+                return torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+            raise RuntimeError("this torch build has no torch.serialization.safe_globals: checkpoints cannot be loaded with weights_only=True "
+                               "(pass trust_checkpoint=True / set SAVAD_TRUST_CHECKPOINT=1 if you trust the file)")
         try:
             with torch.serialization.safe_globals(safe):
                 return torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         except pickle.UnpicklingError as exc:  # an unlisted global: only this falls through; I/O and format errors propagate as they are
-            if not (trust or os.environ.get("SAVAD_TRUST_CHECKPOINT") == "1"):
+            if not trusted:
                 raise RuntimeError(
                     f"{checkpoint_path}: not loadable with weights_only=True ({str(exc).splitlines()[0]}). If you trust the "
                     "file, pass trust_checkpoint=True / set SAVAD_TRUST_CHECKPOINT=1 to unpickle it in full "
