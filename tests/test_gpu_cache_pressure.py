@@ -170,9 +170,7 @@ def test_a_deliberately_broken_build_is_caught(torch_cuda, model, tmp_path):
     from voice_activity_detection_amd.seeded import seeded_features
 
     torch = torch_cuda
-    lib = build.FAULT_LIB
-    if not lib.exists():
-        build.build_variant(lib, ["SAVAD_FAULT_INJECT=1"])
+    lib = build.build_variant(build.FAULT_LIB, ["SAVAD_FAULT_INJECT=1"])   # (rebuilt only when missing or older than the sources)
     with torch.no_grad():
         want = model(features=torch.from_numpy(seeded_features(5, (500, 7, 80))).cuda()).cpu().numpy()
     np.save(tmp_path / "want.npy", want)
