@@ -826,8 +826,9 @@ void launch_packed_forward_bf16(savad_model* m, hipStream_t st, const float* x, 
     const float c = (float)(1.4426950408889634 / sqrt((double)D));
     const size_t bias_bytes = (size_t)L * LBIAS * 4;
     // variant: row_mode 5 = 8-wave workgroups, 6 = 4 waves + 4 that move the weight stream through a 4-slot ring, 7 = 4 waves +
-    // 2 slots; automatic: 6 while there are fewer 4-block workgroups than twice the CUs (savad_packed_bf16.h)
-    const int variant = m->row_mode >= 5 ? m->row_mode : ((nblk + 3) / 4 <= 2 * m->n_cu ? 6 : 7);
+    // 2 slots; automatic: 6 while the 4-block workgroups fill at most half of the CUs ([1000,7,80], 63 workgroups: 0.044 against 0.049 ms;
+    // [4000,7,80], 250 workgroups: 0.059 against 0.053; scripts/ubench/packed_bf16_bench.py)
+    const int variant = m->row_mode >= 5 ? m->row_mode : ((nblk + 3) / 4 <= m->n_cu / 2 ? 6 : 7);
     const size_t ring2 = (size_t)2 * bf::RING_BYTES, ring4 = (size_t)4 * bf::RING_BYTES;
     if (variant == 5)
         hipLaunchKernelGGL((bf::packed_forward_kernel_bf16<8, 4, 0>), dim3((nblk + 7) / 8), dim3(512), ring4 + bias_bytes, st, x, B, T, F, nblk, pm, c, out,
