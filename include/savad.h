@@ -134,8 +134,9 @@ int savad_set_attention_splits(savad_handle h, int splits);
  *        both attention kernels (savad.hip, pw_pays) has it ahead: large batches of long sequences ([160+,800], [256,1000] ...)
  *   bf16 operands, T <= 32 (the reference pipeline's 7-frame windows): 0 and 4 run the WHOLE forward in one launch (a wave per
  *        packed block for all layers, csrc/savad_packed_bf16.h; same bits as the per-layer launches of 1 - 3) in the variant
- *        the number of blocks suggests; 5 / 6 / 7 pin a variant (8-wave workgroups / 4 waves with a 4-slot weight ring /
- *        4 waves with a 2-slot ring) */
+ *        the number of blocks suggests; 5 / 6 / 7 / 8 pin a variant (8-wave workgroups / 4 waves + 4 that move the weight stream
+ *        through a 4-slot ring / 4 waves with a 2-slot ring / ONE block per workgroup, its four waves splitting every GEMM's
+ *        output features: the latency variant, picked up to one block per CU) */
 int savad_set_row_mode(savad_handle h, int mode);
 /* Per-kernel timing (bench.py's roofline block).  savad_set_profiling(h, capacity): the next `capacity` calls of
  * savad_forward bracket every launch with hipEvents on `stream` (capacity 0 switches profiling off and frees the

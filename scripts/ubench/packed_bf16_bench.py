@@ -36,13 +36,13 @@ def main():
     res = {}
     shapes = ((1000, 7), (250, 7), (4000, 7), (16384, 7), (65536, 7), (400, 20), (1000, 32))
     if "--quick" in sys.argv:
-        shapes = ((1000, 7), (65536, 7))
+        shapes = ((1000, 7), (2000, 7), (4000, 7), (8000, 7), (65536, 7))
     for B, T in shapes:
         x = torch.randn(B, T, 80, device="cuda")
         out = torch.empty(B, T, 2, device="cuda")
         reps = 50 if B <= 4000 else 5
         row = {}
-        for name, prec, mode in (("fp32", "fp32", 0), ("bf16_auto", "bf16", 0), ("bf16_nw8", "bf16", 5), ("bf16_nw4_ring4", "bf16", 6), ("bf16_nw4_ring2", "bf16", 7), ("bf16_per_layer", "bf16", 1)):
+        for name, prec, mode in (("fp32", "fp32", 0), ("bf16_auto", "bf16", 0), ("bf16_nw8", "bf16", 5), ("bf16_nw4_ring4", "bf16", 6), ("bf16_nw4_ring2", "bf16", 7), ("bf16_nsplit", "bf16", 8), ("bf16_per_layer", "bf16", 1)):
             m.precision = prec
             m.row_mode = mode
             with torch.no_grad():

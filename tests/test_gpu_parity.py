@@ -616,7 +616,7 @@ def test_bf16_single_launch_is_the_per_layer_launches_bit_for_bit(torch_cuda, mo
     y0 = _run_bf16_mode(torch, model, x, 0)
     y1 = _run_bf16_mode(torch, model, x, 1)
     assert np.isfinite(y0).all() and np.array_equal(y0, y1)
-    for variant in (5, 6, 7):  # 8-wave workgroups; 4 waves with a 4-slot / a 2-slot weight ring
+    for variant in (5, 6, 7, 8):  # 8-wave workgroups; 4 waves with a 4-slot / a 2-slot weight ring; one block per workgroup (4 waves split the features)
         assert np.array_equal(y0, _run_bf16_mode(torch, model, x, variant)), variant
     if shape[0] <= 1000:
         assert np.abs(y0 - oracle.forward(state1234, x)).max() < BF16_TOL

@@ -23,11 +23,13 @@ LABELS = {
     "row_kernel_bf16<false, 4>": "row_bf16", "row_kernel_bf16<true, 4>": "row_last_bf16", "input_qkv_kernel_bf16<__bf16, 4>": "input_qkv_bf16",
     "packed_forward_kernel": "packed_forward",
     "packed_forward_kernel_bf16<4, 4, 4>": "packed_forward_bf16", "packed_forward_kernel_bf16<4, 2, 0>": "packed_forward_bf16",
+    "packed_forward_kernel_bf16_ns": "packed_forward_bf16",
     "logmel_fft_kernel": "logmel",
 }
 # explained excesses: kernel -> (bound, why)
 KNOWN = {
     "packed_forward_kernel_bf16<4, 4, 4>": (12.0, "[1000,7,80]: 2.3 MB algorithmic; the 1.2 MB of bf16 weight fragments are fetched once per XCD L2 (and the biases): benign"),
+    "packed_forward_kernel_bf16_ns": (12.0, "as packed_forward_kernel_bf16<4, 4, 4>: [1000,7,80], weights once per XCD L2"),
     "packed_forward_kernel": (12.0, "[1000,7,80]: 2.3 MB algorithmic; each of the 8 XCD L2s fetches the 2.4 MB of packed weights once: 0.3 % of the HBM roof"),
     "attention_pw_kernel_bf16": (1.65, "T = 800: the key-split tail item's workgroup starts its full group 0.55 item-times behind the sequence's other two "
                                        "groups and fetches K / V^T a second time (+105 MB); T = 768, no tail group: 1.00x (DESIGN section 4b-3)"),

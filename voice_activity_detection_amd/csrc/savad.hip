@@ -701,7 +701,7 @@ SAVAD_EXPORT int savad_set_attention_splits(savad_handle m, int splits) {
 }
 
 SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
-    if (!m || mode < 0 || mode > 7) return fail(SAVAD_E_INVALID, "row mode %d", mode);
+    if (!m || mode < 0 || mode > 8) return fail(SAVAD_E_INVALID, "row mode %d", mode);
     m->row_mode = mode;
     return SAVAD_OK;
 }
@@ -794,12 +794,16 @@ int prepare_bf16_launch(savad_model* m) {
     if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 2, 0>, r4 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
     if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 4, 4>, r8 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
     if ((rc = allow_lds(bf::packed_forward_kernel_bf16<8, 4, 0>, r8 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
+    if ((rc = allow_lds(bf::packed_forward_kernel_bf16_ns, bf::ns_lds_bytes(bf::PACKED_BF16_MAX_LAYERS)))) return rc;
     m->lds_attrs_set = true;
     return SAVAD_OK;
 }
 
 // T <= 32 with bf16 operands: the whole forward in one launch (savad_packed_bf16.h); a wave per packed block, NW blocks per
 // workgroup.  Weights, fragments, the PE table and the kernels' LDS attributes must be ready.
+#ifndef SAVAD_NS_MAX_ROUNDS
+#define SAVAD_NS_MAX_ROUNDS 1   // blocks per CU up to which one block per workgroup beats four (scripts/ubench/packed_bf16_bench.py)
+#endif
 bool packed_bf16_applies(const savad_model* m, int T) {
     // row_mode 0 (automatic) and 4: picked by the number of blocks; 5 - 7: a fixed variant (launch_packed_forward_bf16; tuning
     // knobs at T <= 32, where the persistent attention kernel that 5 selects for long sequences does not exist); 1 - 3 keep
@@ -828,9 +832,13 @@ void launch_packed_forward_bf16(savad_model* m, hipStream_t st, const float* x, 
     // variant: row_mode 5 = 8-wave workgroups, 6 = 4 waves + 4 that move the weight stream through a 4-slot ring, 7 = 4 waves +
     // 2 slots; automatic: 6 while the 4-block workgroups fill at most half of the CUs ([1000,7,80], 63 workgroups: 0.044 against 0.049 ms;
     // [4000,7,80], 250 workgroups: 0.059 against 0.053; scripts/ubench/packed_bf16_bench.py)
-    const int variant = m->row_mode >= 5 ? m->row_mode : ((nblk + 3) / 4 <= m->n_cu / 2 ? 6 : 7);
+    // 8 = the latency variant: ONE block per workgroup, its four waves split the output features (savad_packed_bf16.h)
+    const int variant = m->row_mode >= 5 ? m->row_mode : (nblk <= SAVAD_NS_MAX_ROUNDS * m->n_cu ? 8 : ((nblk + 3) / 4 <= m->n_cu / 2 ? 6 : 7));
     const size_t ring2 = (size_t)2 * bf::RING_BYTES, ring4 = (size_t)4 * bf::RING_BYTES;
-    if (variant == 5)
+    if (variant == 8)
+        hipLaunchKernelGGL(bf::packed_forward_kernel_bf16_ns, dim3(nblk), dim3(256), bf::ns_lds_bytes(L), st, x, B, T, F, nblk, pm, c, out, wo, win_base,
+                           m->d_sat);
+    else if (variant == 5)
         hipLaunchKernelGGL((bf::packed_forward_kernel_bf16<8, 4, 0>), dim3((nblk + 7) / 8), dim3(512), ring4 + bias_bytes, st, x, B, T, F, nblk, pm, c, out,
                            wo, win_base, m->d_sat);
     else if (variant == 6)
