@@ -4,7 +4,7 @@
 # tree's csrc_hash), and -- with what is left of BUDGET seconds -- repeated runs of the multi-stream RCCL tests (the ones that
 # caught the registers-with-a-load-in-flight race of round 4).  Usage: [SKIP_TESTS=1] scripts/final_measurements.sh [BUDGET seconds, default 600]
 set -u
-BUDGET=${1:-600}
+BUDGET=${1:-60}
 T0=$(date +%s)
 OUT=$PWD/gpurun_out/r5final; mkdir -p $OUT
 if [ "${SKIP_TESTS:-0}" != 1 ]; then

@@ -24,7 +24,8 @@ pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parent.parent
 
 CASES = [("fp32", (8, 200, 80)), ("fp32", (2, 800, 80)), ("fp32", (500, 7, 80)), ("fp32", (64, 20, 80)), ("fp32", (32, 800, 80)),
-         ("fp32", (512, 50, 80)), ("bf16", (40, 264, 80)), ("bf16", (500, 7, 80)), ("bf16", (9000, 7, 80)), ("bf16", (64, 800, 80))]
+         ("fp32", (512, 50, 80)), ("bf16", (40, 264, 80)), ("bf16", (500, 7, 80)), ("bf16", (2000, 7, 80)), ("bf16", (9000, 7, 80)), ("bf16", (64, 800, 80))]
+# (the three bf16 T = 7 shapes: one block per workgroup with weights hand-streamed from L2; four blocks + four mover waves; the 2-slot ring)
 
 
 @pytest.fixture(scope="module")
