@@ -129,7 +129,7 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     for key, entry in data.items():
         if not isinstance(entry, dict):
             continue
-        if key == prefix or key.startswith(prefix + "<") or key.startswith(prefix + "_m") or (stem == "attention_bf16" and key.startswith("attention") and "bf16" in key and "row" not in key):
+        if key == prefix or key.startswith(prefix + "<") or key.startswith(prefix + "_m") or key.startswith(prefix + "_ns") or (stem == "attention_bf16" and key.startswith("attention") and "bf16" in key and "row" not in key):
             if "<" in key and prefix.startswith(("attention_row", "row")):
                 if ("<true" in key) != last:
                     continue
@@ -182,7 +182,7 @@ def rocprof_averages(precision, B, T):
     if (precision, B, T) == ("fp32", 32, 800):
         files = [f for f in sorted((REPO / "profiles").glob("*_kernel_avg.json")) if not any(t in f.name for t in ("bf16", "_t7_", "_t50_", "logmel"))]
     elif (precision, B, T) == ("bf16", 256, 800):
-        files = sorted((REPO / "profiles").glob("*bf16_kernel_avg.json"))
+        files = [f for f in sorted((REPO / "profiles").glob("*bf16_kernel_avg.json")) if "t7" not in f.name]
     elif (precision, B, T) == ("fp32", 1000, 7):
         files = sorted((REPO / "profiles").glob("*t7_kernel_avg.json"))
     elif (precision, B, T) == ("bf16", 1000, 7):
