@@ -791,9 +791,9 @@ int prepare_bf16_launch(savad_model* m) {
     if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::attention_pw_kernel_bf16, bf::PW_LDS_BYTES))) return rc;
-    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 2, 0>, r4 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
-    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 4, 4>, r8 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
-    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<8, 4, 0>, r8 + bf::PACKED_BF16_MAX_LAYERS * LBIAS * 4))) return rc;
+    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 2, 0>, r4 + (bf::PACKED_BF16_MAX_LAYERS * LBIAS + 2 * D + 4) * 4))) return rc;
+    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 4, 4>, r8 + (bf::PACKED_BF16_MAX_LAYERS * LBIAS + 2 * D + 4) * 4))) return rc;
+    if ((rc = allow_lds(bf::packed_forward_kernel_bf16<8, 4, 0>, r8 + (bf::PACKED_BF16_MAX_LAYERS * LBIAS + 2 * D + 4) * 4))) return rc;
     if ((rc = allow_lds(bf::packed_forward_kernel_bf16_ns, bf::ns_lds_bytes(bf::PACKED_BF16_MAX_LAYERS)))) return rc;
     m->lds_attrs_set = true;
     return SAVAD_OK;
@@ -828,7 +828,7 @@ void launch_packed_forward_bf16(savad_model* m, hipStream_t st, const float* x, 
     pm.bc = m->d_packed + m->p_bc;
     pm.L = L;
     const float c = (float)(1.4426950408889634 / sqrt((double)D));
-    const size_t bias_bytes = (size_t)L * LBIAS * 4;
+    const size_t bias_bytes = ((size_t)L * LBIAS + 2 * D + 4) * 4;   // every layer's biases + the classifier
     // variant: row_mode 5 = 8-wave workgroups, 6 = 4 waves + 4 that move the weight stream through a 4-slot ring, 7 = 4 waves +
     // 2 slots; automatic: 6 while the 4-block workgroups fill at most half of the CUs ([1000,7,80], 63 workgroups: 0.044 against 0.049 ms;
     // [4000,7,80], 250 workgroups: 0.059 against 0.053; scripts/ubench/packed_bf16_bench.py)

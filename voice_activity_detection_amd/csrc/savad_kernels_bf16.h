@@ -618,6 +618,10 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
     stage_bias(lb1, A.b1, DFF);
     stage_bias(lb2, A.b2, D);
     if (!LAST) stage_bias(lbn, A.bn, 3 * D);
+    else {  // the classifier's [2][D] weights and its bias take the unused Q/K/V bias slot: its tail reads them from LDS, not from global memory
+        stage_bias(lbn, A.wc, 2 * D);
+        if (threadIdx.x < 2) lbn[2 * D + threadIdx.x] = A.bn[threadIdx.x];
+    }
     hres_t* hb = A.hbuf + (size_t)blk * HBLK_FLOATS;
     f32x16 h1[4];
 #pragma unroll
@@ -664,15 +668,15 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
         float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
         for (int G = 0; G < 16; ++G) {
-            const f32x4 c0 = ld4(A.wc + 8 * G + 4 * h), c1 = ld4(A.wc + D + 8 * G + 4 * h);
+            const f32x4 c0 = ld4(lbn + 8 * G + 4 * h), c1 = ld4(lbn + D + 8 * G + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 z0 = __builtin_fmaf(xg[G][e], c0[e], z0);
                 z1 = __builtin_fmaf(xg[G][e], c1[e], z1);
             }
         }
-        z0 = half_sum(z0) + A.bn[0];
-        z1 = half_sum(z1) + A.bn[1];
+        z0 = half_sum(z0) + lbn[2 * D];
+        z1 = half_sum(z1) + lbn[2 * D + 1];
         const float mx = fmaxf(z0, z1);
         const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
         size_t row;

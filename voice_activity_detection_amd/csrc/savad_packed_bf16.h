@@ -123,6 +123,9 @@ __global__ __launch_bounds__(64 * (NW + DW), (NW + DW == 8) ? 1 : 2) void packed
         for (int t = 0; t < R::DEPTH; ++t) issue(t);
     }
     for (int i = threadIdx.x * 4; i < L * LBIAS; i += 64 * (NW + DW) * 4) st4(lbias + i, ld4(M.bias + i));  // published by the first ring barrier
+    float* lwc = lbias + L * LBIAS;   // the classifier's folded weights [2][D] + bias [2] behind the biases
+    for (int i = threadIdx.x * 4; i < 2 * D; i += 64 * (NW + DW) * 4) st4(lwc + i, ld4(M.wc + i));
+    if (threadIdx.x < 2) lwc[2 * D + threadIdx.x] = M.bc[threadIdx.x];
     if (mover) {  // one barrier per ring block, like the waves that compute
         for (int t = 0; t < NB; ++t) advance(t);
         return;
@@ -278,15 +281,15 @@ __global__ __launch_bounds__(64 * (NW + DW), (NW + DW == 8) ? 1 : 2) void packed
     float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
     for (int Gq = 0; Gq < 16; ++Gq) {
-        const f32x4 c0 = ld4(M.wc + 8 * Gq + 4 * h), c1 = ld4(M.wc + D + 8 * Gq + 4 * h);
+        const f32x4 c0 = ld4(lwc + 8 * Gq + 4 * h), c1 = ld4(lwc + D + 8 * Gq + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             z0 = __builtin_fmaf(xg[Gq][e], c0[e], z0);
             z1 = __builtin_fmaf(xg[Gq][e], c1[e], z1);
         }
     }
-    z0 = half_sum(z0) + M.bc[0];
-    z1 = half_sum(z1) + M.bc[1];
+    z0 = half_sum(z0) + lwc[2 * D];
+    z1 = half_sum(z1) + lwc[2 * D + 1];
     const float mx = fmaxf(z0, z1);
     const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
     if (h == 0 && valid) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
