@@ -484,6 +484,41 @@ def test_one_call_predictor_matches_the_three_entry_points(torch_cuda, model, pr
         model.precision = "fp32"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_reference_mode_one_hour_full_size(torch_cuda, model, state1234, precision):
+    """The reference's OWN mode at configs[4]'s size: an hour of audio = 360 001 feature frames -> 359 963 windows of 7 frames
+    (vad/predictor.py:169-224) -> boosted probabilities [N,7], in ONE library call (bf16: one launch over all 89 991 packed blocks,
+    windows read in place): the same bits as the three entry points stepwise in chunks of 16 384, the 0.5 placeholders where the
+    reference leaves them, and sampled stretches against the oracle's predictor."""
+    from oracle import oracle
+    from voice_activity_detection_amd import VADFromScratchPredictor
+
+    torch = torch_cuda
+    N = 360_001
+    feat_np = feats(4242, (N, 80))
+    feat = torch.from_numpy(feat_np).cuda()
+    model.precision = precision
+    try:
+        pred = VADFromScratchPredictor(model, "cuda")
+        p1, m1 = pred.predict_probabilities_device(feat)
+        p0, m0 = pred.predict_probabilities_device_stepwise(feat)
+        torch.cuda.synchronize()
+    finally:
+        model.precision = "fp32"
+    assert p1.shape == (N, 7) and torch.equal(p1, p0) and torch.equal(m1, m0)
+    got = p1.cpu().numpy()
+    assert np.isfinite(got).all() and (got >= 0).all() and (got <= 1).all()
+    tol = 3e-5 if precision == "fp32" else 6e-3
+    for lo in (0, 123_456, N - 400):   # the head (placeholders in the first 19 frames), the middle, the tail
+        hi = min(N, lo + 400)
+        a, b = max(0, lo - 38), min(N, hi + 38)
+        ref, _ = oracle.predict_probabilities(state1234, feat_np[a:b])
+        # a window only reads 38 frames around its centre: inside [a + 38, b - 38) the slice's predictor equals the recording's
+        s0, s1 = (lo if a == 0 else a + 38), (hi if b == N else b - 38)
+        assert np.abs(got[s0:s1] - ref[s0 - a:s1 - a]).max() < tol, (lo, np.abs(got[s0:s1] - ref[s0 - a:s1 - a]).max())
+    assert (got[:19] == 0.5).sum() == (oracle.predict_probabilities(state1234, feat_np[:200])[0][:19] == 0.5).sum()
+
+
 def test_gather_and_boost_bit_exact(torch_cuda):
     """Index/byte work is bit-exact against the oracle."""
     from oracle import oracle
