@@ -707,6 +707,49 @@ def reference_mode_hour(state, dev, min_seconds):
     return res
 
 
+def stream_one_hour_sharded(state, dev, rank, world, min_seconds):
+    """BASELINE configs[4] on N GPUs: 1 h of synthetic audio (the same recording on every rank's HOST) -> every rank uploads and
+    transforms ITS samples only (StreamingPredictor.audio_shard_plan: its windows, their frames, the samples those read), runs its
+    windows in place, ONE all_gather of the log-probs, overlap merge -> per-frame probabilities on every rank; bf16 and fp32
+    operands; wall time per call bracketed by barriers (max over ranks), real-time factor end to end from host audio."""
+    from voice_activity_detection_amd import SelfAttentiveVAD, StreamingPredictor
+    from voice_activity_detection_amd import distributed as vdist
+
+    seconds = 3600
+    model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model = model.to(dev).eval()
+    audio = np.random.default_rng(0).standard_normal(16000 * seconds, dtype=np.float32) * np.float32(0.1)
+    plan = StreamingPredictor.audio_shard_plan(len(audio), 800, 400, rank, world)
+    res = {"workload": f"BASELINE configs[4] on {world} GPU(s): {seconds} s of 16 kHz audio on the host -> per rank: its samples -> log-mel of its frames -> its "
+                       "windows T=800 hop=400 in place -> forward; one all_gather; overlap merge", "audio_seconds": seconds,
+           "rank0_share": {"windows": [int(plan[1]), int(plan[2])], "frames": [int(plan[3]), int(plan[4])], "samples": int(plan[6])},
+           "note": "wall time from HOST audio: includes each rank's host -> device copy of its own samples (230 MB / world over PCIe); the "
+                   "device-resident figure of one GPU is secondary.configs4_stream_1h.*.from_audio_ms of the N = 1 line"}
+    for prec in ("bf16", "fp32"):
+        model.precision = prec
+        sp = StreamingPredictor(model, dev, 800, 400, max_batch=256)
+        for _ in range(2):
+            probs = sp.predict_audio_device(audio)
+        torch.cuda.synchronize()
+        walls = []
+        while len(walls) < 5 or (vdist.agree(sum(walls), dev) < min_seconds and len(walls) < 50):   # rank 0's clock decides: equal counts of collectives
+            vdist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            probs = sp.predict_audio_device(audio)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            vdist.barrier()
+            walls.append(dt)
+        walls = vdist.max_over_ranks(walls, dev)
+        med = statistics.median(walls)
+        res[prec] = {"ms_per_hour_of_audio_from_host_audio": round(med * 1e3, 4), "ms_min": round(min(walls) * 1e3, 4), "calls": len(walls),
+                     "rtf": round(med / seconds, 10), "finite": bool(torch.isfinite(probs).all().item())}
+    model.precision = "fp32"
+    return res
+
+
 def stream_one_hour(state, dev, min_seconds):
     """BASELINE configs[4] at its full size on one GPU: 1 h of synthetic 16 kHz audio resident on the device -> log-mel
     [360001, 80] -> 900 sliding windows T=800 hop=400 (read in place: savad_forward_strided) -> forward -> overlap merge ->
@@ -932,7 +975,9 @@ def main():
             leg("configs4_stream_1h", lambda: stream_one_hour(state, dev, args.min_seconds))
         elif use_dist:
             b3, t3 = (int(v) for v in args.config3_shape.split(","))
-            leg("config3", shape_leg("bf16", b3, t3, "step"))  # configs[3]: [256 x world, 800, 80] bf16, batch-sharded
+            leg("config3", shape_leg("bf16", b3, t3, args.gather))  # configs[3]: [256 x world, 800, 80] bf16, batch-sharded
+            if not stub:
+                leg("config4", lambda: stream_one_hour_sharded(state, dev, rank, world, args.min_seconds))
 
     # every rank's collective counts (they must agree: a mismatch is a hang waiting to happen)
     counts = vdist.collective_counts()
@@ -982,9 +1027,9 @@ def main():
         if gather_modes:
             line.update(gather_modes)
         for k, v in secondary.items():
-            if k == "config3":
-                line["config3"] = v
-        rest = {k: v for k, v in secondary.items() if k != "config3"}
+            if k in ("config3", "config4"):
+                line[k] = v
+        rest = {k: v for k, v in secondary.items() if k not in ("config3", "config4")}
         if rest:
             line["secondary"] = rest
         if world == 1 and not args.no_cpu_baseline and not stub:
