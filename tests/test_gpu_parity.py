@@ -657,6 +657,36 @@ def test_bf16_single_launch_is_the_per_layer_launches_bit_for_bit(torch_cuda, mo
         assert np.abs(y0 - oracle.forward(state1234, x)).max() < BF16_TOL
 
 
+@pytest.mark.parametrize("F,L", [(40, 2), (257, 1), (13, 1), (80, 6), (80, 7)])
+def test_bf16_single_launch_other_model_sizes(torch_cuda, F, L):
+    """Other feature sizes (zero-padded to the K granularity inside the library: the windows are then copied, not read in place) and
+    layer counts (1 .. 6 in one launch; 7 falls back to the per-layer launches) through the T <= 32 bf16 paths: every variant the same
+    bits as the per-layer launches, the windowed predictor == the stepwise one, and close to the oracle."""
+    from oracle import oracle
+    from voice_activity_detection_amd import VADFromScratchPredictor
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    torch = torch_cuda
+    st = seeded_state_dict(300 + F + L, feature_size=F, num_layers=L)
+    m = make_model(torch, st, F=F, L=L)
+    x = feats(31 + F, (333, 7, F))
+    y1 = _run_bf16_mode(torch, m, x, 1)
+    for variant in (0, 5, 6, 7, 8):
+        assert np.array_equal(_run_bf16_mode(torch, m, x, variant), y1), (F, L, variant)
+    assert np.abs(y1 - oracle.forward(st, x)).max() < BF16_TOL * (1 if L <= 3 else 2)
+    if F % 4:   # (the predictor's window gather moves float4s: feature sizes that are not a multiple of 4 stop at the module level)
+        return
+    m.precision = "bf16"
+    try:
+        pred = VADFromScratchPredictor(m, "cuda")
+        feat = torch.from_numpy(feats(5 + F, (700, F))).cuda()
+        p1, m1 = pred.predict_probabilities_device(feat)
+        p0, m0 = pred.predict_probabilities_device_stepwise(feat)
+        assert torch.equal(p1, p0) and torch.equal(m1, m0)
+    finally:
+        m.precision = "fp32"
+
+
 def test_bf16_single_launch_against_the_reference_goldens(torch_cuda, model, golden):
     """The reference's own outputs (tests/golden/golden.npz: the pipeline shape g1, every edge length up to 32 frames, the
     [1000,7,80] chunk) through the bf16 single launch, at the bf16 bound."""
