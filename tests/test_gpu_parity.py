@@ -455,8 +455,8 @@ def test_predictor_level_golden(torch_cuda, model, golden, tag, n, seed):
 def test_one_call_predictor_matches_the_three_entry_points(torch_cuda, model, precision):
     """savad_predict_probabilities (windows read straight out of the feature matrix by the single-launch forward, boosted
     prediction as a gather) against savad_gather_windows + savad_forward + savad_boost: the same bits -- whole clips, a clip
-    longer than one launch's 4096 windows, clips too short for a single window, the bf16 path (window copies + forward
-    inside the call) and a reference-style chunk_size."""
+    longer than one launch's 4096 windows, clips too short for a single window, the bf16 path (since round 5: the windows read in place
+    by the bf16 single launch, any number of them) and a reference-style chunk_size."""
     from voice_activity_detection_amd import VADFromScratchPredictor
 
     torch = torch_cuda
