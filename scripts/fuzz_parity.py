@@ -19,7 +19,7 @@ for it in range(n):
     maxB = max(1, min(48, 40000 // T)) if T > 32 else int(rng.choice([3, 40, 300, 1200, 5000]))
     B = int(rng.integers(1, maxB + 1))
     prec = "bf16" if rng.random() < 0.35 else "fp32"
-    mode = int(rng.integers(0, 6))  # 0 .. 5 (include/savad.h)
+    mode = int(rng.integers(0, 9))  # 0 .. 8 (include/savad.h)
     splits = int(rng.choice([0, 0, 1, 1, 2, 3, 5]))
     if it % 4 == 3:   # another model width: csrc/savad_generic.h (fp32 only; splits = query tiles)
         D, F, L = int(rng.choice([6, 8, 30, 64, 96, 130, 256, 384])), int(rng.choice([13, 40, 80, 257])), int(rng.integers(1, 4))
