@@ -562,8 +562,34 @@ def clip_pipeline(state, dev, seconds, min_seconds):
         per_call.append(ms / 50)
         spent += ms * 1e-3
     med = statistics.median(per_call)
+    # the same chain with bf16 operands (the single-launch T <= 32 forward in its latency variant), and both as a captured HIP graph
+    # (four launches per clip: at this size the host side is a visible share of the call)
+    extra = {}
+    try:
+        model.precision = "bf16"
+        m16, mn16, _, _ = _event_blocks(chain, 50, min_seconds / 2, warm=30)
+        extra["bf16_ms_per_clip"] = round(m16, 4)
+        for prec in ("fp32", "bf16"):
+            model.precision = prec
+            for _ in range(3):
+                chain()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                chain()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                gp, _ = chain()
+            mg, _, _, _ = _event_blocks(g.replay, 50, min_seconds / 2, warm=5)
+            extra[f"{prec}_graph_ms_per_clip"] = round(mg, 4)
+    except Exception as exc:   # (a capture problem must not take the leg down)
+        extra["graph_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    finally:
+        model.precision = "fp32"
     return {"workload": f"BASELINE configs[0]: {seconds:g} s of 16 kHz audio on the device -> log-mel -> {probs.shape[0] - 6} windows [7,80] -> forward -> boost -> probabilities {list(probs.shape)}",
-            "ms_per_clip": round(med, 4), "ms_per_clip_min": round(min(per_call), 4), "frames": int(probs.shape[0]),
+            "ms_per_clip": round(med, 4), "ms_per_clip_min": round(min(per_call), 4), **extra, "frames": int(probs.shape[0]),
             "frames_per_s": round(probs.shape[0] / (med * 1e-3), 1), "real_time_factor": round(med * 1e-3 / seconds, 9),
             "finite": bool(torch.isfinite(probs).all().item()), "blocks": len(per_call)}
 
