@@ -780,6 +780,36 @@ def test_bf16_launch_shapes_identical(torch_cuda, model, shape):
     assert np.array_equal(ys[1], ys[2]) and np.array_equal(ys[1], ys[3]) and np.array_equal(ys[1], ys[0])
 
 
+@pytest.mark.parametrize("shape,F,bf16_input", [((100, 96, 80), 80, False), ((100, 96, 80), 80, True), ((41, 257, 80), 80, False),
+                                                ((300, 33, 80), 80, False), ((64, 160, 96), 96, False), ((64, 160, 48), 48, True),
+                                                ((33, 250, 13), 13, False), ((1500, 7, 80), 80, True)])
+def test_bf16_persistent_input_stage_bits(torch_cuda, shape, F, bf16_input):
+    """Round 5: from one block per CU up, the automatic bf16 schedules run the input stage as ONE persistent launch with its weights
+    resident in LDS (input_qkv_kernel_bf16_p: a workgroup per CU, every wave walking blocks on its own; at 80 features with the next
+    block's feature pieces and positional-encoding rows requested a block ahead by hand-issued loads and one counted wait).  Against
+    row_mode 1 (the ring kernel, a block per wave and workgroup lifetime): the same bits -- fp32 and bf16 features, ragged last
+    blocks, other feature sizes (the un-pipelined form; 13 is zero-padded inside the library), T <= 32 with bf16 features (the
+    per-layer launches: the single launch takes fp32 features), and on a workspace full of NaNs."""
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    torch = torch_cuda
+    st = seeded_state_dict(1234 if F == 80 else 700 + F, feature_size=F, num_layers=2)
+    m = make_model(torch, st, F=F, L=2)
+    x = feats(90 + sum(shape), shape)
+    m.row_mode = 1
+    try:
+        want = run_bf16(torch, m, x, bf16_input)
+    finally:
+        m.row_mode = 0
+    QB = (shape[1] + 31) // 32 if shape[1] > 32 else 1
+    assert (shape[0] * QB if shape[1] > 32 else shape[0] // (32 // shape[1])) >= 256   # enough blocks for the persistent form
+    got = run_bf16(torch, m, x, bf16_input)
+    if m._workspace is not None:
+        m._workspace.fill_(255)
+    again = run_bf16(torch, m, x, bf16_input)
+    assert np.isfinite(want).all() and np.array_equal(got, want) and np.array_equal(again, want)
+
+
 PW_SHAPES = [(3, 800, 80), (4, 801, 80), (7, 300, 80), (9, 1000, 80), (5, 33, 80), (2, 96, 80), (3, 65, 80), (1, 64, 80), (2, 264, 80),
              (40, 200, 80), (3, 128, 80), (2, 600, 80), (3, 320, 80), (70, 800, 80), (2, 3200, 80), (700, 100, 80), (530, 40, 80), (3, 48, 80),
              (19, 290, 80), (5, 833, 80)]

@@ -771,6 +771,9 @@ SAVAD_EXPORT int savad_set_precision(savad_handle m, int precision) {
     return SAVAD_OK;
 }
 
+#ifndef SAVAD_INPUT_PERSISTENT
+#define SAVAD_INPUT_PERSISTENT 1   // 0: experiment builds that keep the ring form of the bf16 input stage everywhere (scripts/ubench/input_p_ab.py)
+#endif
 namespace {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) for every bf16 kernel, once per handle
@@ -780,6 +783,10 @@ int prepare_bf16_launch(savad_model* m) {
     constexpr int r4 = bf::Ring<4>::NRING * bf::RING_BYTES, r8 = bf::Ring<8>::NRING * bf::RING_BYTES;
     if ((rc = allow_lds(bf::input_qkv_kernel_bf16<float, 4>, r4 + 3 * D * 4))) return rc;
     if ((rc = allow_lds(bf::input_qkv_kernel_bf16<__bf16, 4>, r4 + 3 * D * 4))) return rc;
+    if ((rc = allow_lds(bf::input_qkv_kernel_bf16_p<float, 8, 5>, bf::input_p_lds_bytes(5)))) return rc;
+    if ((rc = allow_lds(bf::input_qkv_kernel_bf16_p<__bf16, 8, 5>, bf::input_p_lds_bytes(5)))) return rc;
+    if ((rc = allow_lds(bf::input_qkv_kernel_bf16_p<float, 8, 0>, bf::input_p_lds_bytes(15)))) return rc;
+    if ((rc = allow_lds(bf::input_qkv_kernel_bf16_p<__bf16, 8, 0>, bf::input_p_lds_bytes(15)))) return rc;
     if ((rc = allow_lds(bf::attention_kernel_bf16<4>, r4))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<false, 4>, r4 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<true, 4>, r4 + 9 * D * 4))) return rc;
@@ -931,7 +938,24 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
         constexpr int ring = bf::Ring<NW>::NRING * bf::RING_BYTES;
         const int grid_rows = bp.nblk_pad / NW;
         const dim3 wg(64 * NW);
-        if (x_is_bf16)
+        // Persistent weights-resident form of the stage (input_qkv_kernel_bf16_p) in the automatic schedules and in 5, from one block per
+        // CU up (scripts/ubench/input_p_ab.py, us per launch ring / persistent, fp32 features at T = 800: B=16 19.4 / 17.1, 32 20.5 / 19.1,
+        // 64 22.4 / 22.7, 128 39.9 / 33.2, 256 79.6 / 64.9, 512 151.4 / 114.6; the same bits); row_mode 1 - 3 keep the ring kernel.
+        const int KSx = F / 16;
+        if (SAVAD_INPUT_PERSISTENT && (automatic_bf16 || m->row_mode == 5) && KSx >= 1 && KSx <= 15 && bp.nblk_pad >= m->n_cu) {
+            auto go = [&](auto xt, auto ks_tag) {
+                using XT = decltype(xt);
+                constexpr int KSC = decltype(ks_tag)::value;
+                hipLaunchKernelGGL((bf::input_qkv_kernel_bf16_p<XT, 8, KSC>), dim3(m->n_cu), dim3(512), bf::input_p_lds_bytes(KSx), st,
+                                   (const XT*)x, xbs, B, T, F, bp.nblk, bp.nblk_pad, Fr + m->f_win, R + m->r_bin, m->d_pe,
+                                   Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb, qf, kf, vtf, c, m->d_sat);
+            };
+            if (KSx == 5) {
+                if (x_is_bf16) go(__bf16{}, std::integral_constant<int, 5>{}); else go(float{}, std::integral_constant<int, 5>{});
+            } else {
+                if (x_is_bf16) go(__bf16{}, std::integral_constant<int, 0>{}); else go(float{}, std::integral_constant<int, 0>{});
+            }
+        } else if (x_is_bf16)
             hipLaunchKernelGGL((bf::input_qkv_kernel_bf16<__bf16, NW>), dim3(grid_rows), wg, ring + 3 * D * 4, st, (const __bf16*)x, xbs,
                                B, T, F, bp.nblk, Fr + m->f_win, R + m->r_bin, m->d_pe, Fr + m->lf[0].wqkv, P + m->lp[0].bqkv, hb,
                                qf, kf, vtf, c, m->d_sat);

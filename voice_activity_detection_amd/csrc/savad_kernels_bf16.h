@@ -377,6 +377,201 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void input_qkv_kernel_bf1
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernel 1, persistent form (round 5): the stage's weights -- layer 0's Q / K / V fragments (96 KiB) and the input Linear's
+// (4 KS KiB, KS = F / 16) -- are RESIDENT in LDS, one workgroup of NW waves per CU, every wave walking blocks on its own:
+// no weight ring, no barrier after the prologue, and the 96 KiB a 4-block workgroup of the kernel above pulls through the
+// L2 for every 128 rows (157 MB per launch at [256,800,80], as much again as the stage writes) are pulled once per CU.
+// Block order: round r of the launch covers blocks r G NW .. (r+1) G NW - 1 (G workgroups), wave w of workgroup g taking
+// block r G NW + w G + g -- neighbouring CUs write neighbouring blocks, and a thin last round spreads over all CUs.
+// KSC = KS at compile time (5: the reference's 80 mel bands) adds a software pipeline: the NEXT block's feature pieces and
+// positional-encoding rows are requested by hand-issued loads while this block's LayerNorm and Q / K / V products run, and
+// waited for with ONE counted s_waitcnt at the bottom of this one -- vmcnt(24): the 24 fragment stores of this block are
+// younger than every one of those loads, and vector-memory operations retire in order, so "at most 24 outstanding" means
+// all the loads have landed while the stores may still be in flight (the ablation of the un-pipelined form, scripts/ubench/
+// input_p_ablate.sh: 72 us with, 47 us without the feature loads -- five dependent round trips to memory per block).
+// KSC = 0: any KS, features loaded where they are used.
+// Arithmetic, operand for operand, is the kernel above's: the same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int input_p_lds_bytes(int KS) { return 3 * RING_BYTES + KS * 4 * FRAG_BYTES + 4 * D * 4; }
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <typename XT>
+struct XRaw;
+template <>
+struct XRaw<float> {
+    f32x4 a, b;
+};
+template <>
+struct XRaw<__bf16> {
+    u32x2 a, b;
+};
+// the two pieces of K-step ks of one input row (load_x_frag's addresses), requested without waiting
+template <int KS>
+__device__ __forceinline__ void request_x(XRaw<float> (&r)[KS], const float* lanep /* &x[row][4 h] */) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r[ks].a) : "v"(lanep), "n"(64 * ks) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r[ks].b) : "v"(lanep), "n"(64 * ks + 32) : "memory");
+    }
+}
+template <int KS>
+__device__ __forceinline__ void request_x(XRaw<__bf16> (&r)[KS], const __bf16* lanep) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(r[ks].a) : "v"(lanep), "n"(32 * ks) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(r[ks].b) : "v"(lanep), "n"(32 * ks + 16) : "memory");
+    }
+}
+__device__ __forceinline__ bf16x8 x_frag(const XRaw<float>& r, bool valid) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = (__bf16)(valid ? r.a[e] : 0.0f);
+        f[4 + e] = (__bf16)(valid ? r.b[e] : 0.0f);
+    }
+    return f;
+}
+__device__ __forceinline__ bf16x8 x_frag(const XRaw<__bf16>& r, bool valid) {
+    return __builtin_bit_cast(bf16x8, valid ? u32x4{r.a[0], r.a[1], r.b[0], r.b[1]} : u32x4{0u, 0u, 0u, 0u});
+}
+// a positional-encoding row in add_block's pieces: piece 4 nb + g = features 32 nb + 8 g + 4 h ..
+__device__ __forceinline__ void request_pe(f32x4 (&r)[16], const float* lanep /* &pe[t][4 h] */) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r[i]) : "v"(lanep), "n"(128 * (i >> 2) + 32 * (i & 3)) : "memory");
+}
+template <int PENDING>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");
+}
+template <class V>
+__device__ __forceinline__ void landed(V& v) {   // orders every use of v behind the vm_wait in front of it
+    asm volatile("" : "+v"(v));
+}
+
+template <typename XT, int NW, int KSC>
+__global__ __launch_bounds__(64 * NW, 1) void input_qkv_kernel_bf16_p(
+    const XT* __restrict__ x, long xbs, int B, int T, int F, int nblk, int nblk_pad, const char* __restrict__ win_frag,
+    const float* __restrict__ bin, const float* __restrict__ pe, const char* __restrict__ wqkv_frag,
+    const float* __restrict__ bqkv, hres_t* __restrict__ hbuf, char* __restrict__ qf, char* __restrict__ kf,
+    char* __restrict__ vtf, float qscale, unsigned* __restrict__ satcnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KS = KSC ? KSC : F / 16;
+    char* lwin = smem + 3 * RING_BYTES;
+    float* lbq = reinterpret_cast<float*>(lwin + KS * 4 * FRAG_BYTES);
+    float* lbin = lbq + 3 * D;
+    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {   // prologue: 4-KiB pieces of the two weight images, wave w moving pieces w, w + NW, ... by LDS-DMA
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+        const int npieces = 24 + KS;
+        for (int p = w; p < npieces; p += NW) {
+            const char* src = p < 24 ? wqkv_frag + (size_t)p * 4 * FRAG_BYTES : win_frag + (size_t)(p - 24) * 4 * FRAG_BYTES;
+            Ring<4>::dma4k<0>(src, lds0 + (unsigned)p * 4 * FRAG_BYTES, (unsigned)lane * 16u);
+        }
+        wait_vmem_all();
+        __syncthreads();
+        for (int i = threadIdx.x * 4; i < 3 * D; i += 64 * NW * 4) st4(lbq + i, ld4(bqkv + i));
+        for (int i = threadIdx.x * 4; i < D; i += 64 * NW * 4) st4(lbin + i, ld4(bin + i));
+        __syncthreads();
+    }
+    const int per_round = gridDim.x * NW;
+    int blk = w * gridDim.x + blockIdx.x;
+    if (blk >= nblk_pad) return;   // (the padding blocks are written like the kernel above writes them)
+    size_t row;
+    int t_frame;
+    bool valid = (blk < nblk) && slot_row(B, T, blk, m, row, t_frame);
+    if (!valid) {
+        row = 0;
+        t_frame = 0;
+    }
+    XRaw<XT> xr[KSC ? KSC : 1];
+    f32x4 per[16];
+    if constexpr (KSC > 0) {
+        request_x(xr, x + x_row_offset(row, T, F, xbs) + 4 * h);
+        request_pe(per, pe + (size_t)t_frame * D + 4 * h);
+        vm_wait<0>();
+    }
+    for (;;) {
+        f32x16 h0[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            h0[nb] = zero16();
+            add_bias(h0[nb], lbin + 32 * nb, h);
+        }
+        const int nxt = blk + per_round;
+        const bool has_next = nxt < nblk_pad;   // wave-uniform
+        size_t nrow = 0;
+        int nt = 0;
+        bool nvalid = false;
+        if (has_next) {
+            nvalid = (nxt < nblk) && slot_row(B, T, nxt, m, nrow, nt);
+            if (!nvalid) {
+                nrow = 0;
+                nt = 0;
+            }
+        }
+        if constexpr (KSC > 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) landed(per[i]);   // (behind the vm_wait in front of the loop / at its bottom)
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks) {
+                landed(xr[ks].a);
+                landed(xr[ks].b);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) h0[nb][4 * g + s_] += per[4 * nb + g][s_];
+            bf16x8 xf[KSC];
+            if (__all(valid)) {   // (wave-uniform: all but a sequence's last block)
+#pragma unroll
+                for (int ks = 0; ks < KSC; ++ks) xf[ks] = x_frag(xr[ks], true);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KSC; ++ks) xf[ks] = x_frag(xr[ks], valid);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    h0[nb] = SAVAD_MFMA_BF16(ldfrag(lwin + ((nb * KSC + ks) * 64 + lane) * 16), xf[ks], h0[nb]);
+            if (has_next) request_x(xr, x + x_row_offset(nrow, T, F, xbs) + 4 * h);
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) add_block(h0[nb], pe + (size_t)t_frame * D + 32 * nb, h);
+            const XT* xrow = x + x_row_offset(row, T, F, xbs);
+            for (int ks = 0; ks < KS; ++ks) {
+                const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
+                const bf16x8 xf = (SAVAD_ABLATE & 64) ? ldfrag(lwin + lane * 16 + ks * 64) : load_x_frag(xrow + f0, valid);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) h0[nb] = SAVAD_MFMA_BF16(ldfrag(lwin + ((nb * KS + ks) * 64 + lane) * 16), xf, h0[nb]);
+            }
+        }
+        if (!(SAVAD_ABLATE & 32) || qscale < 0.0f) store_hblock(hbuf + (size_t)blk * HBLK_FLOATS, h0, lane, satcnt);
+        f32x4 xg[16];
+        layernorm_regs(h0, xg);
+        bf16x8 xp[8];
+        pack_row(xg, xp);
+        if constexpr (KSC > 0) {
+            if (has_next) request_pe(per, pe + (size_t)nt * D + 4 * h);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            qkv_block_bf16(t, smem + t * RING_BYTES, xp, lbq, qf, kf, vtf, blk, lane, qscale, !(SAVAD_ABLATE & 16) || qscale < 0.0f);
+        // the next block's requests are older than this block's 24 fragment stores (in front of the exit test: every path from
+        // a request to the loop's top passes the wait, which is what scripts/check_async_loads.py can verify)
+        if constexpr (KSC > 0) vm_wait<24>();
+        if (!has_next) break;
+        blk = nxt;
+        row = nrow;
+        t_frame = nt;
+        valid = nvalid;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Kernel 2 (bf16): flash attention on fragments.  T > 32: workgroup = (sequence, group of <= NW
 // query blocks); K and V^T fragments of 2 key blocks (64 keys, 32 KiB) per ring block.
 // Output: NORMALISED context as B-operand fragments.
