@@ -204,7 +204,7 @@ ROCPROF_NAMES = {  # bench launch label -> kernel short name in the rocprofv3 st
     "attention_row": "attention_row_kernel<false>", "attention_row_last": "attention_row_kernel<true>",
     "input_qkv": "input_qkv_kernel_m", "packed_forward": "packed_forward_kernel",
     "attention_bf16": ("attention_pw_kernel_bf16", "attention_kernel_bf16<4>"), "row_bf16": "row_kernel_bf16<false, 4>", "row_last_bf16": "row_kernel_bf16<true, 4>",
-    "input_qkv_bf16": "input_qkv_kernel_bf16<__bf16, 4>",
+    "input_qkv_bf16": ("input_qkv_kernel_bf16_p<__bf16, 8, 5>", "input_qkv_kernel_bf16<__bf16, 4>"),
     "packed_forward_bf16": ("packed_forward_kernel_bf16_ns", "packed_forward_kernel_bf16<4, 4, 4>", "packed_forward_kernel_bf16<4, 2, 0>"),
 }
 

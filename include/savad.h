@@ -132,6 +132,8 @@ int savad_set_attention_splits(savad_handle h, int splits);
  *        tail group of one or two query blocks (ceil(T / 32) mod 8 in {1, 2}), whose keys are summed as four partial softmaxes
  *        (key-split item): those agree with 1 to the bf16 rounding of the context.  Automatic picks it where a cost model of
  *        both attention kernels (savad.hip, pw_pays) has it ahead: large batches of long sequences ([160+,800], [256,1000] ...)
+ *     0, 4 and 5 run the input stage, from one 32-row block per CU up, as ONE persistent launch with its weights resident in LDS
+ *        (input_qkv_kernel_bf16_p; the same bits as the ring kernel 1 - 3 keep)
  *   bf16 operands, T <= 32 (the reference pipeline's 7-frame windows): 0 and 4 run the WHOLE forward in one launch (a wave per
  *        packed block for all layers, csrc/savad_packed_bf16.h; same bits as the per-layer launches of 1 - 3) in the variant
  *        the number of blocks suggests; 5 / 6 / 7 / 8 pin a variant (8-wave workgroups / 4 waves + 4 that move the weight stream

@@ -21,6 +21,7 @@ LABELS = {
     "attention_kernel": "attention", "row_kernel_m<false>": "row", "row_kernel_m<true>": "row_last",
     "attention_pw_kernel_bf16": "attention_bf16", "attention_kernel_bf16<4>": "attention_bf16",
     "row_kernel_bf16<false, 4>": "row_bf16", "row_kernel_bf16<true, 4>": "row_last_bf16", "input_qkv_kernel_bf16<__bf16, 4>": "input_qkv_bf16",
+    "input_qkv_kernel_bf16_p<__bf16, 8, 5>": "input_qkv_bf16",
     "packed_forward_kernel": "packed_forward",
     "packed_forward_kernel_bf16<4, 4, 4>": "packed_forward_bf16", "packed_forward_kernel_bf16<4, 2, 0>": "packed_forward_bf16",
     "packed_forward_kernel_bf16_ns": "packed_forward_bf16",
