@@ -508,6 +508,42 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 __device__ __forceinline__ void stage_bias(float* dst, const float* __restrict__ src, int count) {
     for (int i = threadIdx.x * 4; i < count; i += 256 * 4) st4(dst + i, ld4(src + i));
 }
+// Several pieces at once (each <= 1024 floats, a multiple of 4; count 0 = none): ALL the loads first, then the LDS stores.
+// Piece by piece (stage_bias four times in a row) the compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per piece: four
+// dependent round trips to the L2 at the start of every row chain, the first of which also drains whatever else the wave has
+// in flight (round 5, read off the disassembly; the loads are unconditional -- a lane past a piece's end re-reads its last
+// float4 -- so that no branch separates them).
+struct BiasPiece {
+    float* dst;
+    const float* src;
+    int count;
+};
+template <int N>
+struct BiasRegs {
+    f32x4 v[N];
+};
+template <int N>
+__device__ __forceinline__ BiasRegs<N> request_bias_pieces(const BiasPiece (&p)[N]) {
+    const int i = threadIdx.x * 4;
+    BiasRegs<N> r;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int j = i < p[n].count ? i : (p[n].count >= 4 ? p[n].count - 4 : 0);
+        r.v[n] = ld4(p[n].src + j);
+    }
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void commit_bias_pieces(const BiasPiece (&p)[N], const BiasRegs<N>& r) {
+    const int i = threadIdx.x * 4;
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+        if (i < p[n].count) st4(p[n].dst + i, r.v[n]);
+}
+template <int N>
+__device__ __forceinline__ void stage_bias_pieces(const BiasPiece (&p)[N]) {
+    commit_bias_pieces(p, request_bias_pieces(p));
+}
 __device__ __forceinline__ f32x16 bias_block(const float* lds_bias /* &bias[n0] */, int h) {
     f32x16 r;
 #pragma unroll
@@ -1337,10 +1373,7 @@ __global__ __launch_bounds__(256, 2) void row_kernel_m(
     SAVAD_STAMP(0);
     const DmaLanes LA = dma_lanes_rows32(D, true, w, lane), LB = dma_lanes_rows128(DFF, w, lane);
     dma_block(Wo, LA, ring, w);
-    stage_bias(lbo, bo, D);
-    stage_bias(lb1, b1, DFF);
-    stage_bias(lb2, b2, D);
-    if (!LAST) stage_bias(lbn, bn, 3 * D);
+    stage_bias_pieces<4>({{lbo, bo, D}, {lb1, b1, DFF}, {lb2, b2, D}, {lbn, LAST ? bo : bn, LAST ? 0 : 3 * D}});
     // the out-projection accumulators start at the residual stream.  Without key splits the loads are issued now and
     // consumed after phase 0; with splits they wait until the partials are combined: the combine keeps two partials
     // (128 registers) in flight next to the 64 accumulators, and 64 more live registers made the kernel spill
@@ -1469,10 +1502,7 @@ __global__ __launch_bounds__(256, 2) void attention_row_kernel(
     __syncthreads();
     const DmaLanes LA = dma_lanes_rows32(D, true, w, lane), LB = dma_lanes_rows128(DFF, w, lane);
     dma_block(Wo, LA, ring, w);
-    stage_bias(lbo, bo, D);
-    stage_bias(lb1, b1, DFF);
-    stage_bias(lb2, b2, D);
-    if (!LAST) stage_bias(lbn, bn, 3 * D);
+    stage_bias_pieces<4>({{lbo, bo, D}, {lb1, b1, DFF}, {lb2, b2, D}, {lbn, LAST ? bo : bn, LAST ? 0 : 3 * D}});
     {
         const float inv = qvalid ? 1.0f / l_run : 0.0f;
 #pragma unroll

@@ -809,19 +809,19 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
     };
 #pragma unroll
     for (int t = 0; t < R::DEPTH; ++t) issue(t);
-    stage_bias(lbo, A.bo, D);
-    stage_bias(lb1, A.b1, DFF);
-    stage_bias(lb2, A.b2, D);
-    if (!LAST) stage_bias(lbn, A.bn, 3 * D);
-    else {  // the classifier's [2][D] weights and its bias take the unused Q/K/V bias slot: its tail reads them from LDS, not from global memory
-        stage_bias(lbn, A.wc, 2 * D);
-        if (threadIdx.x < 2) lbn[2 * D + threadIdx.x] = A.bn[threadIdx.x];
-    }
+    // Every request of the prologue goes out before anything waits (round 5; stage_bias_pieces): the residual block first, then
+    // the bias pieces -- LAST: the classifier's [2][D] weights and its bias take the unused Q/K/V bias slot, its tail reads them
+    // from LDS, not from global memory -- and one round trip later the ring's first barrier publishes them.
+    const BiasPiece pieces[4] = {{lbo, A.bo, D}, {lb1, A.b1, DFF}, {lb2, A.b2, D}, {lbn, LAST ? A.wc : A.bn, LAST ? 2 * D : 3 * D}};
+    const BiasRegs<4> breg = request_bias_pieces(pieces);
+    const float bc = LAST ? A.bn[threadIdx.x & 1] : 0.0f;
     hres_t* hb = A.hbuf + (size_t)blk * HBLK_FLOATS;
     f32x16 h1[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) h1[nb] = zero16();
     load_hblock(h1, hb, lane);
+    commit_bias_pieces(pieces, breg);
+    if (LAST && threadIdx.x < 2) lbn[2 * D + threadIdx.x] = bc;
     // ---- h1 = h + bo + ctx Wo^T
     advance(0);
 #pragma unroll
