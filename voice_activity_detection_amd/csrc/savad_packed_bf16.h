@@ -153,12 +153,36 @@ __global__ __launch_bounds__(64 * (NW + DW), (NW + DW == 8) ? 1 : 2) void packed
         const size_t src_row = wo.w > 0 ? (size_t)win_base + (valid ? seq : 0) + wo.off[valid ? t_frame : 0] : row;
         const float* xr = x + src_row * (size_t)F;
         const int KS = F / 16;
-        for (int ks = 0; ks < KS; ++ks) {
+        // Every feature piece of the rows is requested before the first MFMA (up to 128 features), the input weights' fragments one
+        // K-step ahead of the MFMAs that use them (round 5; before: load, wait, four MFMAs per K-step -- five dependent round trips at
+        // the head of every block, the rows' cache lines among them).  The same MFMAs in the same order.
+        constexpr int KSMAX = 8;
+        bf16x8 xf[KSMAX], wcur[4], wnxt[4];
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            const int kc = ks < KS ? ks : KS - 1;   // past the end: a valid address, unused
+            xf[ks] = load_x_frag(xr + 32 * (kc >> 1) + 16 * (kc & 1) + 4 * h, valid);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) wcur[nb] = ldfrag(M.win + ((size_t)(nb * KS) * 64 + lane) * 16);
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            if (ks < KS) {   // wave-uniform
+                const int kn = ks + 1 < KS ? ks + 1 : KS - 1;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) wnxt[nb] = ldfrag(M.win + ((size_t)(nb * KS + kn) * 64 + lane) * 16);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = SAVAD_MFMA_BF16(wcur[nb], xf[ks], acc[nb]);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) wcur[nb] = wnxt[nb];
+            }
+        }
+        for (int ks = KSMAX; ks < KS; ++ks) {
             const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
-            const bf16x8 xf = load_x_frag(xr + f0, valid);
+            const bf16x8 xfl = load_x_frag(xr + f0, valid);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
-                acc[nb] = SAVAD_MFMA_BF16(ldfrag(M.win + ((size_t)(nb * KS + ks) * 64 + lane) * 16), xf, acc[nb]);
+                acc[nb] = SAVAD_MFMA_BF16(ldfrag(M.win + ((size_t)(nb * KS + ks) * 64 + lane) * 16), xfl, acc[nb]);
         }
     }
     u32x4 hp[8];
