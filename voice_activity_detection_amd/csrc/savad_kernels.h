@@ -274,6 +274,66 @@ __global__ __launch_bounds__(64) void attention_packed_kernel(const float* __res
 //                           32 consecutive floats of one key row: conflict-free), row-major.
 constexpr int KV_TILE_FLOATS = 32 * D;
 
+// O^T += V^T P^T for one LDS-staged 32-key tile (`vb`: [32 keys][128] row-major; lane (n, h) of K-step r needs
+// V[8 (r >> 2) + 4 h + (r & 3)][n + 32 nb]).  The 32 pairs of values (two consecutive keys, one ds_read2st64_b32 each) are read by
+// HAND-issued loads SAVAD_PV_PIPE pairs ahead of the MFMAs that consume them, with counted lgkmcnt waits (round 5).  Left to the
+// compiler every pair landed in the SAME register pair -- read, s_waitcnt lgkmcnt(0), two MFMAs, read ... -- so that each 128
+// cycles of matrix work waited out one LDS round trip that could only be requested once the pair before had issued: the one
+// wave per SIMD of the fused launch has nothing else to cover it with.  dma(nb) issues the wave's nb-th DMA piece of the next
+// tile (vector-memory counter: not part of the counting here).  The same MFMAs in the same order: the same bits.
+#ifndef SAVAD_PV_PIPE
+#define SAVAD_PV_PIPE 4
+#endif
+template <class Dma>
+__device__ __forceinline__ void pv_tile_lds(f32x16 (&O)[4], const f32x16& sc, const float* vb, int n, int h, Dma&& dma) {
+#if SAVAD_PV_PIPE > 0
+    constexpr int P = SAVAD_PV_PIPE;
+    static_assert(P >= 1 && P <= 8, "SAVAD_PV_PIPE");
+    // LDS byte address (low half of the flat address); odd feature blocks from a second base 32 floats on: the instruction's two
+    // offsets count units of 64 dwords (a key row is two units, two feature blocks are one)
+    const unsigned a0 = (unsigned)(size_t)(vb + 4 * h * D + n), a1 = a0 + 128u;
+    f32x2 f[P];
+    // pair i = 8 nb + p holds K-steps r = 2 p, 2 p + 1: keys R, R + 1 with R = 8 (p >> 1) + 2 (p & 1)
+#define SAVAD_PV_OFF0(i) (2 * (8 * (((i) & 7) >> 1) + 2 * ((i) & 1)) + ((i) >> 4))
+#define SAVAD_PV_LOAD(i)                                                                               \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3"                                       \
+                 : "=v"(f[(i) % P])                                                                    \
+                 : "v"((((i) >> 3) & 1) ? a1 : a0), "n"(SAVAD_PV_OFF0(i)), "n"(SAVAD_PV_OFF0(i) + 2))
+#define SAVAD_PV_STEP(i)                                                                               \
+    {                                                                                                  \
+        constexpr int newer_ = 31 - (i) < P - 1 ? 31 - (i) : P - 1; /* younger reads that may stay in flight */ \
+        if constexpr (((i) & 7) == 0) dma((i) >> 3);                                                   \
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[(i) % P]) : "n"(newer_));                        \
+        O[(i) >> 3] = SAVAD_MFMA(f[(i) % P][0], sc[2 * ((i) & 7)], O[(i) >> 3]);                       \
+        O[(i) >> 3] = SAVAD_MFMA(f[(i) % P][1], sc[2 * ((i) & 7) + 1], O[(i) >> 3]);                   \
+        if constexpr ((i) + P < 32) SAVAD_PV_LOAD((i) + P);                                            \
+    }
+#define SAVAD_PV_STEP4(i) SAVAD_PV_STEP(i) SAVAD_PV_STEP((i) + 1) SAVAD_PV_STEP((i) + 2) SAVAD_PV_STEP((i) + 3)
+    SAVAD_PV_LOAD(0);
+    if constexpr (P > 1) SAVAD_PV_LOAD(1);
+    if constexpr (P > 2) SAVAD_PV_LOAD(2);
+    if constexpr (P > 3) SAVAD_PV_LOAD(3);
+    if constexpr (P > 4) SAVAD_PV_LOAD(4);
+    if constexpr (P > 5) SAVAD_PV_LOAD(5);
+    if constexpr (P > 6) SAVAD_PV_LOAD(6);
+    if constexpr (P > 7) SAVAD_PV_LOAD(7);
+    SAVAD_PV_STEP4(0) SAVAD_PV_STEP4(4) SAVAD_PV_STEP4(8) SAVAD_PV_STEP4(12) SAVAD_PV_STEP4(16) SAVAD_PV_STEP4(20)
+    SAVAD_PV_STEP4(24) SAVAD_PV_STEP4(28)
+#undef SAVAD_PV_STEP4
+#undef SAVAD_PV_STEP
+#undef SAVAD_PV_LOAD
+#undef SAVAD_PV_OFF0
+#else
+    const float* vp = vb + 4 * h * D + n;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        dma(nb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
+    }
+#endif
+}
+
 // Workgroup -> (sequence, index among the sequence's `per_seq` workgroups) for the attention-type kernels.
 // Workgroups go to the 8 XCDs round-robin by blockIdx (each XCD has its own L2); the linear order (sequence major)
 // is cut into 8 equal chunks, one per XCD, so that a sequence's workgroups -- which all read the same K/V -- share an
@@ -475,13 +535,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         online_softmax(sc, m_run, l_run, O, c);
         SAVAD_TACC(3);
         // ---- O^T += V^T P^T
-        const float* vp = vb + 4 * h * D + n;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
+        pv_tile_lds(O, sc, vb, n, h, [&](int nb) {
             if (more) dma_piece(vnext, LV, kn + KV_TILE_FLOATS, w, nb);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
-        }
+        });
         SAVAD_TACC(4);
     }
 #ifdef SAVAD_TIMING
@@ -1476,13 +1532,9 @@ __global__ __launch_bounds__(256, 2) void attention_row_kernel(
             }
         }
         online_softmax(sc, m_run, l_run, O, c);
-        const float* vp = vb + 4 * h * D + n;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
+        pv_tile_lds(O, sc, vb, n, h, [&](int nb) {
             if (more) dma_piece(vnext, LV, kn2 + KV_TILE_FLOATS, w, nb);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[nb] = SAVAD_MFMA(vp[(8 * (r >> 2) + (r & 3)) * D + 32 * nb], sc[r], O[nb]);
-        }
+        });
     }
     // ---- hand-over: everyone is done with the K/V tiles; the staging area becomes weight ring + biases
     float* ring = lds;
