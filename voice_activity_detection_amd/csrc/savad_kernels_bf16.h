@@ -142,6 +142,14 @@ __device__ __forceinline__ void store_hblock(hres_t* hb, const f32x16 (&x)[4], i
 // Completion is tracked with a COUNTED s_waitcnt: loads return in order, so "at most PER * k
 // outstanding" (k = DMA blocks issued after block t) implies block t has landed, whatever other
 // vector-memory operations are in flight (they can only make the wait longer, never shorter).
+// Ring waits of the 2-slot ring leave a wave's own result stores in flight (round 5): the residual block's and the Q / K blocks'
+// eight stores are YOUNGER than the DMA block the next ring step waits for, vector-memory operations retire in order, so
+// vmcnt(8) instead of vmcnt(0) says "the DMA has landed" without draining the stores' write acknowledgements three times per
+// block (bf16 row launch at [256,800,80]: 105.3 -> 104.0 us, the forward -0.5 %; same-box A/B, scripts/ubench/ab_head.sh).
+// Round 2 had tried this on the fp32-residual kernels and seen no change.  0 = the drained form (A/B builds).
+#ifndef SAVAD_STORES_IN_FLIGHT
+#define SAVAD_STORES_IN_FLIGHT 1
+#endif
 template <int NW, int NR = (NW == 8 ? 4 : 2), int DP = NR - 1>
 struct Ring {
     static constexpr int NRING = NR;
@@ -192,13 +200,16 @@ struct Ring {
         }
     }
     // wait until block t has landed for every wave; `newer` = DMA blocks issued after block t (wave-uniform)
-    __device__ __forceinline__ void acquire(int newer) const {
+    // stores_after (wave-uniform, 0 or 8): result stores this wave issued AFTER its newest DMA block -- they may stay in flight
+    __device__ __forceinline__ void acquire(int newer, int stores_after = 0) const {
         if (SAVAD_ABLATE & 2) return;
         // builtin, not asm: see wait_vmem_all().  gfx9 encoding: vmcnt in bits 3:0 (PER <= 8), others "no wait"
         if (DEPTH >= 3 && newer >= 2)
             __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * PER));
         else if (DEPTH >= 2 && newer == 1)
             __builtin_amdgcn_s_waitcnt(vmcnt_imm(PER));
+        else if (SAVAD_STORES_IN_FLIGHT && DEPTH == 1 && stores_after == 8)
+            __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
         else
             __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         asm volatile("" ::: "memory");
@@ -803,8 +814,8 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
         });
     };
     // acquire block t (wave-uniform t), then keep the DMA DEPTH blocks ahead
-    auto advance = [&](int t) {
-        ring.acquire(NBLK - 1 - t < R::DEPTH - 1 ? NBLK - 1 - t : R::DEPTH - 1);
+    auto advance = [&](int t, int stores_after = 0) {
+        ring.acquire(NBLK - 1 - t < R::DEPTH - 1 ? NBLK - 1 - t : R::DEPTH - 1, stores_after);
         if (t + R::DEPTH < NBLK) issue(t + R::DEPTH);
     };
 #pragma unroll
@@ -856,7 +867,7 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
         pack_row(xg, xp);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
-            advance(9 + rb);
+            advance(9 + rb, live ? 8 : 0);   // the residual block's / the previous Q / K block's eight stores are younger than the DMA waited for
             qkv_block_bf16(rb, ring.slot(9 + rb), xp, lbn, A.qf, A.kf, A.vtf, blk, lane, A.qscale, live);
         }
     } else {
