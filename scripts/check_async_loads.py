@@ -32,6 +32,11 @@ Round 5 added two more rules, same data flow:
     access LDS (ds_read / ds_write) and issue a DMA again without an `s_barrier` in between (a removed or misplaced ring barrier
     shows as exactly that).  Kernels in which one logical request is several statements with LDS reads of OTHER buffers scheduled
     between them are listed in DMA_DISJOINT with the reason.
+  * LDS-DMA publication (dma_barriers_in_flight): a wave's DMA pieces must have LANDED -- retired by one of its own counted
+    `s_waitcnt vmcnt(N)`, stores counted as the hardware counts them -- before the wave passes the barrier that hands the block to
+    the other waves: per DMA instruction the number of barriers it may cross in flight, against a bound per kernel (0 for the
+    2-slot rings and the double-buffered tiles: DMA_PUBLISH_BARRIERS lists the others and why).  This is the rule that checks the
+    ring waits which leave a wave's own stores in flight (vmcnt(8) instead of vmcnt(0): savad_kernels_bf16.h, Ring::acquire).
 
     python scripts/check_async_loads.py             # compiles csrc/savad.hip to assembly (cached by source hash) and checks it
     python scripts/check_async_loads.py --asm f.s   # checks an assembly file
@@ -322,6 +327,107 @@ def check_dma_after_access(blocks):
     return sorted(hazards.values())
 
 
+def dma_barriers_in_flight(blocks, count_stores: bool = True, cap: int = 6):
+    """LDS-DMA PUBLISH rule.  A wave publishes its share of an LDS block to the other waves by waiting for its own DMA pieces
+    (`s_waitcnt vmcnt(N)`, N = the vector-memory operations it issued after them: they retire in order) and then meeting the others
+    at an `s_barrier`.  -> {line of a DMA instruction: the largest number of barriers the wave passes, over all paths, while that DMA
+    may still be in flight}.  Data flow as in check_kernel, but per DMA a SET of (distance from the young end of the queue, barriers
+    passed) pairs -- one per family of paths; a pair that is no younger and has passed no more barriers than another is dropped --
+    because the two components must not be mixed across paths (a prologue DMA enters a loop young, and grows old inside it).
+    A sufficient vmcnt retires a pair; at a barrier every remaining pair counts one more; `cap` = reported as "never waited for".
+    A ring that runs DEPTH blocks ahead legitimately carries a DMA across DEPTH - 1 barriers; one more than that is a block
+    published before it has landed (the bound per kernel: DMA_PUBLISH_BARRIERS)."""
+    index = {label: k for k, (label, _) in enumerate(blocks)}
+    state_in = [None] * len(blocks)
+    state_in[0] = {}
+    work = [0]
+    worst = {}
+
+    def prune(pairs):
+        keep = []
+        for d, b in sorted(pairs, key=lambda t: (t[0], -t[1])):   # youngest first, then most barriers
+            if not any(kd <= d and kb >= b for kd, kb in keep):
+                keep.append((d, b))
+        return frozenset(keep)
+
+    def merge_into(k, st):
+        cur = state_in[k]
+        if cur is None:
+            state_in[k] = dict(st)
+            work.append(k)
+            return
+        changed = False
+        for key, pairs in st.items():
+            merged = prune(set(cur.get(key, ())) | set(pairs))
+            if merged != cur.get(key):
+                cur[key] = merged
+                changed = True
+        if changed:
+            work.append(k)
+
+    while work:
+        k = work.pop()
+        st = dict(state_in[k])
+        ended = False
+        for ins in blocks[k][1]:
+            if ins.vmcnt is not None:
+                st = {key: frozenset(p for p in pairs if p[0] < ins.vmcnt) for key, pairs in st.items()}
+                st = {key: pairs for key, pairs in st.items() if pairs}
+                continue
+            if ins.is_barrier:
+                nxt = {}
+                for key, pairs in st.items():
+                    worst[key] = max(worst.get(key, 0), max(b for _, b in pairs) + 1)
+                    moved = frozenset((d, b + 1) for d, b in pairs if b + 1 < cap)
+                    if moved:
+                        nxt[key] = moved
+                st = nxt
+            if ins.is_load or (count_stores and ins.is_store):
+                st = {key: prune({(d + 1, b) for d, b in pairs if d + 1 < 64}) for key, pairs in st.items()}
+                st = {key: pairs for key, pairs in st.items() if pairs}
+                if ins.is_dma:
+                    st[ins.line] = prune(set(st.get(ins.line, ())) | {(0, 0)})
+                    worst.setdefault(ins.line, 0)
+            if ins.kind == "jump":
+                if ins.target in index:
+                    merge_into(index[ins.target], st)
+                ended = True
+                break
+            if ins.kind == "cond" and ins.target in index:
+                merge_into(index[ins.target], st)
+            if ins.kind == "end":
+                ended = True
+                break
+        if not ended and k + 1 < len(blocks):
+            merge_into(k + 1, st)
+    return worst
+
+
+# symbol substring -> barriers a DMA may legitimately cross in flight (default 0: landed before the next barrier), and why
+_RUNTIME_WAITS = "the counted ring wait is picked at run time from the number of blocks still to come; the analysis cannot tie that to the loop's issue condition and sees paths that never wait"
+_LAST_PASS = "the tile loop's last pass requests nothing (`more` is false) and leaves through the hand-over barrier: the path 'requested, then left' is infeasible"
+DMA_PUBLISH_BARRIERS = {
+    "attention_pw_kernel_bf16": (99, "a generated instruction stream with a three-stage K / V pipeline; its waits and barriers are modelled instruction by instruction in scripts/gfx950_sim.py"),
+    "5savad20attention_row_kernelI": (1, _LAST_PASS),
+    "25attention_row_kernel_bf16ILb0ELi4E": (1, _LAST_PASS),
+    "25attention_row_kernel_bf16ILb1ELi4E": (1, _LAST_PASS),
+    "15row_kernel_bf16ILb0ELi8E": (2, "the 4-slot ring of the 8-wave variant runs three blocks ahead: a block's pieces cross the barriers of the two blocks in front of it"),
+    "15row_kernel_bf16ILb1ELi8E": (99, _RUNTIME_WAITS),
+    "21attention_kernel_bf16ILi8E": (99, _RUNTIME_WAITS),
+    "25attention_row_kernel_bf16ILb0ELi8E": (99, _RUNTIME_WAITS),
+    "25attention_row_kernel_bf16ILb1ELi8E": (99, _RUNTIME_WAITS),
+    "26packed_forward_kernel_bf16ILi4ELi4ELi4E": (99, _RUNTIME_WAITS),
+    "26packed_forward_kernel_bf16ILi8ELi4ELi0E": (99, _RUNTIME_WAITS),
+}
+
+
+def check_dma_publish(sym, blocks, count_stores=True):
+    allowed = max([v[0] for key, v in DMA_PUBLISH_BARRIERS.items() if key in sym] or [0])
+    text = {i.line: i.text for _, b in blocks for i in b}
+    return [(line, text[line], line, f"crosses {n} barrier(s) in flight (allowed for this kernel: {allowed}): published before it has landed")
+            for line, n in sorted(dma_barriers_in_flight(blocks, count_stores).items()) if n > allowed]
+
+
 def source_hash() -> str:
     h = hashlib.sha256()
     for f in sorted(CSRC.iterdir()):
@@ -370,6 +476,8 @@ def _check(kernel_iter, count_stores):
             hazards += check_kernel(blocks, domain="lgkm", all_loads=count_stores)[0]   # (library form: the compiler's own reads too)
         if any(i.is_dma for i in insns) and not any(key in sym for key in DMA_DISJOINT):
             hazards += check_kernel(blocks, domain="dma")[0]
+        if any(i.is_dma for i in insns):
+            hazards += check_dma_publish(sym, blocks)
         if hazards or any((i.is_load and i.in_asm) or (i.is_dsread and i.in_asm) for i in insns):
             report[sym] = (sorted(hazards), False)
     return report

@@ -191,3 +191,23 @@ def test_deliberately_broken_builds_fail_the_check(fault_asm):
     assert any(h[1].startswith("global_load_lds") for h in row)                              # a ring slot re-targeted without the barrier
     packed = by("26packed_forward_kernel_bf16ILi4ELi2ELi0E")
     assert any(h[1].startswith("v_mfma") and h[3].startswith("ds_read_b128") for h in packed) and any(h[1].startswith("global_load_lds") for h in packed)
+
+
+def test_a_ring_wait_that_counts_one_store_too_many_is_reported(tmp_path_factory):
+    """NEGATIVE test of the publication rule on the real sources (bit 8 of SAVAD_FAULT_INJECT, on its own: bit 4 removes the very
+    barriers the rule counts at): the ring waits in front of the bf16 row launch's Q / K / V steps leave the wave's eight stores in
+    flight -- vmcnt(8).  With vmcnt(9) the newest DMA piece of the block being waited for may still be in flight when the wave
+    meets the others at the barrier; the product build has no such DMA (test_no_kernel_of_the_built_library_...)."""
+    import subprocess
+
+    from voice_activity_detection_amd.build import hipcc
+
+    out = tmp_path_factory.mktemp("fault8") / "fault8.s"
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "--cuda-device-only", "-S", "-DSAVAD_FAULT_INJECT=8",
+                    str(REPO / "voice_activity_detection_amd" / "csrc" / "savad.hip"), "-o", str(out)], check=True)
+    report = _checker().check_file(out)
+    row = [h for sym, (hz, _) in report.items() if "15row_kernel_bf16ILb0ELi4E" in sym for h in hz]
+    assert row and all(h[1].startswith("global_load_lds") and "published before it has landed" in h[3] for h in row)
+    # ... and no other kernel's publication moved (register hazards are not looked at here: this form of the check ignores stores in
+    # the queue, the stricter reading, which the persistent input stage's vmcnt(24) does not pass by design -- the library form does)
+    assert not [sym for sym, (hz, _) in report.items() if "15row_kernel_bf16ILb0ELi4E" not in sym and any("published before" in h[3] for h in hz)]

@@ -367,7 +367,8 @@ __device__ long long g_savad_dbg[64];
 // Fault injection for the NEGATIVE tests of the hazard checkers (tests/test_async_load_hazards.py, tests/test_gpu_cache_pressure.py;
 // never defined in the product build): bit 1 = the single-launch fp32 forward uses layer 0's query block without waiting
 // for it (requested one LayerNorm earlier: an L2 hit usually makes it, a miss does not), bit 2 = the bf16
-// ring GEMMs wait for one LDS fragment too few, bit 4 = the bf16 weight ring skips its workgroup barrier.
+// ring GEMMs wait for one LDS fragment too few, bit 4 = the bf16 weight ring skips its workgroup barrier, bit 8 = the ring waits that
+// leave a wave's own stores in flight allow one operation too many (the newest DMA piece may not have landed at the barrier).
 #ifndef SAVAD_FAULT_INJECT
 #define SAVAD_FAULT_INJECT 0
 #endif

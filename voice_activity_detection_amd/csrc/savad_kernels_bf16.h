@@ -209,7 +209,7 @@ struct Ring {
         else if (DEPTH >= 2 && newer == 1)
             __builtin_amdgcn_s_waitcnt(vmcnt_imm(PER));
         else if (SAVAD_STORES_IN_FLIGHT && DEPTH == 1 && stores_after == 8)
-            __builtin_amdgcn_s_waitcnt(vmcnt_imm(8));
+            __builtin_amdgcn_s_waitcnt(vmcnt_imm((SAVAD_FAULT_INJECT & 8) ? 9 : 8));
         else
             __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         asm volatile("" ::: "memory");
@@ -793,7 +793,10 @@ struct RowArgsBf16 {
 // by other waves when this is entered (the first ring barrier inside publishes ring block 0 and the biases).
 // live (wave-uniform) = this wave's block exists: a wave without a block still issues its share of the DMA and takes
 // part in every barrier, but stores nothing.
-template <bool LAST, int NW, class R = Ring<NW>>
+// ALWAYS_LIVE: `live` is the constant true (the row launch: every wave has a block) -- only then do the ring waits of the Q / K / V
+// steps leave the wave's stores in flight: with a run-time `live` the stores and the wait's count sit behind two branches on the
+// same flag, which no static check can tie together (scripts/check_async_loads.py, the publication rule).
+template <bool LAST, int NW, class R = Ring<NW>, bool ALWAYS_LIVE = false>
 __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem, bf16x8 (&xp)[8], int blk, bool live, int lane, int w) {
     float* lbo = reinterpret_cast<float*>(smem + R::NRING * RING_BYTES);
     float* lb1 = lbo + D;
@@ -867,7 +870,7 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
         pack_row(xg, xp);
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
-            advance(9 + rb, live ? 8 : 0);   // the residual block's / the previous Q / K block's eight stores are younger than the DMA waited for
+            advance(9 + rb, ALWAYS_LIVE ? 8 : 0);   // the residual block's / the previous Q / K block's eight stores are younger than the DMA waited for
             qkv_block_bf16(rb, ring.slot(9 + rb), xp, lbn, A.qf, A.kf, A.vtf, blk, lane, A.qscale, live);
         }
     } else {
@@ -904,7 +907,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void row_kernel_bf16(cons
         xp[ks] = ldfrag(ctxf + ((size_t)blk * 8 + ks) * FRAG_BYTES + lane * 16);
         if (blk >= A.nblk) xp[ks] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});  // pad blocks: attention never wrote them
     }
-    row_stage_bf16<LAST, NW>(A, smem, xp, blk, true, lane, w);
+    row_stage_bf16<LAST, NW, Ring<NW>, true>(A, smem, xp, blk, true, lane, w);
 }
 
 // ---------------------------------------------------------------------------------------------
