@@ -229,6 +229,9 @@ struct Ring {
 #ifndef SAVAD_RING_PIPE
 #define SAVAD_RING_PIPE 6
 #endif
+#ifndef SAVAD_RING_INTERLEAVE
+#define SAVAD_RING_INTERLEAVE 1   // 0: block after block (A/B builds; [256,800,80] last row launch 77.6 -> 76.4 us, [65536,7,80] 0.648 -> 0.642 ms with 1)
+#endif
 template <bool SWAP>
 __device__ __forceinline__ void gemm_ring_t(f32x16 (&acc)[4], const char* ringblk, const bf16x8 (&xp)[8], int lane) {
 #if SAVAD_RING_PIPE > 0
@@ -236,13 +239,23 @@ __device__ __forceinline__ void gemm_ring_t(f32x16 (&acc)[4], const char* ringbl
     const unsigned a = (unsigned)(size_t)ringblk + (unsigned)lane * 16u;  // LDS byte address (low half of the flat address)
     u32x4 f[P];
     // (macros, not a compile-time loop over a generic lambda: clang rejects asm operands that name captured variables there)
-#define SAVAD_RING_LOAD(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[(i) % P]) : "v"(a), "n"((i) * FRAG_BYTES))
+    // step i works on output block NB(i) and K-step KS(i).  SAVAD_RING_INTERLEAVE: the four accumulators take turns (every
+    // accumulator still sees its K-steps in order: the same bits), so that no MFMA waits for the one issued just before it
+#if SAVAD_RING_INTERLEAVE
+#define SAVAD_RING_NB(i) ((i) % 4)
+#define SAVAD_RING_KS(i) ((i) / 4)
+#else
+#define SAVAD_RING_NB(i) ((i) / 8)
+#define SAVAD_RING_KS(i) ((i) % 8)
+#endif
+#define SAVAD_RING_LOAD(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[(i) % P]) : "v"(a), "n"((SAVAD_RING_NB(i) * 8 + SAVAD_RING_KS(i)) * FRAG_BYTES))
 #define SAVAD_RING_STEP(i)                                                                                              \
     {                                                                                                                   \
         constexpr int newer_ = (31 - (i) < P - 1 ? 31 - (i) : P - 1) + ((SAVAD_FAULT_INJECT & 2) ? 1 : 0); /* of this statement's reads */ \
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[(i) % P]) : "n"(newer_));                                         \
         const bf16x8 w_ = __builtin_bit_cast(bf16x8, f[(i) % P]);                                                       \
-        acc[(i) / 8] = SWAP ? SAVAD_MFMA_BF16(xp[(i) % 8], w_, acc[(i) / 8]) : SAVAD_MFMA_BF16(w_, xp[(i) % 8], acc[(i) / 8]); \
+        acc[SAVAD_RING_NB(i)] = SWAP ? SAVAD_MFMA_BF16(xp[SAVAD_RING_KS(i)], w_, acc[SAVAD_RING_NB(i)])                 \
+                                     : SAVAD_MFMA_BF16(w_, xp[SAVAD_RING_KS(i)], acc[SAVAD_RING_NB(i)]);                \
         if constexpr ((i) + P < 32) SAVAD_RING_LOAD((i) + P);                                                           \
     }
 #define SAVAD_RING_STEP4(i) SAVAD_RING_STEP(i) SAVAD_RING_STEP((i) + 1) SAVAD_RING_STEP((i) + 2) SAVAD_RING_STEP((i) + 3)
@@ -260,6 +273,8 @@ __device__ __forceinline__ void gemm_ring_t(f32x16 (&acc)[4], const char* ringbl
 #undef SAVAD_RING_STEP4
 #undef SAVAD_RING_STEP
 #undef SAVAD_RING_LOAD
+#undef SAVAD_RING_NB
+#undef SAVAD_RING_KS
 #else
 #pragma unroll
     for (int nbl = 0; nbl < 4; ++nbl)
