@@ -140,6 +140,16 @@ int savad_set_attention_splits(savad_handle h, int splits);
  *        through a 4-slot ring / 4 waves with a 2-slot ring / ONE block per workgroup, its four waves splitting every GEMM's
  *        output features: the latency variant, picked up to one block per CU) */
 int savad_set_row_mode(savad_handle h, int mode);
+/* bf16 operands: results that do not depend on the batch a sequence is evaluated in (0 = off, the default; 1 = on).  Every bf16 launch
+ * schedule computes a frame with the same arithmetic, bit for bit -- with one exception: the persistent attention kernel that automatic
+ * picks for large batches of long sequences sums the keys of a sequence's tail group of one or two query blocks as four partial
+ * softmaxes (row_mode 5 above), so the same window can differ in the bf16 rounding of the context (<= 3e-3 in the log-probs) between a
+ * 256-sequence batch and a 100-sequence remainder.  On: that kernel runs its tail groups as ordinary items (a second generated
+ * instruction stream, csrc/savad_attn_pw_bf16_nosplit.inc) and every schedule -- hence every batching, chunk size and shard size --
+ * gives the same bits, at about 9 % of that launch (3 - 4 % of a [256,800,80] forward).  fp32 operands: no effect (there a sequence's
+ * result depends on its batch only through the automatic key-split count, <= 2e-6; savad_set_attention_splits(h, 1) pins that).
+ * The reference itself (BLAS blocking) is not batch-invariant at the bit level. */
+int savad_set_batch_invariant(savad_handle h, int on);
 /* Per-kernel timing (bench.py's roofline block).  savad_set_profiling(h, capacity): the next `capacity` calls of
  * savad_forward bracket every launch with hipEvents on `stream` (capacity 0 switches profiling off and frees the
  * events); savad_profiling_skip(h, n): the next n forwards run un-recorded first (event creation idles the GPU for

@@ -822,6 +822,41 @@ def pw_key_split_rows(T):
     return 256 * (QB // 8) if QB % 8 in (1, 2) else T
 
 
+@pytest.mark.parametrize("shape", [(3, 800, 80), (4, 801, 80), (19, 290, 80), (2, 264, 80), (5, 833, 80), (9, 1000, 80), (3, 65, 80), (70, 800, 80)])
+def test_bf16_batch_invariant_mode_gives_every_schedule_the_same_bits(torch_cuda, model, shape):
+    """model.batch_invariant (savad_set_batch_invariant): the persistent attention kernel runs a second generated stream whose tail
+    groups are ORDINARY items (csrc/savad_attn_pw_bf16_nosplit.inc) -- attention_kernel_bf16's arithmetic for every frame -- so
+    row_mode 5 (that kernel, forced) carries the bits of row_mode 1 on ALL rows, tail groups of one and two query blocks included;
+    with the flag off the key-split rows may differ by the bf16 rounding of their context, which is what the flag is for."""
+    torch = torch_cuda
+    x = feats(sum(shape) + 3, shape)
+    want = _run_bf16_mode(torch, model, x, 1)
+    off = _run_bf16_mode(torch, model, x, 5)
+    model.batch_invariant = True
+    try:
+        on5 = _run_bf16_mode(torch, model, x, 5)
+        on0 = _run_bf16_mode(torch, model, x, 0)
+    finally:
+        model.batch_invariant = False
+    assert np.isfinite(on5).all() and np.array_equal(on5, want) and np.array_equal(on0, want)
+    assert np.abs(off - want).max() < 3e-3   # (off: the key-split rows may differ by the bf16 rounding of their context)
+
+
+def test_bf16_batch_invariant_mode_across_batchings(torch_cuda, model):
+    """the use case: 200 sequences of 800 frames in one batch (automatic picks the persistent attention kernel) against the same
+    sequences in chunks of 48 and 8 (fused launches, the first-generation attention arithmetic): the same bits with the flag on."""
+    torch = torch_cuda
+    x = feats(77, (200, 800, 80))
+    model.batch_invariant = True
+    try:
+        whole = run_bf16(torch, model, x)
+        parts = np.concatenate([run_bf16(torch, model, x[i:i + 48]) for i in range(0, 192, 48)] + [run_bf16(torch, model, x[192:])])
+    finally:
+        model.batch_invariant = False
+    assert np.array_equal(whole, parts)
+    assert np.abs(run_bf16(torch, model, x) - whole).max() < 3e-3   # off: the key-split rows of the big batch may differ by that much
+
+
 @pytest.mark.parametrize("shape", PW_SHAPES)
 def test_bf16_persistent_attention_one_layer(torch_cuda, shape):
     """row_mode 5: the attention stage as ONE persistent launch of 4 x 64-row workgroups (savad_attn_pw_bf16.h, instruction

@@ -58,3 +58,23 @@ def test_packed_row_sum_variant_on_the_functional_model(tmp_path, B, T, grid, sc
     base = pw_sim.simulate(B, T, grid=grid, scale=scale, seed=B + T, nan_pad=nan_pad, strict=True)
     assert np.abs(r["ctx"] - base["ctx"]).max() < 4e-3          # one bf16 ulp of a context value at most: only the summation order moved
     assert sum(sum(s["instr"]) for s in r["stats"]) < sum(sum(s["instr"]) for s in base["stats"])
+
+
+@pytest.mark.parametrize("B,T,grid,scale,nan_pad", [CASES[0], CASES[1], CASES[4]])
+def test_no_split_stream_on_the_functional_model(B, T, grid, scale, nan_pad):
+    """csrc/savad_attn_pw_bf16_nosplit.inc (savad_set_batch_invariant: every tail group an ORDINARY item, no key-split combine): the same
+    checks, no key-split item ever entered, and -- outside the tail rows, whose summation order is the point of the variant -- the
+    product stream's bits."""
+    import pw_sim
+
+    text = (Path(__file__).resolve().parent.parent / "voice_activity_detection_amd" / "csrc" / "savad_attn_pw_bf16_nosplit.inc").read_text()
+    r = pw_sim.simulate(B, T, grid=grid, scale=scale, seed=B + T, nan_pad=nan_pad, strict=True, inc_text=text)
+    assert r["finite"] and r["pad_zero"]
+    assert np.abs(r["ctx"] - r["ref"]).max() < 0.03
+    assert not any("_ks" in k for s in r["stats"] for k in s["labels"])
+    base = pw_sim.simulate(B, T, grid=grid, scale=scale, seed=B + T, nan_pad=nan_pad, strict=True)
+    full = 256 * (((T + 31) // 32) // 8)          # frames of a sequence that full groups cover
+    if full:
+        a, b = r["ctx"].reshape(B, -1, r["ctx"].shape[-1]), base["ctx"].reshape(B, -1, base["ctx"].shape[-1])
+        assert np.array_equal(a[:, :full], b[:, :full])
+    assert np.abs(r["ctx"] - base["ctx"]).max() <= 2.0 ** -7 * np.abs(base["ctx"]).max()   # the tail rows: the bf16 rounding of the context's range

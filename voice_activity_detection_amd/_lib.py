@@ -37,6 +37,7 @@ SYMBOLS = {
     "savad_forward_strided": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "savad_set_attention_splits": (c_int, [c_void_p, c_int]),
     "savad_set_row_mode": (c_int, [c_void_p, c_int]),
+    "savad_set_batch_invariant": (c_int, [c_void_p, c_int]),
     "savad_set_profiling": (c_int, [c_void_p, c_int]),
     "savad_profiling_skip": (c_int, [c_void_p, c_int]),
     "savad_last_kernel_times": (c_int, [c_void_p, POINTER(c_char_p), POINTER(c_float), c_int]),

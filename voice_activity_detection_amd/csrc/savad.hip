@@ -69,6 +69,7 @@ struct savad_model {
     std::vector<float> h_pe;
     int splits = 0;
     int row_mode = 0;  // 0 auto, 1 N-split (32-row tiles), 2 M-split (128-row tiles)
+    bool batch_invariant = false;   // bf16: the persistent attention kernel without key-split tail items (savad_set_batch_invariant)
     int precision = 0;  // 0 = fp32 MFMA, 1 = bf16 MFMA operands (fp32 accumulate / statistics / residual stream)
     unsigned* d_sat = nullptr;  // bf16 path: elements of the fp16-stored residual stream that saturated since the last query
     char* d_frag = nullptr;  // bf16 weight fragments (savad_kernels_bf16.h), filled when precision == 1
@@ -706,6 +707,12 @@ SAVAD_EXPORT int savad_set_row_mode(savad_handle m, int mode) {
     return SAVAD_OK;
 }
 
+SAVAD_EXPORT int savad_set_batch_invariant(savad_handle m, int on) {
+    if (!m || on < 0 || on > 1) return fail(SAVAD_E_INVALID, "batch_invariant %d (0 or 1)", on);
+    m->batch_invariant = on != 0;
+    return SAVAD_OK;
+}
+
 SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* bytes) {
     if (!m || !bytes || B < 0 || T < 0) return fail(SAVAD_E_INVALID, "bad argument");
     if ((double)B * T * D >= 2.0e9) return fail(SAVAD_E_UNSUPPORTED, "B*T=%ld rows exceed the 32-bit tile index range", (long)B * T);
@@ -798,6 +805,7 @@ int prepare_bf16_launch(savad_model* m) {
     if ((rc = allow_lds(bf::row_kernel_bf16<false, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::row_kernel_bf16<true, 8>, r8 + 9 * D * 4))) return rc;
     if ((rc = allow_lds(bf::attention_pw_kernel_bf16, bf::PW_LDS_BYTES))) return rc;
+    if ((rc = allow_lds(bf::attention_pw_kernel_bf16_nosplit, bf::PW_LDS_BYTES))) return rc;
     if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 2, 0>, r4 + (bf::PACKED_BF16_MAX_LAYERS * LBIAS + 2 * D + 4) * 4))) return rc;
     if ((rc = allow_lds(bf::packed_forward_kernel_bf16<4, 4, 4>, r8 + (bf::PACKED_BF16_MAX_LAYERS * LBIAS + 2 * D + 4) * 4))) return rc;
     if ((rc = allow_lds(bf::packed_forward_kernel_bf16<8, 4, 0>, r8 + (bf::PACKED_BF16_MAX_LAYERS * LBIAS + 2 * D + 4) * 4))) return rc;
@@ -912,14 +920,15 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     // with a stride of 32 per XCD, a sequence's tail group attached to one of them; a key-split tail costs 0.55 of a full item) times
     // 0.62 us per key block + 7 us per item, + 5 us per launch.  First generation: 0.54 ns per (query block x key block) + 2.5 ns per
     // query block, per sequence.  The persistent kernel is picked unless the model has it more than 5 % behind.
-    auto pw_pays = [](int Bq, int Tq) {
+    const bool ks_tail = !m->batch_invariant;   // key-split tail items (0.55 of a full item) or ordinary ones (a full item's time)
+    auto pw_pays = [ks_tail](int Bq, int Tq) {
         const int QBq = (Tq + 31) / 32, NGFq = QBq >> 3, TQq = QBq & 7;
         if (NGFq == 0) return false;
         const int wg = bf::PW_GRID / 8;
         auto ff1 = [](int x) { return __builtin_ctz((unsigned)x); };
         const int t0 = ff1(NGFq) < ff1(wg) ? ff1(NGFq) : ff1(wg), sh = ff1(wg) - t0, mask = (1 << t0) - 1;
         const int S = (Bq + 7) / 8;  // sequences of the fullest XCD
-        const double ctail = TQq == 0 ? 0.0 : (TQq <= 2 ? 0.55 : 1.0);
+        const double ctail = TQq == 0 ? 0.0 : (TQq <= 2 && ks_tail ? 0.55 : 1.0);
         double busiest = 0.0;
         for (int j = 0; j < wg; ++j) {
             double n = 0.0;
@@ -1006,7 +1015,10 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
                 hipLaunchKernelGGL(bf::attention_packed_kernel_bf16, dim3((bp.nblk + 3) / 4), dim3(256), 0, st, qf, kf, vtf, ctxf,
                                    B, T, bp.nblk);
             } else if (m->row_mode == 5 || (automatic_bf16 && pw_pays(B, T))) {  // persistent 4 x 64-row attention (savad_attn_pw_bf16.h)
-                hipLaunchKernelGGL(bf::attention_pw_kernel_bf16, dim3(bf::PW_GRID), dim3(256), bf::PW_LDS_BYTES, st, qf, kf, vtf, ctxf, B, T);
+                if (m->batch_invariant)
+                    hipLaunchKernelGGL(bf::attention_pw_kernel_bf16_nosplit, dim3(bf::PW_GRID), dim3(256), bf::PW_LDS_BYTES, st, qf, kf, vtf, ctxf, B, T);
+                else
+                    hipLaunchKernelGGL(bf::attention_pw_kernel_bf16, dim3(bf::PW_GRID), dim3(256), bf::PW_LDS_BYTES, st, qf, kf, vtf, ctxf, B, T);
             } else {
                 const int QB = (T + 31) / 32, NG = (QB + NW - 1) / NW;
                 hipLaunchKernelGGL((bf::attention_kernel_bf16<NW>), dim3(8 * (((long)B * NG + 7) / 8)), wg, ring, st, qf, kf, vtf, ctxf, B,

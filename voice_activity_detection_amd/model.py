@@ -80,7 +80,7 @@ class SelfAttentiveVAD(nn.Module):
         self._synced_versions = None
         self._workspace: Optional[Tensor] = None
         self._param_dicts = None      # the `_parameters` dicts of the leaf modules, collected once (the module tree is fixed)
-        self._pushed_knobs = None     # (attention_splits, row_mode, precision) the handle was last told
+        self._pushed_knobs = None     # (attention_splits, row_mode, precision, batch_invariant) the handle was last told
         self._ws_bytes = {}           # (B, T, knobs) -> savad_workspace_bytes
         # bumped whenever the caller declares the weights changed behind autograd's back (sync_weights(force=True), a mode switch):
         # PipelinedVAD's replicas share the parameters but keep their own handles, and re-push when they see a new generation
@@ -92,6 +92,9 @@ class SelfAttentiveVAD(nn.Module):
         # "fp32": exact-fp32 MFMA (default, log-probs within 1e-4 of the reference).
         # "bf16": bf16 MFMA operands, fp32 accumulation / statistics, fp16-stored residual stream (BASELINE configs[2..3]).
         self.precision = "fp32"
+        # bf16 only: the same bits for a sequence whatever batch it is evaluated in (chunk sizes, shard sizes, remainders), at 3 - 4 % of a
+        # large-batch forward: the persistent attention kernel then runs without its key-split tail items (include/savad.h)
+        self.batch_invariant = False
 
     # ---- library handle / weights -----------------------------------------------------------
     def _ensure_handle(self, device: torch.device):
@@ -249,11 +252,12 @@ class SelfAttentiveVAD(nn.Module):
         lib = _lib.load()
         self._ensure_handle(device)
         self.sync_weights()
-        knobs = (int(self.attention_splits), int(self.row_mode), self.precision)
-        if knobs != self._pushed_knobs:   # three library calls only when a knob moved, none on the steady path
+        knobs = (int(self.attention_splits), int(self.row_mode), self.precision, bool(getattr(self, "batch_invariant", False)))
+        if knobs != self._pushed_knobs:   # four library calls only when a knob moved, none on the steady path
             _lib.check(lib.savad_set_attention_splits(self._handle, knobs[0]))
             _lib.check(lib.savad_set_row_mode(self._handle, knobs[1]))
             _lib.check(lib.savad_set_precision(self._handle, 1 if knobs[2] == "bf16" else 0))
+            _lib.check(lib.savad_set_batch_invariant(self._handle, int(knobs[3])))
             self._pushed_knobs = knobs
         return lib
 

@@ -20,7 +20,7 @@ from torch import Tensor
 
 from .model import SelfAttentiveVAD
 
-_KNOBS = ("precision", "row_mode", "attention_splits", "training")
+_KNOBS = ("precision", "row_mode", "attention_splits", "batch_invariant", "training")
 
 
 class PipelinedVAD:

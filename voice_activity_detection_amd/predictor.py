@@ -272,7 +272,10 @@ class StreamingPredictor:
     def __init__(self, model: SelfAttentiveVAD, device, T: int = 800, hop: int = 400, max_batch: int = 256, in_flight: int = 2):
         self.model, self.device, self.T, self.hop, self.max_batch = model, torch.device(device), int(T), int(hop), int(max_batch)
         # the window batches are independent: `in_flight` of them run concurrently (PipelinedVAD: own stream / handle / workspace
-        # each, same bits); 1 = one after the other on the caller's stream
+        # each, same bits); 1 = one after the other on the caller's stream.
+        # bf16 operands: a full batch of max_batch windows and a smaller remainder (or a rank's smaller shard) may run different attention
+        # kernels, whose results differ in the bf16 rounding of a few rows' context (<= 3e-3 in the log-probs); set
+        # model.batch_invariant = True where the same window must give the same bits in every batching (+4 % of a large forward)
         self.in_flight = int(in_flight)
         self._pipe = None
 
