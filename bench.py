@@ -967,8 +967,8 @@ def main():
             w, e = r.timed_blocks(k2, 5, args.min_seconds)
             s = summarize(w, e, k2, world * b2 * t2)
             s1 = s
-            if r.sp.in_flight > 1:   # and one forward at a time
-                tuned = r.sp.in_flight
+            tuned = r.sp.in_flight
+            if tuned > 1:   # and one forward at a time
                 r.drain()
                 r.sp.set_in_flight(1)
                 w1, e1 = r.timed_blocks(k2, 2, args.min_seconds / 2)
@@ -976,6 +976,19 @@ def main():
                 r.drain()
                 r.sp.set_in_flight(tuned)
             kt = [] if args.no_events else r.kernel_profile(10, s1["ms_per_step"])
+            if prec == "bf16" and t2 > 32 and not stub and r.model is not None:
+                # the price of model.batch_invariant (savad_set_batch_invariant: the persistent attention kernel without key-split tail
+                # items, every batching the same bits), one forward at a time, same run
+                try:
+                    r.drain()
+                    r.sp.set_in_flight(1)
+                    r.model.batch_invariant = True
+                    wi, ei = r.timed_blocks(k2, 2, args.min_seconds / 2)
+                    s["batch_invariant_ms_per_step_one_in_flight"] = summarize(wi, ei, k2, world * b2 * t2)["ms_per_step"]
+                finally:
+                    r.drain()
+                    r.model.batch_invariant = False
+                    r.sp.set_in_flight(tuned)
             s.update({"workload": workload_label(prec, b2, t2), "global_batch": world * b2, "unit": "frames/s",
                       "in_flight": r.sp.in_flight, "in_flight_tuning_ms": r.tuning,
                       "ms_per_step_one_in_flight": s1["ms_per_step"], "value_one_in_flight": s1["value"],
