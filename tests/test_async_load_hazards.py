@@ -208,6 +208,4 @@ def test_a_ring_wait_that_counts_one_store_too_many_is_reported(tmp_path_factory
     report = _checker().check_file(out)
     row = [h for sym, (hz, _) in report.items() if "15row_kernel_bf16ILb0ELi4E" in sym for h in hz]
     assert row and all(h[1].startswith("global_load_lds") and "published before it has landed" in h[3] for h in row)
-    # ... and no other kernel's publication moved (register hazards are not looked at here: this form of the check ignores stores in
-    # the queue, the stricter reading, which the persistent input stage's vmcnt(24) does not pass by design -- the library form does)
-    assert not [sym for sym, (hz, _) in report.items() if "15row_kernel_bf16ILb0ELi4E" not in sym and any("published before" in h[3] for h in hz)]
+    assert not [sym for sym, (hz, _) in report.items() if hz and "15row_kernel_bf16ILb0ELi4E" not in sym]   # ... and nothing else moved
