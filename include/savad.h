@@ -94,7 +94,10 @@ int savad_forward(savad_handle h, const float* x, int B, int T, float* out, void
 /* Arithmetic of the forward pass: 0 = fp32 operands on the exact-fp32 MFMA (default; log-probs within
  * 1e-4 of the reference), 1 = bf16 operands (weights, Q/K/V, probabilities, FFN activations) with fp32
  * accumulation, fp32 softmax / LayerNorm statistics, residual stream fp32 in registers / fp16 in memory (BASELINE.json
- * configs[2..3]; judged on AUC, not on 1e-4). */
+ * configs[2..3]; judged on AUC, not on 1e-4), 2 = "fp32s": the fp32 arithmetic of vad/modeling/transformer.py:281-284,
+ * 347,351-363,370-375 on the bf16 matrix pipe -- every GEMM operand kept as three bf16 pieces (hi + mid + lo = the fp32 value,
+ * exactly), six bf16 MFMA products per K-step into one fp32 accumulator, everything else fp32 (softmax, LayerNorm, residual
+ * stream): the same 1e-4 bar as precision 0, at 6/16 of its matrix time (gfx950 has no TF32; csrc/savad_kernels_f32s.h). */
 int savad_set_precision(savad_handle h, int precision);
 /* bf16 precision only: the residual stream lives in HBM as fp16 between kernels and saturates at +-65504 where the
  * reference's fp32 stream (vad/modeling/transformer.py:234-238) would not.  Saturation is counted, not silent: this

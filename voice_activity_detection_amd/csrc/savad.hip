@@ -5,6 +5,7 @@
 #include "savad_kernels_bf16.h"
 #include "savad_attn_pw_bf16.h"
 #include "savad_packed_bf16.h"
+#include "savad_kernels_f32s.h"
 #include "savad_generic.h"
 #include <type_traits>
 #include "savad_logmel.h"
@@ -70,7 +71,13 @@ struct savad_model {
     int splits = 0;
     int row_mode = 0;  // 0 auto, 1 N-split (32-row tiles), 2 M-split (128-row tiles)
     bool batch_invariant = false;   // bf16: the persistent attention kernel without key-split tail items (savad_set_batch_invariant)
-    int precision = 0;  // 0 = fp32 MFMA, 1 = bf16 MFMA operands (fp32 accumulate / statistics / residual stream)
+    int precision = 0;  // 0 = fp32 MFMA, 1 = bf16 MFMA operands (fp32 accumulate / statistics / residual stream),
+                        // 2 = "fp32s": fp32 parity on the bf16 pipe, every operand as three bf16 pieces (savad_kernels_f32s.h)
+    char* d_frag3 = nullptr;  // fp32s weight triples (savad_kernels_f32s.h), filled when precision == 2
+    size_t frag3_bytes = 0;
+    bool frag3_dirty = true;
+    bool lds_attrs3_set = false;
+    size_t f3_win = 0;
     unsigned* d_sat = nullptr;  // bf16 path: elements of the fp16-stored residual stream that saturated since the last query
     char* d_frag = nullptr;  // bf16 weight fragments (savad_kernels_bf16.h), filled when precision == 1
     size_t frag_bytes = 0;
@@ -83,6 +90,7 @@ struct savad_model {
         size_t wqkv, wo, w1, w2;
     };
     std::vector<LayerFrag> lf;
+    std::vector<LayerFrag> lf3;  // byte offsets into d_frag3
     // profiling
     int prof_capacity = 0, prof_used = 0, prof_nk = 0, prof_skip = 0;
     std::vector<hipEvent_t> events;  // prof_capacity * MAX_EVENTS
@@ -368,6 +376,57 @@ BlockPlan plan_blocks(const savad_model* m, int B, int T) {
     return p;
 }
 
+// block space of the fp32s path (savad_kernels_f32s.h): fp32 residual blocks, Q / K / V^T as triples, double-buffered between
+// layers (the fused launch of layer l writes layer l + 1's Q / K / V^T while other workgroups still read layer l's)
+struct BlockPlan3 {
+    int nblk, nblk_pad;
+    size_t h, q, k, vt, q2, k2, vt2, xpad, total;  // byte offsets
+};
+BlockPlan3 plan_blocks3(const savad_model* m, int B, int T) {
+    BlockPlan3 p;
+    if (T > 32)
+        p.nblk = B * ((T + 31) / 32);
+    else
+        p.nblk = (B + (32 / T) - 1) / (32 / T);
+    p.nblk_pad = (p.nblk + 3) / 4 * 4;
+    size_t off = 0;
+    p.h = off;
+    off += (size_t)p.nblk_pad * fs::HBLK_BYTES;
+    const size_t fb = (size_t)p.nblk_pad * fs::BLK3_BYTES;
+    size_t* slots[6] = {&p.q, &p.k, &p.vt, &p.q2, &p.k2, &p.vt2};
+    for (size_t* s : slots) {
+        *s = off;
+        off += fb;
+    }
+    p.xpad = off;
+    if (m->FP != m->cfg.feature_size) off += (size_t)B * T * m->FP * sizeof(float);
+    p.total = off;
+    return p;
+}
+
+int pack_frags3(savad_model* m, hipStream_t st, const float* W, int N, int K, size_t off) {
+    const size_t total = (size_t)N * K;
+    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(fs::pack_weight_frags3_kernel, dim3(grid), dim3(256), 0, st, W, N, K, reinterpret_cast<__bf16*>(m->d_frag3 + off));
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
+int prepare_frags3(savad_model* m, hipStream_t st) {
+    if (!m->frag3_dirty) return SAVAD_OK;
+    const int L = m->cfg.num_layers;
+    int rc;
+    if ((rc = pack_frags3(m, st, win_fp32(m), D, m->FP, m->f3_win))) return rc;
+    for (int l = 0; l < L; ++l) {
+        if ((rc = pack_frags3(m, st, m->d_packed + m->lp[l].wqkv, 3 * D, D, m->lf3[l].wqkv))) return rc;
+        if ((rc = pack_frags3(m, st, m->d_raw + m->lr[l].wo, D, D, m->lf3[l].wo))) return rc;
+        if ((rc = pack_frags3(m, st, m->d_packed + m->lp[l].w1, DFF, D, m->lf3[l].w1))) return rc;
+        if ((rc = pack_frags3(m, st, m->d_raw + m->lr[l].w2, D, DFF, m->lf3[l].w2))) return rc;
+    }
+    m->frag3_dirty = false;
+    return SAVAD_OK;
+}
+
 template <typename KernelT>
 int allow_lds(KernelT kernel, int bytes) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -647,8 +706,23 @@ SAVAD_EXPORT int savad_create(const savad_config* cfg, savad_handle* out) {
         fl.w2 = m->frag_bytes;
         m->frag_bytes += (size_t)D * DFF * 2;
     }
+    m->lf3.resize(L);
+    m->f3_win = 0;
+    m->frag3_bytes = (size_t)D * ((F + 15) / 16 * 16) * 6;
+    for (int l = 0; l < L; ++l) {
+        auto& fl = m->lf3[l];
+        fl.wqkv = m->frag3_bytes;
+        m->frag3_bytes += (size_t)3 * D * D * 6;
+        fl.wo = m->frag3_bytes;
+        m->frag3_bytes += (size_t)D * D * 6;
+        fl.w1 = m->frag3_bytes;
+        m->frag3_bytes += (size_t)DFF * D * 6;
+        fl.w2 = m->frag3_bytes;
+        m->frag3_bytes += (size_t)D * DFF * 6;
+    }
     hipError_t e = hipMalloc(&m->d_raw, sizeof(float) * m->raw_floats);
     if (e == hipSuccess) e = hipMalloc(&m->d_frag, m->frag_bytes);
+    if (e == hipSuccess) e = hipMalloc(&m->d_frag3, m->frag3_bytes);
     if (e == hipSuccess) e = hipMalloc(&m->d_sat, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(m->d_sat, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc(&m->d_packed, sizeof(float) * m->packed_floats);
@@ -667,6 +741,7 @@ SAVAD_EXPORT void savad_destroy(savad_handle m) {
     if (m->d_raw) hipFree(m->d_raw);
     if (m->d_packed) hipFree(m->d_packed);
     if (m->d_frag) hipFree(m->d_frag);
+    if (m->d_frag3) hipFree(m->d_frag3);
     if (m->d_sat) hipFree(m->d_sat);
     if (m->d_pe) hipFree(m->d_pe);
     delete m;
@@ -690,6 +765,7 @@ SAVAD_EXPORT int savad_set_param(savad_handle m, const char* key, const float* d
         p.set = true;
         m->dirty = true;
         m->frag_dirty = true;
+        m->frag3_dirty = true;
         return SAVAD_OK;
     }
     return fail(SAVAD_E_NOKEY, "unexpected key '%s' in state_dict", key);
@@ -722,6 +798,8 @@ SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* byt
         *bytes = gen::plan(B, T, m->cfg.d_model, m->splits).total * sizeof(float);
     else if (m->precision == 1)
         *bytes = plan_blocks(m, B, T).total;
+    else if (m->precision == 2)
+        *bytes = plan_blocks3(m, B, T).total;
     else
         *bytes = plan(m, B, T).total * sizeof(float);
     return SAVAD_OK;
@@ -734,6 +812,7 @@ SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* byt
 // into a HIP graph.  With parameters still missing only the table is sized (the forward reports the missing key).
 namespace {
 int prepare_bf16_launch(savad_model* m);
+int prepare_f32s_launch(savad_model* m);
 }
 SAVAD_EXPORT int savad_reserve(savad_handle m, int T_max, void* stream) {
     if (!m || T_max < 0) return fail(SAVAD_E_INVALID, "bad argument");
@@ -749,6 +828,10 @@ SAVAD_EXPORT int savad_reserve(savad_handle m, int T_max, void* stream) {
     if (m->precision == 1) {
         if ((rc = prepare_frags(m, st))) return rc;
         if ((rc = prepare_bf16_launch(m))) return rc;
+    }
+    if (m->precision == 2) {
+        if ((rc = prepare_frags3(m, st))) return rc;
+        if ((rc = prepare_f32s_launch(m))) return rc;
     }
     return SAVAD_OK;
 }
@@ -771,9 +854,9 @@ SAVAD_EXPORT int savad_residual_saturations(savad_handle m, unsigned long long* 
 }
 
 SAVAD_EXPORT int savad_set_precision(savad_handle m, int precision) {
-    if (!m || precision < 0 || precision > 1) return fail(SAVAD_E_INVALID, "precision %d (0 = fp32, 1 = bf16)", precision);
-    if (m->generic && precision == 1)
-        return fail(SAVAD_E_UNSUPPORTED, "bf16 operands are implemented for d_model=128 only (this handle: d_model=%d, fp32)", m->cfg.d_model);
+    if (!m || precision < 0 || precision > 2) return fail(SAVAD_E_INVALID, "precision %d (0 = fp32, 1 = bf16, 2 = fp32s)", precision);
+    if (m->generic && precision != 0)
+        return fail(SAVAD_E_UNSUPPORTED, "bf16 / split-bf16 operands are implemented for d_model=128 only (this handle: d_model=%d, fp32)", m->cfg.d_model);
     m->precision = precision;
     return SAVAD_OK;
 }
@@ -1041,6 +1124,94 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
     return SAVAD_OK;
 }
 
+
+int prepare_f32s_launch(savad_model* m) {
+    int rc;
+    if (m->lds_attrs3_set) return SAVAD_OK;
+    if ((rc = allow_lds(fs::input_qkv_kernel_f32s, fs::NRING3 * fs::SLOT_BYTES + 3 * D * 4))) return rc;
+    if ((rc = allow_lds(fs::attention_row_kernel_f32s<false, false>, fs::ROW_LDS_BYTES))) return rc;
+    if ((rc = allow_lds(fs::attention_row_kernel_f32s<true, false>, fs::ROW_LDS_BYTES))) return rc;
+    if ((rc = allow_lds(fs::attention_row_kernel_f32s<false, true>, fs::ROW_LDS_BYTES))) return rc;
+    if ((rc = allow_lds(fs::attention_row_kernel_f32s<true, true>, fs::ROW_LDS_BYTES))) return rc;
+    m->lds_attrs3_set = true;
+    return SAVAD_OK;
+}
+
+// fp32s forward (precision 2): input_qkv -> [attention + row chain] x L, every GEMM as six bf16 MFMA products of three-piece operands
+int forward_f32s(savad_model* m, const float* x, int B, int T, float* out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const BlockPlan3 bp = plan_blocks3(m, B, T);
+    if (workspace_bytes < bp.total) return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, bp.total);
+    int rc;
+    if ((rc = prepare_weights(m, st))) return rc;
+    if ((rc = prepare_frags3(m, st))) return rc;
+    if ((rc = ensure_pe(m, T, st))) return rc;
+    if ((rc = prepare_f32s_launch(m))) return rc;
+    char* W = (char*)workspace;
+    float* hb = (float*)(W + bp.h);
+    const int L = m->cfg.num_layers;
+    int F = m->cfg.feature_size;
+    if (m->FP != F) {  // zero-pad the features to the kernels' K granularity
+        float* xp = (float*)(W + bp.xpad);
+        const size_t rows = (size_t)B * T;
+        const int grid = (int)((rows * m->FP + 255) / 256 < 4096 ? (rows * m->FP + 255) / 256 : 4096);
+        hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(grid), dim3(256), 0, st, x, rows, F, m->FP, xp);
+        x = xp;
+        F = m->FP;
+    }
+    const long xbs = m->xbs_override > 0 ? m->xbs_override : (long)T * F;
+    const float c = (float)(1.4426950408889634 / sqrt((double)D));
+    const float* R = m->d_raw;
+    const float* P = m->d_packed;
+    const char* Fr = m->d_frag3;
+    Prof prof(m, st);
+    char* sets[2][3] = {{W + bp.q, W + bp.k, W + bp.vt}, {W + bp.q2, W + bp.k2, W + bp.vt2}};
+    hipLaunchKernelGGL(fs::input_qkv_kernel_f32s, dim3(bp.nblk_pad / 4), dim3(256), fs::NRING3 * fs::SLOT_BYTES + 3 * D * 4, st, x, xbs, B, T, F,
+                       bp.nblk, Fr + m->f3_win, R + m->r_bin, m->d_pe, Fr + m->lf3[0].wqkv, P + m->lp[0].bqkv, hb, sets[0][0], sets[0][1],
+                       sets[0][2], c);
+    prof.mark("input_qkv_f32s");
+    const bool packed = T <= 32;
+    const int QB = (T + 31) / 32, NG = (QB + 3) / 4;
+    const dim3 grid(packed ? bp.nblk_pad / 4 : 8 * (((long)B * NG + 7) / 8));
+    for (int l = 0; l < L; ++l) {
+        const auto& r = m->lr[l];
+        const auto& p = m->lp[l];
+        const auto& f = m->lf3[l];
+        const bool last = l + 1 == L;
+        char** cur = sets[l & 1];
+        char** nxt = sets[(l + 1) & 1];
+        fs::RowArgs3 A;
+        A.B = B;
+        A.T = T;
+        A.nblk = bp.nblk;
+        A.hbuf = hb;
+        A.wo_frag = Fr + f.wo;
+        A.bo = R + r.bo;
+        A.w1_frag = Fr + f.w1;
+        A.b1 = P + p.b1;
+        A.w2_frag = Fr + f.w2;
+        A.b2 = R + r.b2;
+        A.wn_frag = last ? nullptr : Fr + m->lf3[l + 1].wqkv;
+        A.wc = last ? P + m->p_wc : nullptr;
+        A.bn = last ? P + m->p_bc : P + m->lp[l + 1].bqkv;
+        A.qf = nxt[0];
+        A.kf = nxt[1];
+        A.vtf = nxt[2];
+        A.out = out;
+        A.qscale = c;
+        if (packed) {
+            if (last) hipLaunchKernelGGL((fs::attention_row_kernel_f32s<true, true>), grid, dim3(256), fs::ROW_LDS_BYTES, st, cur[0], cur[1], cur[2], NG, A);
+            else hipLaunchKernelGGL((fs::attention_row_kernel_f32s<false, true>), grid, dim3(256), fs::ROW_LDS_BYTES, st, cur[0], cur[1], cur[2], NG, A);
+        } else {
+            if (last) hipLaunchKernelGGL((fs::attention_row_kernel_f32s<true, false>), grid, dim3(256), fs::ROW_LDS_BYTES, st, cur[0], cur[1], cur[2], NG, A);
+            else hipLaunchKernelGGL((fs::attention_row_kernel_f32s<false, false>), grid, dim3(256), fs::ROW_LDS_BYTES, st, cur[0], cur[1], cur[2], NG, A);
+        }
+        prof.mark(last ? "attention_row_last_f32s" : "attention_row_f32s");
+    }
+    prof.done();
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -1070,7 +1241,7 @@ void launch_packed_forward(savad_model* m, hipStream_t st, const float* x, int B
 SAVAD_EXPORT int savad_forward_ex(savad_handle m, const void* x, int x_dtype, int B, int T, float* out, void* workspace,
                                   size_t workspace_bytes, void* stream) {
     if (!m) return fail(SAVAD_E_INVALID, "null handle");
-    if (x_dtype == 0 && m->precision == 0) return savad_forward(m, (const float*)x, B, T, out, workspace, workspace_bytes, stream);
+    if (x_dtype == 0 && m->precision != 1) return savad_forward(m, (const float*)x, B, T, out, workspace, workspace_bytes, stream);
     if (x_dtype < 0 || x_dtype > 1) return fail(SAVAD_E_INVALID, "x_dtype %d", x_dtype);
     if (m->generic) return fail(SAVAD_E_UNSUPPORTED, "bf16 features need the d_model=128 kernels (this handle: d_model=%d, fp32)", m->cfg.d_model);
     if (m->precision != 1) return fail(SAVAD_E_UNSUPPORTED, "bf16 features need savad_set_precision(h, 1)");
@@ -1110,6 +1281,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     hipStream_t st = (hipStream_t)stream;
     if (m->generic) return forward_generic(m, x, B, T, out, workspace, workspace_bytes, st);
     if (m->precision == 1) return forward_bf16(m, x, 0, B, T, out, workspace, workspace_bytes, st);
+    if (m->precision == 2) return forward_f32s(m, x, B, T, out, workspace, workspace_bytes, st);
     const Workspace ws = plan(m, B, T);
     if (workspace_bytes < ws.total * sizeof(float))
         return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, ws.total * sizeof(float));
@@ -1342,7 +1514,7 @@ int plan_predict(savad_model* m, int N, int half, int jump, int chunk, PredictPl
     if (m->precision == 1)
         p->windowed = !m->generic && p->W <= 32 && m->FP == F && packed_bf16_applies(m, p->W);
     else
-        p->windowed = !m->generic && p->W <= 32 && m->cfg.num_layers <= PACKED_MAX_LAYERS && m->FP == F &&
+        p->windowed = m->precision == 0 && !m->generic && p->W <= 32 && m->cfg.num_layers <= PACKED_MAX_LAYERS && m->FP == F &&
                       (m->row_mode == 4 || (m->row_mode == 0 && p->n_items <= 1024 * (32 / p->W)));
     // chunk-sized forwards write their log-probs at logp + first*W*2 floats and savad_forward wants 16-byte aligned
     // pointers: an even chunk keeps every offset a multiple of 16 bytes whatever W is (windows are independent, so the

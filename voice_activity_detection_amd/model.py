@@ -59,6 +59,9 @@ def _layer_params(d_model: int, d_ff: int) -> nn.Module:
     return m
 
 
+PRECISIONS = {"fp32": 0, "bf16": 1, "fp32s": 2}   # savad_set_precision codes (include/savad.h)
+
+
 class SelfAttentiveVAD(nn.Module):
     def __init__(self, feature_size: int, num_layers: int, d_model: int, dropout: float = 0.0):
         super().__init__()
@@ -91,6 +94,8 @@ class SelfAttentiveVAD(nn.Module):
         self.row_mode = 0  # 0 = automatic, 1 = N-split 32-row tiles, 2 / 3 = M-split 128-row tiles, 4 = T <= 32 in one launch (include/savad.h)
         # "fp32": exact-fp32 MFMA (default, log-probs within 1e-4 of the reference).
         # "bf16": bf16 MFMA operands, fp32 accumulation / statistics, fp16-stored residual stream (BASELINE configs[2..3]).
+        # "fp32s": fp32 parity on the bf16 matrix pipe -- every GEMM operand as three bf16 pieces, six MFMA products per
+        #          K-step into an fp32 accumulator (csrc/savad_kernels_f32s.h): the same 1e-4 bar as "fp32", 6/16 of its matrix time.
         self.precision = "fp32"
         # bf16 only: the same bits for a sequence whatever batch it is evaluated in (chunk sizes, shard sizes, remainders), at 3 - 4 % of a
         # large-batch forward: the persistent attention kernel then runs without its key-split tail items (include/savad.h)
@@ -242,8 +247,8 @@ class SelfAttentiveVAD(nn.Module):
                 "Move the model and the features to the GPU (model.to('cuda'), features.to('cuda')).")
         if self.training and self.dropout_p > 0:
             raise _lib.SavadError("training-mode dropout is outside this build's scope: call model.eval()")
-        if self.precision not in ("fp32", "bf16"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {self.precision!r}")
+        if self.precision not in PRECISIONS:
+            raise ValueError(f"precision must be 'fp32', 'fp32s' or 'bf16', got {self.precision!r}")
         pdev = self._pdev
         if pdev is None:
             pdev = self._pdev = self.classifier.weight.device
@@ -256,7 +261,7 @@ class SelfAttentiveVAD(nn.Module):
         if knobs != self._pushed_knobs:   # four library calls only when a knob moved, none on the steady path
             _lib.check(lib.savad_set_attention_splits(self._handle, knobs[0]))
             _lib.check(lib.savad_set_row_mode(self._handle, knobs[1]))
-            _lib.check(lib.savad_set_precision(self._handle, 1 if knobs[2] == "bf16" else 0))
+            _lib.check(lib.savad_set_precision(self._handle, PRECISIONS[knobs[2]]))
             _lib.check(lib.savad_set_batch_invariant(self._handle, int(knobs[3])))
             self._pushed_knobs = knobs
         return lib
@@ -288,7 +293,7 @@ class SelfAttentiveVAD(nn.Module):
         if features.dim() != 3 or features.size(2) != self.feature_size:
             raise ValueError(f"features must be [B, T, {self.feature_size}], got {tuple(features.shape)}")
         device = features.device
-        if device.type != "cuda" or self.precision not in ("fp32", "bf16"):
+        if device.type != "cuda" or self.precision not in PRECISIONS:
             self._prepare_call(device)  # raises the matching error
         x = features.detach() if features.requires_grad else features
         x_dtype = 0
