@@ -404,6 +404,23 @@ BlockPlan3 plan_blocks3(const savad_model* m, int B, int T) {
     return p;
 }
 
+// T <= 32 in precision 2: the single-launch wave-per-block kernel from `SAVAD_F32S_PACKED_MIN_BLOCKS` packed blocks up (four blocks
+// per workgroup share the weight stream; a block's chain is 7 320 bf16 MFMAs); below that the chain's latency is the forward's time
+// and the exact-fp32 kernels of precision 0 (which split a block's GEMMs over four waves) are faster -- "fp32s" promises the fp32
+// result at the best speed the library has, not a particular instruction.
+#ifndef SAVAD_F32S_PACKED_MIN_BLOCKS
+#define SAVAD_F32S_PACKED_MIN_BLOCKS 384
+#endif
+bool packed_f32s_applies(const savad_model* m, int B, int T) {
+    if (T > 32 || m->cfg.num_layers > fs::PACKED_F32S_MAX_LAYERS) return false;
+    const long nblk = ((long)B + 32 / T - 1) / (32 / T);
+    return m->row_mode == 4 || (m->row_mode == 0 && nblk >= SAVAD_F32S_PACKED_MIN_BLOCKS);
+}
+// precision 2 shapes that run the exact-fp32 kernels: T <= 32 below the single launch's break-even (row_mode 1 - 3 force the fp32s
+// per-layer launches: the tests' cross-check)
+bool f32s_uses_exact_fp32(const savad_model* m, int B, int T) {
+    return T <= 32 && m->row_mode == 0 && !packed_f32s_applies(m, B, T);
+}
 int pack_frags3(savad_model* m, hipStream_t st, const float* W, int N, int K, size_t off) {
     const size_t total = (size_t)N * K;
     const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
@@ -799,7 +816,7 @@ SAVAD_EXPORT int savad_workspace_bytes(savad_handle m, int B, int T, size_t* byt
     else if (m->precision == 1)
         *bytes = plan_blocks(m, B, T).total;
     else if (m->precision == 2)
-        *bytes = plan_blocks3(m, B, T).total;
+        *bytes = f32s_uses_exact_fp32(m, B, T) ? plan(m, B, T).total * sizeof(float) : plan_blocks3(m, B, T).total;
     else
         *bytes = plan(m, B, T).total * sizeof(float);
     return SAVAD_OK;
@@ -1133,8 +1150,31 @@ int prepare_f32s_launch(savad_model* m) {
     if ((rc = allow_lds(fs::attention_row_kernel_f32s<true, false>, fs::ROW_LDS_BYTES))) return rc;
     if ((rc = allow_lds(fs::attention_row_kernel_f32s<false, true>, fs::ROW_LDS_BYTES))) return rc;
     if ((rc = allow_lds(fs::attention_row_kernel_f32s<true, true>, fs::ROW_LDS_BYTES))) return rc;
+    if ((rc = allow_lds(fs::packed_forward_kernel_f32s, fs::packed_f32s_lds_bytes(fs::PACKED_F32S_MAX_LAYERS)))) return rc;
     m->lds_attrs3_set = true;
     return SAVAD_OK;
+}
+
+void launch_packed_forward_f32s(savad_model* m, hipStream_t st, const float* x, int B, int T, int F, float* out, const WindowOffsets& wo,
+                                int win_base) {
+    const int L = m->cfg.num_layers;
+    const char* Fr = m->d_frag3;
+    const int G = 32 / T, nblk = (B + G - 1) / G;
+    fs::PackedF32sModel pm;
+    for (int l = 0; l < fs::PACKED_F32S_MAX_LAYERS; ++l) {
+        const auto& f = m->lf3[l < L ? l : 0];
+        pm.layer[l] = fs::PackedF32sLayer{Fr + f.wqkv, Fr + f.wo, Fr + f.w1, Fr + f.w2};
+    }
+    pm.win = Fr + m->f3_win;
+    pm.bin = m->d_raw + m->r_bin;
+    pm.pe = m->d_pe;
+    pm.bias = m->d_packed + m->p_bias;
+    pm.wc = m->d_packed + m->p_wc;
+    pm.bc = m->d_packed + m->p_bc;
+    pm.L = L;
+    const float c = (float)(1.4426950408889634 / sqrt((double)D));
+    hipLaunchKernelGGL(fs::packed_forward_kernel_f32s, dim3((nblk + 3) / 4), dim3(256), fs::packed_f32s_lds_bytes(L), st, x, B, T, F, nblk, pm, c,
+                       out, wo, win_base);
 }
 
 // fp32s forward (precision 2): input_qkv -> [attention + row chain] x L, every GEMM as six bf16 MFMA products of three-piece operands
@@ -1164,6 +1204,15 @@ int forward_f32s(savad_model* m, const float* x, int B, int T, float* out, void*
     const float* P = m->d_packed;
     const char* Fr = m->d_frag3;
     Prof prof(m, st);
+    if (packed_f32s_applies(m, B, T) && m->xbs_override == 0) {
+        WindowOffsets none;
+        none.w = 0;
+        launch_packed_forward_f32s(m, st, x, B, T, F, out, none, 0);
+        prof.mark("packed_forward_f32s");
+        prof.done();
+        HIP_TRY(hipGetLastError());
+        return SAVAD_OK;
+    }
     char* sets[2][3] = {{W + bp.q, W + bp.k, W + bp.vt}, {W + bp.q2, W + bp.k2, W + bp.vt2}};
     hipLaunchKernelGGL(fs::input_qkv_kernel_f32s, dim3(bp.nblk_pad / 4), dim3(256), fs::NRING3 * fs::SLOT_BYTES + 3 * D * 4, st, x, xbs, B, T, F,
                        bp.nblk, Fr + m->f3_win, R + m->r_bin, m->d_pe, Fr + m->lf3[0].wqkv, P + m->lp[0].bqkv, hb, sets[0][0], sets[0][1],
@@ -1281,7 +1330,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     hipStream_t st = (hipStream_t)stream;
     if (m->generic) return forward_generic(m, x, B, T, out, workspace, workspace_bytes, st);
     if (m->precision == 1) return forward_bf16(m, x, 0, B, T, out, workspace, workspace_bytes, st);
-    if (m->precision == 2) return forward_f32s(m, x, B, T, out, workspace, workspace_bytes, st);
+    if (m->precision == 2 && !f32s_uses_exact_fp32(m, B, T)) return forward_f32s(m, x, B, T, out, workspace, workspace_bytes, st);
     const Workspace ws = plan(m, B, T);
     if (workspace_bytes < ws.total * sizeof(float))
         return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, ws.total * sizeof(float));
@@ -1498,6 +1547,7 @@ namespace {
 struct PredictPlan {
     int W, n_items, chunk;
     bool windowed;  // the single-launch forward reads its windows straight out of the feature matrix
+    bool f32s;      // ... and it is the fp32s one (precision 2 from SAVAD_F32S_PACKED_MIN_BLOCKS blocks up; shorter clips: the exact-fp32 one)
     size_t logp, windows, fwd, total;  // byte offsets into the workspace
     size_t fwd_bytes;
 };
@@ -1511,15 +1561,18 @@ int plan_predict(savad_model* m, int N, int half, int jump, int chunk, PredictPl
     // audio: savad_forward's own limit for that kernel); longer inputs go through `chunk`-sized M-split forwards, which
     // are ~9 % faster per window than 4096-window launches (5.27 vs 5.36 ms for 10 min of audio)
     // (bf16 operands: the single launch amortises the weight stream over the workgroup's blocks, so it takes any number of windows)
+    p->f32s = m->precision == 2 && !m->generic && p->W <= 32 && m->FP == F && p->n_items > 0 && packed_f32s_applies(m, p->n_items, p->W);
     if (m->precision == 1)
         p->windowed = !m->generic && p->W <= 32 && m->FP == F && packed_bf16_applies(m, p->W);
+    else if (p->f32s)   // (the fp32s single launch takes any number of windows)
+        p->windowed = true;
     else
-        p->windowed = m->precision == 0 && !m->generic && p->W <= 32 && m->cfg.num_layers <= PACKED_MAX_LAYERS && m->FP == F &&
+        p->windowed = !m->generic && p->W <= 32 && m->cfg.num_layers <= PACKED_MAX_LAYERS && m->FP == F &&
                       (m->row_mode == 4 || (m->row_mode == 0 && p->n_items <= 1024 * (32 / p->W)));
     // chunk-sized forwards write their log-probs at logp + first*W*2 floats and savad_forward wants 16-byte aligned
     // pointers: an even chunk keeps every offset a multiple of 16 bytes whatever W is (windows are independent, so the
     // chunking never changes a result beyond fp32 summation order)
-    p->chunk = p->windowed ? (m->precision == 1 ? (1 << 22) : 1024 * (32 / p->W)) : chunk + (chunk & 1);
+    p->chunk = p->windowed ? (m->precision == 1 || p->f32s ? (1 << 22) : 1024 * (32 / p->W)) : chunk + (chunk & 1);
     if (p->chunk > p->n_items) p->chunk = p->n_items > 0 ? p->n_items : 1;
     auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
     size_t off = 0;
@@ -1576,12 +1629,18 @@ SAVAD_EXPORT int savad_predict_probabilities(savad_handle m, const float* featur
             if ((rc = prepare_frags(m, st))) return rc;
             if ((rc = prepare_bf16_launch(m))) return rc;
         }
+        if (p.f32s) {
+            if ((rc = prepare_frags3(m, st))) return rc;
+            if ((rc = prepare_f32s_launch(m))) return rc;
+        }
     }
     for (int first = 0; first < p.n_items; first += p.chunk) {
         const int count = p.n_items - first < p.chunk ? p.n_items - first : p.chunk;
         float* out = logp + (size_t)first * W * 2;
         if (p.windowed && m->precision == 1) {
             launch_packed_forward_bf16(m, st, feature, count, W, F, out, wo, half + first);
+        } else if (p.windowed && p.f32s) {
+            launch_packed_forward_f32s(m, st, feature, count, W, F, out, wo, half + first);
         } else if (p.windowed) {
             launch_packed_forward(m, st, feature, count, W, F, out, wo, half + first);
         } else {

@@ -57,6 +57,10 @@ struct Tri {
 // a = h + m + l exactly (round-to-nearest pieces: every residual is exactly representable in fp32)
 __device__ __forceinline__ void split1(float a, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)a;
+    if (SAVAD_ABLATE & 128) {  // experiment builds: no residual arithmetic
+        m = l = h;
+        return;
+    }
     const float r1 = a - (float)h;
     m = (__bf16)r1;
     const float r2 = r1 - (float)m;
@@ -151,6 +155,7 @@ struct Ring3 {
     __device__ __forceinline__ char* slot(int t) const { return base + (t % NRING3) * SLOT_BYTES; }
     template <class SegSrc>
     __device__ __forceinline__ void issue(int t, SegSrc seg_src) const {
+        if (SAVAD_ABLATE & 1) return;
         const unsigned slot0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot(t));
         const unsigned off = (unsigned)lane * 16u;
         const char* s0 = seg_src(w >> 1) + (size_t)(w & 1) * (BLK3_BYTES / 2);
@@ -162,6 +167,7 @@ struct Ring3 {
     // slot t has landed for every wave.  newer = slots issued after slot t (0 .. 2); stores_after = this wave's vector stores
     // issued after its newest DMA (they may stay in flight)
     __device__ __forceinline__ void acquire(int newer, int stores_after = 0) const {
+        if (SAVAD_ABLATE & 2) return;
         const int n = PER * newer + stores_after;
         if (n == 0) __builtin_amdgcn_s_waitcnt(bf::Ring<4>::vmcnt_imm(0));
         else if (n == 12) __builtin_amdgcn_s_waitcnt(bf::Ring<4>::vmcnt_imm(12));
@@ -177,8 +183,8 @@ template <bool SWAP>
 __device__ __forceinline__ void gemm_slot(f32x16& acc0, f32x16& acc1, const char* slot, const Tri (&xp)[8], int lane) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const Tri w0 = ldtri(slot + ks * TFRAG_BYTES + lane * 16);
-        const Tri w1 = ldtri(slot + BLK3_BYTES + ks * TFRAG_BYTES + lane * 16);
+        const Tri w0 = (SAVAD_ABLATE & 8) ? xp[7 - ks] : ldtri(slot + ks * TFRAG_BYTES + lane * 16);
+        const Tri w1 = (SAVAD_ABLATE & 8) ? xp[ks ^ 1] : ldtri(slot + BLK3_BYTES + ks * TFRAG_BYTES + lane * 16);
         mfma6x2<SWAP>(acc0, acc1, w0, w1, xp[ks]);
     }
 }
@@ -323,7 +329,7 @@ __device__ __forceinline__ void attn_tile3(AttnState& st, const Tri (&qp)[8], co
     f32x16 sa = st.negm, sb = zero16();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const Tri k = ldtri(kblk + ks * TFRAG_BYTES + lane * 16);
+        const Tri k = (SAVAD_ABLATE & 8) ? qp[7 - ks] : ldtri(kblk + ks * TFRAG_BYTES + lane * 16);
         sa = SAVAD_MF(k.h, qp[ks].l, sa);
         sb = SAVAD_MF(k.l, qp[ks].h, sb);
         sa = SAVAD_MF(k.m, qp[ks].m, sa);
@@ -333,18 +339,18 @@ __device__ __forceinline__ void attn_tile3(AttnState& st, const Tri (&qp)[8], co
     }
     f32x16 sc = sa + sb;
     mask(sc);
-    online_softmax_shifted(sc, st, first);
+    if (!(SAVAD_ABLATE & 4)) online_softmax_shifted(sc, st, first);
     const Tri p0 = split_half(sc, 0), p1 = split_half(sc, 1);
 #pragma unroll
     for (int nbd = 0; nbd < 4; nbd += 2) {
         {
-            const Tri v0 = ldtri(vtblk + ((nbd * 2 + 0) * TFRAG_BYTES) + lane * 16);
-            const Tri v1 = ldtri(vtblk + (((nbd + 1) * 2 + 0) * TFRAG_BYTES) + lane * 16);
+            const Tri v0 = (SAVAD_ABLATE & 8) ? qp[nbd] : ldtri(vtblk + ((nbd * 2 + 0) * TFRAG_BYTES) + lane * 16);
+            const Tri v1 = (SAVAD_ABLATE & 8) ? qp[nbd + 1] : ldtri(vtblk + (((nbd + 1) * 2 + 0) * TFRAG_BYTES) + lane * 16);
             mfma6x2<false>(st.O[nbd], st.O[nbd + 1], v0, v1, p0);
         }
         {
-            const Tri v0 = ldtri(vtblk + ((nbd * 2 + 1) * TFRAG_BYTES) + lane * 16);
-            const Tri v1 = ldtri(vtblk + (((nbd + 1) * 2 + 1) * TFRAG_BYTES) + lane * 16);
+            const Tri v0 = (SAVAD_ABLATE & 8) ? qp[4 + nbd] : ldtri(vtblk + ((nbd * 2 + 1) * TFRAG_BYTES) + lane * 16);
+            const Tri v1 = (SAVAD_ABLATE & 8) ? qp[5 + nbd] : ldtri(vtblk + (((nbd + 1) * 2 + 1) * TFRAG_BYTES) + lane * 16);
             mfma6x2<false>(st.O[nbd], st.O[nbd + 1], v0, v1, p1);
         }
     }
@@ -565,6 +571,244 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
         }
     }
     row_stage_f32s<LAST>(A, smem, xp, blk_q, active, lane, w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// T <= 32: the WHOLE forward in one launch (the fp32s edition of savad_packed_bf16.h's wave-per-block kernel).  The reference
+// pipeline only ever runs 7-frame windows (vad/predictor.py:180-224).  A wave owns one packed block (floor(32/T) whole sequences)
+// for ALL layers: Q, K and V^T are produced by the wave that consumes them, so the attention never leaves its registers; the fp32
+// residual stream waits in registers; nothing but x, the weight stream and the log-probabilities crosses the CU boundary.  The four
+// waves of a workgroup share the weight stream: 24 ring slots per layer -- Wq Wk Wv Wo (two slots each), then W1 / W2 chunks
+// alternating (two slots each).  Windowed mode (wo.w == T > 0): x is the predictor's feature MATRIX [N][F] and sequence s is its
+// window feature[win_base + s + wo.off[0..T-1]] (vad/predictor.py:180-220): the gather is an address computation.
+// ---------------------------------------------------------------------------------------------
+constexpr int PACKED_F32S_MAX_LAYERS = 3;  // ring (144 KiB) + 3 x 4.5 KiB of biases + the classifier fit the 160 KiB of LDS
+struct PackedF32sLayer {
+    const char *wqkv, *wo, *w1, *w2;  // triples (pack_weight_frags3_kernel), LayerNorm affine folded in
+};
+struct PackedF32sModel {
+    PackedF32sLayer layer[PACKED_F32S_MAX_LAYERS];
+    const char* win;    // input Linear triples [4][F/16]
+    const float* bin;   // input bias
+    const float* pe;    // positional encoding / sqrt(D)
+    const float* bias;  // [L][LBIAS]: b1' | b2 | bqkv' | bo of every layer
+    const float *wc, *bc;
+    int L;
+};
+inline constexpr int packed_f32s_lds_bytes(int L) { return NRING3 * SLOT_BYTES + (L * LBIAS + 2 * D + 4) * 4; }
+
+__global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float* __restrict__ x, int B, int T, int F, int nblk,
+                                                                     PackedF32sModel M, float qscale, float* __restrict__ out,
+                                                                     WindowOffsets wo, int win_base) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lbias = reinterpret_cast<float*>(smem + NRING3 * SLOT_BYTES);
+    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * 4 + w;
+    const bool live = blk < nblk;  // wave-uniform; a wave without a block still moves its share of the weight stream
+    const Ring3 ring{smem, w, lane};
+    const int L = M.L, NS = 24 * L;
+    auto issue = [&](int t) {
+        const int l = t / 24, i = t - 24 * l;
+        const PackedF32sLayer Lw = M.layer[l];
+        ring.issue(t, [&](int sgm) -> const char* {
+            if (i < 6) return Lw.wqkv + (size_t)(2 * i + sgm) * BLK3_BYTES;
+            if (i < 8) return Lw.wo + (size_t)(2 * (i - 6) + sgm) * BLK3_BYTES;
+            const int c = (i - 8) >> 2, r = (i - 8) & 3;
+            return r < 2 ? Lw.w1 + (size_t)(4 * c + 2 * r + sgm) * BLK3_BYTES
+                         : Lw.w2 + (size_t)((2 * (r - 2) + sgm) * 32 + 8 * c) * TFRAG_BYTES;
+        });
+    };
+    auto advance = [&](int t) {
+        ring.acquire(NS - 1 - t < 1 ? NS - 1 - t : 1);
+        if (t + 2 < NS) issue(t + 2);
+    };
+    issue(0);
+    issue(1);
+    for (int i = threadIdx.x * 4; i < L * LBIAS; i += 1024) st4(lbias + i, ld4(M.bias + i));  // published by the first ring barrier
+    float* lwc = lbias + L * LBIAS;  // the classifier's folded weights [2][D] + bias [2] behind the biases
+    for (int i = threadIdx.x * 4; i < 2 * D; i += 1024) st4(lwc + i, ld4(M.wc + i));
+    if (threadIdx.x < 2) lwc[2 * D + threadIdx.x] = M.bc[threadIdx.x];
+
+    // ---- slots of the block: sequence blk * G + m / T, frame m % T
+    const int G = 32 / T, seq = blk * G + m / T, t_frame = m % T;
+    const bool valid = live && m < G * T && seq < B;
+    const size_t row = valid ? (size_t)seq * T + t_frame : 0;
+    bool keyok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int jk = 8 * (r >> 2) + 4 * h + (r & 3);
+        keyok[r] = (jk < G * T) && (jk / T == m / T) && (blk * G + jk / T < B);
+    }
+    // ---- input Linear + positional encoding (vad/models/self_attention.py:12-16,24)
+    f32x16 hres[4], acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        hres[nb] = zero16();
+        add_bias(hres[nb], M.bin + 32 * nb, h);
+        add_block(hres[nb], M.pe + (size_t)(valid ? t_frame : 0) * D + 32 * nb, h);
+    }
+    {
+        const size_t src_row = wo.w > 0 ? (size_t)win_base + (valid ? seq : 0) + wo.off[valid ? t_frame : 0] : row;
+        const float* xr = x + src_row * (size_t)F;
+        const int KS = F / 16;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
+            const Tri xf = load_x_tri(xr + f0, valid);
+#pragma unroll
+            for (int nb = 0; nb < 4; nb += 2) {
+                const Tri w0 = ldtri(M.win + (size_t)(nb * KS + ks) * TFRAG_BYTES + lane * 16);
+                const Tri w1 = ldtri(M.win + (size_t)((nb + 1) * KS + ks) * TFRAG_BYTES + lane * 16);
+                mfma6x2<false>(hres[nb], hres[nb + 1], w0, w1, xf);
+            }
+        }
+    }
+    f32x4 xg[16];
+    layernorm_regs(hres, xg);
+    Tri xp[8];
+    split_row(xg, xp);
+
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        const int t0 = 24 * l;
+        const float* lb = lbias + l * LBIAS;
+        const float *lb1 = lb, *lb2 = lb + DFF, *lbn = lb + DFF + D, *lbo = lb + DFF + 4 * D;
+        // ---- Q (pre-scaled by log2(e)/sqrt(D)) and K in row layout -> triples
+        Tri qp[8], kp[8];
+#pragma unroll
+        for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] = bias_block(lbn + 32 * nbl, h);
+        advance(t0);
+        gemm_slot<false>(acc[0], acc[1], ring.slot(t0), xp, lane);
+        advance(t0 + 1);
+        gemm_slot<false>(acc[2], acc[3], ring.slot(t0 + 1), xp, lane);
+#pragma unroll
+        for (int nbl = 0; nbl < 4; ++nbl) {
+            acc[nbl] *= qscale;
+            qp[2 * nbl] = split_half(acc[nbl], 0);
+            qp[2 * nbl + 1] = split_half(acc[nbl], 1);
+        }
+#pragma unroll
+        for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] = bias_block(lbn + D + 32 * nbl, h);
+        advance(t0 + 2);
+        gemm_slot<false>(acc[0], acc[1], ring.slot(t0 + 2), xp, lane);
+        advance(t0 + 3);
+        gemm_slot<false>(acc[2], acc[3], ring.slot(t0 + 3), xp, lane);
+#pragma unroll
+        for (int nbl = 0; nbl < 4; ++nbl) {
+            kp[2 * nbl] = split_half(acc[nbl], 0);
+            kp[2 * nbl + 1] = split_half(acc[nbl], 1);
+        }
+        // ---- scores and softmax of the single key tile (vad/modeling/transformer.py:351-363,333)
+        f32x16 sa = zero16(), sb = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            sa = SAVAD_MF(kp[ks].h, qp[ks].l, sa);
+            sb = SAVAD_MF(kp[ks].l, qp[ks].h, sb);
+            sa = SAVAD_MF(kp[ks].m, qp[ks].m, sa);
+            sb = SAVAD_MF(kp[ks].h, qp[ks].m, sb);
+            sa = SAVAD_MF(kp[ks].m, qp[ks].h, sa);
+            sb = SAVAD_MF(kp[ks].h, qp[ks].h, sb);
+        }
+        f32x16 sc = sa + sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = keyok[r] ? sc[r] : NEG_BIG;
+        float l_run;
+        {
+            float mx = sc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+            mx = half_max(mx);
+            float rs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = __builtin_amdgcn_exp2f(sc[r] - mx);
+                rs += sc[r];
+            }
+            l_run = rs;
+        }
+        const Tri p0 = split_half(sc, 0), p1 = split_half(sc, 1);
+        // ---- V^T (operands swapped: lane = feature, registers = keys) and O^T = V^T P^T, normalised -> the context triples
+#pragma unroll
+        for (int nbl = 0; nbl < 4; ++nbl) {
+            const float bv = lbn[2 * D + 32 * nbl + m];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nbl][r] = bv;
+        }
+        advance(t0 + 4);
+        gemm_slot<true>(acc[0], acc[1], ring.slot(t0 + 4), xp, lane);
+        advance(t0 + 5);
+        gemm_slot<true>(acc[2], acc[3], ring.slot(t0 + 5), xp, lane);
+        {
+            const float inv = 1.0f / half_sum(l_run);
+#pragma unroll
+            for (int nbd = 0; nbd < 4; nbd += 2) {
+                f32x16 O0 = zero16(), O1 = zero16();
+                mfma6x2<false>(O0, O1, split_half(acc[nbd], 0), split_half(acc[nbd + 1], 0), p0);
+                mfma6x2<false>(O0, O1, split_half(acc[nbd], 1), split_half(acc[nbd + 1], 1), p1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    O0[r] = valid ? O0[r] * inv : 0.0f;
+                    O1[r] = valid ? O1[r] * inv : 0.0f;
+                }
+                xp[2 * nbd] = split_half(O0, 0);
+                xp[2 * nbd + 1] = split_half(O0, 1);
+                xp[2 * nbd + 2] = split_half(O1, 0);
+                xp[2 * nbd + 3] = split_half(O1, 1);
+            }
+        }
+        // ---- h1 = h + bo + ctx Wo^T; LN; FFN on top of the residual stream
+        f32x16(&h1)[4] = hres;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) h1[nb] += bias_block(lbo + 32 * nb, h);
+        advance(t0 + 6);
+        gemm_slot<false>(h1[0], h1[1], ring.slot(t0 + 6), xp, lane);
+        advance(t0 + 7);
+        gemm_slot<false>(h1[2], h1[3], ring.slot(t0 + 7), xp, lane);
+        layernorm_regs(h1, xg);
+        split_row(xg, xp);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) h1[nb] += bias_block(lb2 + 32 * nb, h);
+#pragma unroll 1
+        for (int ch = 0; ch < 4; ++ch) {
+            const int tc = t0 + 8 + 4 * ch;
+#pragma unroll
+            for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] = bias_block(lb1 + 128 * ch + 32 * nbl, h);
+            advance(tc);
+            gemm_slot<false>(acc[0], acc[1], ring.slot(tc), xp, lane);
+            advance(tc + 1);
+            gemm_slot<false>(acc[2], acc[3], ring.slot(tc + 1), xp, lane);
+            Tri ap[8];
+#pragma unroll
+            for (int nbl = 0; nbl < 4; ++nbl) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nbl][r] = fmaxf(acc[nbl][r], 0.0f);
+                ap[2 * nbl] = split_half(acc[nbl], 0);
+                ap[2 * nbl + 1] = split_half(acc[nbl], 1);
+            }
+            advance(tc + 2);
+            gemm_slot<false>(h1[0], h1[1], ring.slot(tc + 2), ap, lane);
+            advance(tc + 3);
+            gemm_slot<false>(h1[2], h1[3], ring.slot(tc + 3), ap, lane);
+        }
+        layernorm_regs(hres, xg);
+        if (l + 1 < L) split_row(xg, xp);
+    }
+    // ---- final LayerNorm (folded into the classifier) + Linear(D, 2) + log-softmax (vad/models/self_attention.py:26-28)
+    float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+    for (int Gq = 0; Gq < 16; ++Gq) {
+        const f32x4 c0 = ld4(lwc + 8 * Gq + 4 * h), c1 = ld4(lwc + D + 8 * Gq + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            z0 = __builtin_fmaf(xg[Gq][e], c0[e], z0);
+            z1 = __builtin_fmaf(xg[Gq][e], c1[e], z1);
+        }
+    }
+    z0 = half_sum(z0) + lwc[2 * D];
+    z1 = half_sum(z1) + lwc[2 * D + 1];
+    const float mx = fmaxf(z0, z1);
+    const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+    if (h == 0 && valid) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
 }
 
 }  // namespace fs
