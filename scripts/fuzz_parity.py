@@ -13,12 +13,12 @@ m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
 m = m.cuda().eval()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-worst = {"fp32": 0.0, "bf16": 0.0}
+worst = {"fp32": 0.0, "fp32s": 0.0, "bf16": 0.0}
 for it in range(n):
     T = int(rng.choice([1, 2, 3, 5, 7, 7, 11, 16, 16, 31, 32, 33, 40, 63, 64, 65, 96, 127, 128, 129, 200, 257, 400, 513, 800, 801, 1000]))
     maxB = max(1, min(48, 40000 // T)) if T > 32 else int(rng.choice([3, 40, 300, 1200, 5000]))
     B = int(rng.integers(1, maxB + 1))
-    prec = "bf16" if rng.random() < 0.35 else "fp32"
+    prec = str(rng.choice(["fp32", "fp32", "fp32s", "fp32s", "bf16", "bf16"]))   # (fp32s: the fp32 bar)
     mode = int(rng.integers(0, 9))  # 0 .. 8 (include/savad.h)
     splits = int(rng.choice([0, 0, 1, 1, 2, 3, 5]))
     if it % 4 == 3:   # another model width: csrc/savad_generic.h (fp32 only; splits = query tiles)

@@ -37,14 +37,33 @@ def model(torch_cuda, state1234):
     return make_model(torch_cuda, state1234)
 
 
-def run(torch, model, x, splits=0, row_mode=0):
+# The fp32-parity modes: "fp32" = exact-fp32 MFMA, "fp32s" = the same arithmetic on the bf16 matrix pipe (three-piece operands, six
+# products, fp32 accumulation: csrc/savad_kernels_f32s.h).  Every golden / oracle test that takes the `fp32_mode` fixture runs under
+# both, at the SAME tolerances.
+FP32_MODES = ["fp32", "fp32s"]
+_MODE = "fp32"
+
+
+@pytest.fixture(params=FP32_MODES)
+def fp32_mode(request):
+    global _MODE
+    _MODE = request.param
+    yield request.param
+    _MODE = "fp32"
+
+
+def run(torch, model, x, splits=0, row_mode=0, precision=None):
     model.attention_splits = splits
     model.row_mode = row_mode
-    with torch.no_grad():
-        y = model(features=torch.from_numpy(x).to("cuda"))
-    torch.cuda.synchronize()
-    model.attention_splits = 0
-    model.row_mode = 0
+    model.precision = precision or _MODE
+    try:
+        with torch.no_grad():
+            y = model(features=torch.from_numpy(x).to("cuda"))
+        torch.cuda.synchronize()
+    finally:
+        model.attention_splits = 0
+        model.row_mode = 0
+        model.precision = "fp32"
     return y.cpu().numpy()
 
 
@@ -70,7 +89,7 @@ def test_native_library_is_loaded(torch_cuda, model):
     ("g6_out", 600, (2, 40, 80), "logmel"),
     ("g4_B1T7", 77, (1, 7, 80), "logmel"),
 ])
-def test_golden(torch_cuda, model, golden, tag, seed, shape, kind):
+def test_golden(torch_cuda, model, golden, tag, seed, shape, kind, fp32_mode):
     y = run(torch_cuda, model, feats(seed, shape, kind))
     assert y.shape == golden[tag].shape and y.dtype == np.float32
     err = np.abs(y - golden[tag]).max()
@@ -78,13 +97,13 @@ def test_golden(torch_cuda, model, golden, tag, seed, shape, kind):
 
 
 @pytest.mark.parametrize("T", [1, 2, 5, 10, 11, 16, 17, 31, 32, 33, 63, 64, 65, 100, 799, 801])
-def test_golden_edge_lengths(torch_cuda, model, golden, T):
+def test_golden_edge_lengths(torch_cuda, model, golden, T, fp32_mode):
     y = run(torch_cuda, model, feats(400 + T, (3, T, 80)))
     err = np.abs(y - golden[f"g4_T{T}"]).max()
     assert err < TIGHT, err
 
 
-def test_golden_reference_batch_shape(torch_cuda, model, golden):
+def test_golden_reference_batch_shape(torch_cuda, model, golden, fp32_mode):
     # [1000, 7, 80]: the only shape the reference pipeline runs (vad/predictor.py:180)
     y = run(torch_cuda, model, feats(78, (1000, 7, 80)))
     assert np.abs(y[:8] - golden["g4_B1000T7_head"]).max() < TIGHT
@@ -92,7 +111,7 @@ def test_golden_reference_batch_shape(torch_cuda, model, golden):
     assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g4_B1000T7_seqsum"]).max() < 14 * TIGHT
 
 
-def test_golden_config2_full_size(torch_cuda, model, golden):
+def test_golden_config2_full_size(torch_cuda, model, golden, fp32_mode):
     # BASELINE.json configs[1]: [32, 800, 80] fp32, log-probs vs the reference within 1e-4
     y = run(torch_cuda, model, feats(0, (32, 800, 80)))
     assert np.abs(y[:2] - golden["g3_head"]).max() < TIGHT
@@ -102,7 +121,7 @@ def test_golden_config2_full_size(torch_cuda, model, golden):
     assert np.abs(np.abs(y.astype(np.float64)).sum(axis=(1, 2)) - golden["g3_abssum"]).max() < 1600 * TIGHT
 
 
-def test_golden_peaked_softmax(torch_cuda, golden):
+def test_golden_peaked_softmax(torch_cuda, golden, fp32_mode):
     from voice_activity_detection_amd.seeded import seeded_state_dict
 
     m = make_model(torch_cuda, seeded_state_dict(4321, gain=4.0))
@@ -111,7 +130,7 @@ def test_golden_peaked_softmax(torch_cuda, golden):
         assert np.abs(run(torch_cuda, m, feats(701, (1, 800, 80)), splits) - golden["g7_T800"]).max() < TOL
 
 
-def test_golden_other_model_size(torch_cuda, golden):
+def test_golden_other_model_size(torch_cuda, golden, fp32_mode):
     from voice_activity_detection_amd.seeded import seeded_state_dict
 
     m = make_model(torch_cuda, seeded_state_dict(88, feature_size=40, num_layers=2), F=40, L=2)
@@ -119,7 +138,7 @@ def test_golden_other_model_size(torch_cuda, golden):
 
 
 @pytest.mark.parametrize("F", [257, 13])
-def test_golden_odd_feature_sizes(torch_cuda, golden, F):
+def test_golden_odd_feature_sizes(torch_cuda, golden, F, fp32_mode):
     """Feature sizes that are not a multiple of the kernels' K granularity (257 spectrogram bins, 13 MFCCs) are
     zero-padded inside the library; fp32 and bf16 paths."""
     from voice_activity_detection_amd.seeded import seeded_state_dict
@@ -134,7 +153,7 @@ def test_golden_odd_feature_sizes(torch_cuda, golden, F):
 
 
 @pytest.mark.parametrize("shape", [(5, 7, 80), (3, 45, 80), (2, 257, 80), (9, 33, 80), (37, 3, 80)])
-def test_against_oracle(torch_cuda, model, state1234, shape):
+def test_against_oracle(torch_cuda, model, state1234, shape, fp32_mode):
     from oracle import oracle
 
     x = feats(hash(shape) % 10000, shape)
@@ -143,7 +162,7 @@ def test_against_oracle(torch_cuda, model, state1234, shape):
     assert err < TIGHT, err
 
 
-def test_long_sequence(torch_cuda, model, state1234):
+def test_long_sequence(torch_cuda, model, state1234, fp32_mode):
     """One 20 s sequence (T = 2049: 65 key tiles, ragged tail, PE table grown twice, automatic key splits)."""
     from oracle import oracle
 
@@ -160,7 +179,7 @@ def test_attention_split_invariance(torch_cuda, model, golden, splits):
 
 
 @pytest.mark.parametrize("row_mode", [1, 2])
-def test_row_tilings_agree_with_golden(torch_cuda, model, golden, row_mode):
+def test_row_tilings_agree_with_golden(torch_cuda, model, golden, row_mode, fp32_mode):
     # both tilings of the row-wise stages (32-row N-split, 128-row M-split with the LDS weight ring)
     for tag, seed, shape in (("g2_out", 102, (2, 800, 80)), ("g1_out", 101, (4, 7, 80)), ("g6_out", 600, (2, 40, 80))):
         y = run(torch_cuda, model, feats(seed, shape), row_mode=row_mode)
@@ -175,7 +194,7 @@ def test_row_tilings_agree_with_golden(torch_cuda, model, golden, row_mode):
     assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g3_seqsum"]).max() < 1600 * TIGHT
 
 
-def test_fused_attention_row_launches(torch_cuda, model, golden, state1234):
+def test_fused_attention_row_launches(torch_cuda, model, golden, state1234, fp32_mode):
     """row_mode 3 with one key split: attention + row chain in ONE launch per layer (q/k/v double-buffered), the
     path `automatic` takes for large batches.  Goldens incl. ragged lengths (lanes past T fill MFMA tiles but never
     store), batches that do not fill the 8 XCDs, and bit-identity with the two-launch M-split path is NOT expected
@@ -200,7 +219,7 @@ def test_fused_attention_row_launches(torch_cuda, model, golden, state1234):
     # workspace poisoning: a second call on a recycled workspace full of NaNs must not leak them through the
     # over-read V rows behind the batch
     torch = torch_cuda
-    model.row_mode, model.attention_splits = 3, 1
+    model.row_mode, model.attention_splits, model.precision = 3, 1, fp32_mode
     try:
         xt = torch.from_numpy(feats(77, (3, 801, 80))).cuda()
         with torch.no_grad():
@@ -210,7 +229,7 @@ def test_fused_attention_row_launches(torch_cuda, model, golden, state1234):
             y1 = model(features=xt)
         assert torch.isfinite(y1).all() and torch.equal(y0, y1)
     finally:
-        model.row_mode, model.attention_splits = 0, 0
+        model.row_mode, model.attention_splits, model.precision = 0, 0, "fp32"
 
 
 def test_single_launch_packed_forward(torch_cuda, model, golden, state1234):
@@ -261,7 +280,65 @@ def test_single_launch_packed_forward(torch_cuda, model, golden, state1234):
         assert np.abs(run(torch, m9, x, row_mode=mode) - oracle.forward(st, x)).max() < TIGHT, mode
 
 
-def test_properties_full_size(torch_cuda, model):
+def test_fp32s_launch_schedules(torch_cuda, model, golden, state1234):
+    """precision "fp32s" at T <= 32: its single launch (a wave per packed block, all layers: row_mode 4, automatic from 384 blocks up),
+    its per-layer launches (row_mode 1) and the automatic choice (exact-fp32 kernels for small batches) -- all three against the
+    goldens / the oracle at the fp32 tolerance for every tile shape, a batch of several rounds of the CUs, odd feature sizes, depths
+    beyond the single launch's layer table; results must not depend on what else shares a tile or the batch."""
+    from oracle import oracle
+    from voice_activity_detection_amd import seeded_state_dict
+
+    torch = torch_cuda
+    for rm in (0, 1, 4):
+        assert np.abs(run(torch, model, feats(101, (4, 7, 80)), row_mode=rm, precision="fp32s") - golden["g1_out"]).max() < TIGHT
+        y = run(torch, model, feats(78, (1000, 7, 80)), row_mode=rm, precision="fp32s")
+        assert np.abs(y[:8] - golden["g4_B1000T7_head"]).max() < TIGHT and np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < TIGHT
+        for T in (1, 2, 5, 10, 11, 16, 17, 31, 32):
+            y = run(torch, model, feats(400 + T, (3, T, 80)), row_mode=rm, precision="fp32s")
+            assert np.abs(y - golden[f"g4_T{T}"]).max() < TIGHT, (rm, T)
+    for shape in [(5, 7, 80), (37, 3, 80), (1, 1, 80), (33, 1, 80), (9, 32, 80), (7, 13, 80), (1700, 7, 80), (300, 16, 80), (5000, 7, 80)]:
+        x = feats(7 + shape[0], shape)
+        ref = oracle.forward(state1234, x, threads=8)
+        y = run(torch, model, x, row_mode=4, precision="fp32s")
+        assert np.abs(y - ref).max() < TIGHT, shape
+        assert np.array_equal(y, run(torch, model, x, row_mode=4, precision="fp32s")), shape  # deterministic
+        assert np.abs(run(torch, model, x, row_mode=1, precision="fp32s") - ref).max() < TIGHT, shape
+        assert np.abs(run(torch, model, x, row_mode=0, precision="fp32s") - ref).max() < TIGHT, shape
+    x = feats(91, (41, 7, 80))
+    whole = run(torch, model, x, row_mode=4, precision="fp32s")
+    assert np.array_equal(run(torch, model, x[4:12], row_mode=4, precision="fp32s"), whole[4:12])  # whole tiles move together
+    assert np.array_equal(run(torch, model, x[8:9], row_mode=4, precision="fp32s")[0], whole[8])   # same tile slot: same bits
+    assert np.abs(run(torch, model, x[9:10], row_mode=4, precision="fp32s")[0] - whole[9]).max() < 2e-6
+    for F in (257, 13):  # zero-padded K of the input Linear, K > 128
+        st = seeded_state_dict(900 + F, feature_size=F)
+        xf = feats(901 + F, (5, 7, F))
+        for rm in (1, 4):   # (padded features: row_mode 4 runs the per-layer launches on the padded copy)
+            assert np.abs(run(torch, make_model(torch, st, F=F), xf, row_mode=rm, precision="fp32s") - oracle.forward(st, xf)).max() < TIGHT, F
+        xl = feats(902 + F, (3, 70, F))
+        assert np.abs(run(torch, make_model(torch, st, F=F), xl, precision="fp32s") - oracle.forward(st, xl)).max() < TIGHT, F
+    st = seeded_state_dict(55, num_layers=5)  # deeper than the single launch's layer table (3): the per-layer launches take over
+    x = feats(56, (6, 7, 80))
+    xl = feats(57, (2, 100, 80))
+    m5 = make_model(torch, st, L=5)
+    for rm in (0, 1, 4):
+        assert np.abs(run(torch, m5, x, row_mode=rm, precision="fp32s") - oracle.forward(st, x)).max() < TIGHT, rm
+    assert np.abs(run(torch, m5, xl, precision="fp32s") - oracle.forward(st, xl)).max() < TIGHT
+    # nothing but x, the weights and `out` is touched by the single launch; the per-layer launches survive a poisoned workspace
+    model.precision = "fp32s"
+    try:
+        for rm, shape in ((4, (13, 7, 80)), (1, (13, 7, 80)), (0, (3, 801, 80)), (0, (2000, 7, 80))):
+            model.row_mode = rm
+            xt = torch.from_numpy(feats(5, shape)).cuda()
+            with torch.no_grad():
+                y0 = model(features=xt).clone()
+                model._workspace.fill_(255)
+                y1 = model(features=xt)
+            assert torch.isfinite(y1).all() and torch.equal(y0, y1), (rm, shape)
+    finally:
+        model.precision, model.row_mode = "fp32", 0
+
+
+def test_properties_full_size(torch_cuda, model, fp32_mode):
     # size-independent properties at config-2 size: normalisation, batch-permutation equivariance
     # (sequences are independent: bit-exact), determinism
     x = feats(5, (32, 800, 80))
@@ -303,8 +380,8 @@ def test_empty_and_call_forms(torch_cuda, model):
             model(features=x, out=bad)
 
 
-@pytest.mark.parametrize("shape", [(6, 96, 80), (32, 800, 80), (40, 7, 80)])
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(6, 96, 80), (32, 800, 80), (40, 7, 80), (1600, 7, 80)])
+@pytest.mark.parametrize("precision", ["fp32", "fp32s", "bf16"])
 def test_forward_is_graph_capturable(torch_cuda, model, precision, shape):
     """savad_forward neither allocates nor synchronises (include/savad.h), so after one warm-up call (weights
     packed, PE table grown) the 7 launches can be captured in a hipGraph and replayed on new data."""
@@ -334,7 +411,7 @@ def test_forward_is_graph_capturable(torch_cuda, model, precision, shape):
         model.precision = "fp32"
 
 
-def test_pe_cache_growth(torch_cuda, state1234):
+def test_pe_cache_growth(torch_cuda, state1234, fp32_mode):
     # PE cache starts at 10 frames and regrows on demand (vad/modeling/transformer.py:392-397)
     from oracle import oracle
 
@@ -369,7 +446,7 @@ def test_reserve_makes_forward_capturable(torch_cuda, state1234):
     assert np.abs(out.cpu().numpy() - oracle.forward(state1234, x)).max() < TIGHT
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32s", "bf16"])
 def test_reserve_makes_the_first_forward_capturable(torch_cuda, state1234, precision):
     """model.reserve(T, max_batch=B) pushes and packs the weights, sizes the PE table and the workspace: the module's
     VERY FIRST forward is captured into a HIP graph (nothing but its own kernels may be enqueued: a weight push or a
@@ -415,7 +492,7 @@ def test_odd_chunk_sizes(torch_cuda, model):
             model.precision = "fp32"
 
 
-def test_weight_update_is_seen(torch_cuda, state1234):
+def test_weight_update_is_seen(torch_cuda, state1234, fp32_mode):
     from oracle import oracle
     from voice_activity_detection_amd.seeded import seeded_state_dict
 
@@ -435,23 +512,31 @@ def test_weight_update_is_seen(torch_cuda, state1234):
 
 
 @pytest.mark.parametrize("tag,n,seed", [("g5", 1022, 500), ("g5b", 2100, 501), ("g5c", 39, 502)])
-def test_predictor_level_golden(torch_cuda, model, golden, tag, n, seed):
+def test_predictor_level_golden(torch_cuda, model, golden, tag, n, seed, fp32_mode):
     from voice_activity_detection_amd import VADFromScratchPredictor
 
-    pred = VADFromScratchPredictor(model, "cuda")
-    assert pred.context_window_frames == 7
-    feat = feats(seed, (n, 80))
-    probs = pred.predict_probabilities(feat)
-    assert probs.shape == golden[f"{tag}_probs"].shape and probs.dtype == np.float32
-    assert np.abs(probs - golden[f"{tag}_probs"]).max() < TIGHT
-    assert (probs == 0.5).sum() == (golden[f"{tag}_probs"] == 0.5).sum()  # unfilled slots: exactly 0.5
-    assert np.abs(pred.predict_boosted(feat) - golden[f"{tag}_mean"]).max() < TIGHT
-    # chunking is an implementation detail: one big chunk gives the same answer
-    big = VADFromScratchPredictor(model, "cuda", chunk_size=1 << 20)
-    assert np.abs(big.predict_probabilities(feat) - probs).max() < 1e-6
+    model.precision = fp32_mode
+    try:
+        pred = VADFromScratchPredictor(model, "cuda")
+        assert pred.context_window_frames == 7
+        feat = feats(seed, (n, 80))
+        probs = pred.predict_probabilities(feat)
+        assert probs.shape == golden[f"{tag}_probs"].shape and probs.dtype == np.float32
+        assert np.abs(probs - golden[f"{tag}_probs"]).max() < TIGHT
+        assert (probs == 0.5).sum() == (golden[f"{tag}_probs"] == 0.5).sum()  # unfilled slots: exactly 0.5
+        assert np.abs(pred.predict_boosted(feat) - golden[f"{tag}_mean"]).max() < TIGHT
+        # chunking is an implementation detail: one big chunk gives the same answer
+        big = VADFromScratchPredictor(model, "cuda", chunk_size=1 << 20)
+        assert np.abs(big.predict_probabilities(feat) - probs).max() < 1e-6
+        if fp32_mode == "fp32s":   # ... and so is the kernel: the fp32s single launch forced (automatic below 384 packed blocks: exact fp32)
+            model.row_mode = 4
+            forced = VADFromScratchPredictor(model, "cuda").predict_probabilities(feat)
+            assert np.abs(forced - golden[f"{tag}_probs"]).max() < TIGHT and (forced == 0.5).sum() == (golden[f"{tag}_probs"] == 0.5).sum()
+    finally:
+        model.precision, model.row_mode = "fp32", 0
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32s", "bf16"])
 def test_one_call_predictor_matches_the_three_entry_points(torch_cuda, model, precision):
     """savad_predict_probabilities (windows read straight out of the feature matrix by the single-launch forward, boosted
     prediction as a gather) against savad_gather_windows + savad_forward + savad_boost: the same bits -- whole clips, a clip
@@ -468,6 +553,11 @@ def test_one_call_predictor_matches_the_three_entry_points(torch_cuda, model, pr
             p1, m1 = pred.predict_probabilities_device(feat)
             p0, m0 = pred.predict_probabilities_device_stepwise(feat)
             torch.cuda.synchronize()
+            if precision == "fp32s":
+                # the one call picks its kernel by the CLIP's window count, the stepwise forwards by the chunk's (exact-fp32 kernels below
+                # 384 packed blocks, split-bf16 above): two fp32-parity kernels, equal to fp32 rounding
+                assert p1.shape == p0.shape == (n, 7) and float((p1 - p0).abs().max()) < 2e-6 and torch.equal(p1 == 0.5, p0 == 0.5), (n, chunk)
+                continue
             assert p1.shape == p0.shape == (n, 7) and torch.equal(p1, p0) and torch.equal(m1, m0), (n, chunk)
         big = VADFromScratchPredictor(model, "cuda")
         model.row_mode = 4  # force the windowed single launch beyond its automatic range: 4096-window launches
@@ -476,7 +566,7 @@ def test_one_call_predictor_matches_the_three_entry_points(torch_cuda, model, pr
             p1, _ = big.predict_probabilities_device(feat)
             model.row_mode = 0
             p0, _ = big.predict_probabilities_device_stepwise(feat)
-            assert float((p1 - p0).abs().max()) < (2e-6 if precision == "fp32" else 1e-2)
+            assert float((p1 - p0).abs().max()) < (2e-6 if precision != "bf16" else 1e-2)
         finally:
             model.row_mode = 0
         assert pred.predict_probabilities(np.zeros((0, 80), np.float32)).shape == (0, 7)
@@ -484,7 +574,7 @@ def test_one_call_predictor_matches_the_three_entry_points(torch_cuda, model, pr
         model.precision = "fp32"
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32s", "bf16"])
 def test_reference_mode_one_hour_full_size(torch_cuda, model, state1234, precision):
     """The reference's OWN mode at configs[4]'s size: an hour of audio = 360 001 feature frames -> 359 963 windows of 7 frames
     (vad/predictor.py:169-224) -> boosted probabilities [N,7], in ONE library call (bf16: one launch over all 89 991 packed blocks,
@@ -508,7 +598,7 @@ def test_reference_mode_one_hour_full_size(torch_cuda, model, state1234, precisi
     assert p1.shape == (N, 7) and torch.equal(p1, p0) and torch.equal(m1, m0)
     got = p1.cpu().numpy()
     assert np.isfinite(got).all() and (got >= 0).all() and (got <= 1).all()
-    tol = 3e-5 if precision == "fp32" else 6e-3
+    tol = 3e-5 if precision != "bf16" else 6e-3
     for lo in (0, 123_456, N - 400):   # the head (placeholders in the first 19 frames), the middle, the tail
         hi = min(N, lo + 400)
         a, b = max(0, lo - 38), min(N, hi + 38)
@@ -583,14 +673,18 @@ def test_c_abi_error_behaviour(torch_cuda):
 
 
 @pytest.mark.parametrize("n,T,hop", [(3000, 800, 400), (801, 800, 400), (500, 800, 400), (1234, 96, 32), (1601, 800, 400)])
-def test_streaming_long_form(torch_cuda, model, state1234, n, T, hop):
+def test_streaming_long_form(torch_cuda, model, state1234, n, T, hop, fp32_mode):
     """BASELINE configs[4] (sliding windows T=800 hop=400, overlap-averaged): HIP path vs the oracle."""
     from oracle import oracle
     from voice_activity_detection_amd import StreamingPredictor
 
     feat = feats(1000 + n, (n, 80))
     ref, _ = oracle.predict_streaming(state1234, feat, T, hop)
-    got = StreamingPredictor(model, "cuda", T, hop, max_batch=3).predict(feat)
+    model.precision = fp32_mode
+    try:
+        got = StreamingPredictor(model, "cuda", T, hop, max_batch=3).predict(feat)
+    finally:
+        model.precision = "fp32"
     assert got.shape == (n,) and np.abs(got - ref).max() < TIGHT
 
 
@@ -1137,7 +1231,7 @@ def test_logmel_one_hour_matches_oracle_on_stretches(torch_cuda):
         assert d.max() < 5e-4 and np.median(d) < 2e-6, (f0, d.max(), np.median(d))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32s", "bf16"])
 def test_streaming_windows_in_place_and_audio_sharding(torch_cuda, model, precision):
     """configs[4], round 5: (a) the streaming windows are read IN PLACE out of the feature matrix (savad_forward_strided: sequences
     hop * F elements apart) -- the same bits as the window copies of savad_gather_strided + savad_forward; (b) the audio-level entry
@@ -1181,7 +1275,7 @@ def test_streaming_windows_in_place_and_audio_sharding(torch_cuda, model, precis
                         ref = [model(features=win[b:min(b + 3, hi)]) for b in range(lo, hi, 3)]
                     assert part.shape[0] == hi - lo and (hi == lo or torch.equal(part, torch.cat(ref))), (n, world, r)
                 # against ONE batch of all windows: equal up to the batch-size dependent launch shapes (key splits: fp32 summation order)
-                assert float((torch.cat(parts) - want).abs().max()) < (1e-5 if precision == "fp32" else 1e-2), (n, world)
+                assert float((torch.cat(parts) - want).abs().max()) < (1e-5 if precision != "bf16" else 1e-2), (n, world)
                 assert plans[0][1] == 0 and plans[-1][2] == W and all(a[2] == b[1] for a, b in zip(plans, plans[1:]))
                 assert all(p[6] <= 160 * (p[4] - p[3]) + 512 + 3 for p in plans)   # a rank's samples: its frames + the halo, not the recording
             assert torch.equal(sp.predict_audio_device(audio), whole)
@@ -1368,7 +1462,7 @@ def test_config3_size_batch(torch_cuda, model, state1234):
     assert np.array_equal(run(torch_cuda, model, x2)[200], y[3])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32s", "bf16"])
 def test_config4_one_hour_stream_full_size(torch_cuda, model, state1234, precision):
     """BASELINE configs[4] at its FULL size on one GPU: 1 h of audio = 360 001 frames -> 900 windows (T=800, hop=400,
     zero-padded tail) -> per-frame probabilities.  Size-independent properties on the whole hour, and three stretches
@@ -1388,7 +1482,7 @@ def test_config4_one_hour_stream_full_size(torch_cuda, model, state1234, precisi
         torch.cuda.synchronize()
         assert torch.equal(p, p2)  # deterministic
         other = StreamingPredictor(model, "cuda", T, hop, max_batch=225).predict_device(fd)  # 900 = 4 x 225: other chunking
-        if precision == "fp32":
+        if precision != "bf16":
             assert torch.equal(other, p)  # a window's result does not depend on its batch slot or on the chunking
         else:
             # bf16: automatic picks the persistent attention kernel or the first-generation one by batch size (savad.hip, pw_pays);
@@ -1410,7 +1504,7 @@ def test_config4_one_hour_stream_full_size(torch_cuda, model, state1234, precisi
         model.precision = "fp32"
     ph = p.cpu().numpy()
     assert ph.shape == (N,) and np.isfinite(ph).all() and ph.min() >= 0.0 and ph.max() <= 1.0
-    tol = TIGHT if precision == "fp32" else 1e-2
+    tol = TIGHT if precision != "bf16" else 1e-2
     # head: frames [0, 1600) of the slice feat[0:2000] see the same windows as in the full hour
     ref, _ = oracle.predict_streaming(state1234, feat[:2000], T, hop)
     assert np.abs(ph[:1600] - ref[:1600]).max() < tol
@@ -1488,10 +1582,9 @@ def test_other_model_width_paths(torch_cuda):
     g.replay()
     torch.cuda.synchronize()
     assert np.abs(out.cpu().numpy() - oracle.forward(st, xs.cpu().numpy())).max() < TIGHT
-    m.precision = "bf16"
-    with pytest.raises(SavadError, match="d_model=128"):
-        run(torch, m, x)
-    m.precision = "fp32"
+    for prec in ("bf16", "fp32s"):   # both need the d_model = 128 kernels
+        with pytest.raises(SavadError, match="d_model=128"):
+            run(torch, m, x, precision=prec)
 
 
 def test_randomised_sweep(torch_cuda):
@@ -1520,7 +1613,7 @@ def test_c_client_of_the_abi(torch_cuda, tmp_path):
     assert r.returncode == 0 and r.stdout.startswith("ok "), (r.returncode, r.stdout, r.stderr)
 
 
-@pytest.mark.parametrize("precision,depth", [("fp32", 3), ("fp32", 2), ("bf16", 2), ("fp32", 1)])
+@pytest.mark.parametrize("precision,depth", [("fp32", 3), ("fp32", 2), ("bf16", 2), ("fp32", 1), ("fp32s", 3), ("fp32s", 1)])
 def test_pipelined_forwards_are_the_modules_bits(torch_cuda, state1234, precision, depth):
     """PipelinedVAD: `depth` independent forwards in flight (own stream / handle / workspace each, shared parameters) return what the
     module returns, bit for bit -- different inputs and shapes interleaved, inputs produced on the caller's stream right before

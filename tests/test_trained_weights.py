@@ -82,25 +82,31 @@ def model(torch_cuda, trained):
 
 
 @pytest.mark.gpu
-def test_fp32_logprobs_match_the_reference_on_trained_weights(torch_cuda, model, trained):
+@pytest.mark.parametrize("precision,row_mode", [("fp32", 0), ("fp32s", 0), ("fp32s", 4), ("fp32s", 1)])
+def test_fp32_logprobs_match_the_reference_on_trained_weights(torch_cuda, model, trained, precision, row_mode):
     """north_star: per-frame log-probs within 1e-4 of the reference's, here on a trained model's peaked outputs: the clip's windows
-    as a batch (single launch), through the windowed predictor, and as 800-frame sequences against the oracle"""
+    as a batch (single launch), through the windowed predictor, and as 800-frame sequences against the oracle -- with the exact-fp32
+    MFMA and with the split-bf16 operands of precision "fp32s" (automatic schedule, its single launch forced, its per-layer launches)"""
     from oracle import oracle
     from voice_activity_detection_amd import VADFromScratchPredictor
 
     torch = torch_cuda
     state, clip_logp, clip_probs, _ = trained
     _, feat, _ = recording(2)
-    with torch.no_grad():
-        y = model(features=torch.from_numpy(clip_windows(feat)).cuda()).cpu().numpy()
-    assert np.abs(y - clip_logp).max() < 1e-4, np.abs(y - clip_logp).max()
-    probs = VADFromScratchPredictor(model, "cuda").predict_probabilities(feat)
-    assert np.abs(probs - clip_probs).max() < 1e-4 and np.array_equal(probs == 0.5, clip_probs == 0.5)
-    _, feat93, _ = recording(0)
-    x = np.ascontiguousarray(feat93[:6400].reshape(8, 800, 80))
-    with torch.no_grad():
-        y800 = model(features=torch.from_numpy(x).cuda()).cpu().numpy()
-    assert np.abs(y800 - oracle.forward(state, x, threads=8)).max() < 1e-4
+    model.precision, model.row_mode = precision, row_mode
+    try:
+        with torch.no_grad():
+            y = model(features=torch.from_numpy(clip_windows(feat)).cuda()).cpu().numpy()
+        assert np.abs(y - clip_logp).max() < 1e-4, np.abs(y - clip_logp).max()
+        probs = VADFromScratchPredictor(model, "cuda").predict_probabilities(feat)
+        assert np.abs(probs - clip_probs).max() < 1e-4 and np.array_equal(probs == 0.5, clip_probs == 0.5)
+        _, feat93, _ = recording(0)
+        x = np.ascontiguousarray(feat93[:6400].reshape(8, 800, 80))
+        with torch.no_grad():
+            y800 = model(features=torch.from_numpy(x).cuda()).cpu().numpy()
+        assert np.abs(y800 - oracle.forward(state, x, threads=8)).max() < 1e-4
+    finally:
+        model.precision, model.row_mode = "fp32", 0
 
 
 @pytest.mark.gpu
@@ -119,13 +125,13 @@ def test_auc_parity_on_trained_weights(torch_cuda, model, trained):
         feat = log_mel(audio)
         n = len(labels)
         aucs = {}
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", "fp32s", "bf16"):
             model.precision = prec
             try:
                 aucs[prec] = roc_auc(labels, pred.predict_probabilities(feat).mean(axis=1)[:n])
             finally:
                 model.precision = "fp32"
-        assert abs(aucs["fp32"] - auc_ref[i]) < 1e-3 and abs(aucs["bf16"] - auc_ref[i]) < 1e-3, (i, auc_ref[i], aucs)
+        assert all(abs(aucs[prec] - auc_ref[i]) < 1e-3 for prec in aucs), (i, auc_ref[i], aucs)
     assert model.residual_saturations() == 0
 
 
