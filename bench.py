@@ -62,12 +62,13 @@ def flops_per_frame(T: int) -> float:
 # chain 295 424 (classifier instead of QKV), input stage 118 784.  Bytes: what the launch must read + write in HBM.
 def launch_work(name: str, B: int, T: int, e: int):
     """name = launch label reported by the library -> (FLOP, algorithmic HBM bytes) of one launch; e = bytes per
-    element of q/k/v/context (4 fp32, 2 bf16).  The residual stream is fp32 in the fp32 path, fp16 in the bf16 path."""
+    element of q/k/v/context (4 fp32, 2 bf16, 6 fp32s: three bf16 pieces).  The residual stream is fp32 in the fp32 and fp32s paths,
+    fp16 in the bf16 path.  FLOPs are ALGORITHMIC (fp32s issues six bf16 MFMA products per algorithmic multiply-add)."""
     D, F = D_MODEL, F_MEL
     frames = B * T
     att = 4.0 * T * T * D * B
-    hres = 4 if e == 4 else 2
-    base = name.replace("_bf16", "")
+    hres = 2 if e == 2 else 4
+    base = name.replace("_bf16", "").replace("_f32s", "")
     if base == "attention":
         return att, frames * 4 * D * e                                   # Q, K, V read + context written
     if base == "attention_row":
@@ -79,7 +80,7 @@ def launch_work(name: str, B: int, T: int, e: int):
     if base == "row_last":
         return 295424.0 * frames, frames * (D * e + 8 + D * hres + 8)
     if base == "input_qkv":
-        return 118784.0 * frames, frames * (F * e + D * hres + 3 * D * e)
+        return 118784.0 * frames, frames * (F * (4 if e == 6 else e) + D * hres + 3 * D * e)
     if base == "packed_forward":  # whole forward in one launch (T <= 32): features in, log-probs out
         return flops_per_frame(T) * frames, frames * (F * 4 + 8)   # (the windows are fp32 features in both precisions)
     return 0.0, 0
@@ -104,7 +105,9 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     bench line) or bf16 [256,800] -- and (b) the profile was taken on exactly the kernel sources that are
     running now (`csrc_hash` stored in the file); otherwise null."""
     if (precision, B, T) == ("fp32", 32, 800):
-        files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if not any(t in f.name for t in ("bf16", "t7", "t50", "logmel"))]
+        files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if not any(t in f.name for t in ("bf16", "t7", "t50", "logmel", "fp32s"))]
+    elif (precision, B, T) == ("fp32s", 32, 800):
+        files = sorted((REPO / "profiles").glob("*fp32s_traffic.json"))
     elif (precision, B, T) == ("bf16", 256, 800):
         files = sorted((REPO / "profiles").glob("*bf16_b256_traffic.json"))
     elif (precision, B, T) == ("fp32", 1000, 7):
@@ -120,7 +123,8 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     data = json.loads(files[-1].read_text())
     last = name.endswith("_last") or name.endswith("_last_bf16")
     stem = name.replace("_last", "")
-    prefix = {"attention": "attention_kernel", "attention_row": "attention_row_kernel", "row": "row_kernel", "input_qkv": "input_qkv_kernel",
+    prefix = {"attention_row_f32s": "attention_row_kernel_f32s", "input_qkv_f32s": "input_qkv_kernel_f32s",
+              "packed_forward_f32s": "packed_forward_kernel_f32s", "attention": "attention_kernel", "attention_row": "attention_row_kernel", "row": "row_kernel", "input_qkv": "input_qkv_kernel",
               "attention_bf16": "attention", "row_bf16": "row_kernel_bf16", "input_qkv_bf16": "input_qkv_kernel_bf16",
               "attention_row_bf16": "attention_row_kernel_bf16", "packed_forward": "packed_forward_kernel",
               "packed_forward_bf16": "packed_forward_kernel_bf16"}.get(stem)
@@ -180,7 +184,9 @@ def rocprof_averages(precision, B, T):
     """{kernel short name: average ns} of the committed rocprofv3 --kernel-trace --stats run of this workload
     (profiles/*_kernel_avg.json, written by scripts/summarize_profile.py), only when taken on the running kernel sources."""
     if (precision, B, T) == ("fp32", 32, 800):
-        files = [f for f in sorted((REPO / "profiles").glob("*_kernel_avg.json")) if not any(t in f.name for t in ("bf16", "_t7_", "_t50_", "logmel"))]
+        files = [f for f in sorted((REPO / "profiles").glob("*_kernel_avg.json")) if not any(t in f.name for t in ("bf16", "_t7_", "_t50_", "logmel", "fp32s"))]
+    elif (precision, B, T) == ("fp32s", 32, 800):
+        files = sorted((REPO / "profiles").glob("*fp32s_kernel_avg.json"))
     elif (precision, B, T) == ("bf16", 256, 800):
         files = [f for f in sorted((REPO / "profiles").glob("*bf16_kernel_avg.json")) if "t7" not in f.name]
     elif (precision, B, T) == ("fp32", 1000, 7):
@@ -201,6 +207,8 @@ def rocprof_averages(precision, B, T):
 
 
 ROCPROF_NAMES = {  # bench launch label -> kernel short name in the rocprofv3 stats (fp32 M-split / fused regime, bf16 4-wave kernels)
+    "attention_row_f32s": "attention_row_kernel_f32s<false, false>", "attention_row_last_f32s": "attention_row_kernel_f32s<true, false>",
+    "input_qkv_f32s": "input_qkv_kernel_f32s", "packed_forward_f32s": "packed_forward_kernel_f32s",
     "attention_row": "attention_row_kernel<false>", "attention_row_last": "attention_row_kernel<true>",
     "input_qkv": "input_qkv_kernel_m", "packed_forward": "packed_forward_kernel",
     "attention_bf16": ("attention_pw_kernel_bf16", "attention_kernel_bf16<4>"), "row_bf16": "row_kernel_bf16<false, 4>", "row_last_bf16": "row_kernel_bf16<true, 4>",
@@ -482,10 +490,18 @@ class Runner:
 
 
 def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False, ms_one_forward=None):
-    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
-    e = 2 if precision == "bf16" else 4
-    fwd_tflops = flops_per_frame(T) * B * T / (ms_forward * 1e-3) / 1e12
-    one_tflops = flops_per_frame(T) * B * T / ((ms_one_forward or ms_forward) * 1e-3) / 1e12
+    """precision "fp32s" computes the fp32 arithmetic on the bf16 matrix pipe: every algorithmic multiply-add is SIX bf16 MFMA products
+    (three-piece operands).  Its `achieved` / `frac` are the ISSUED bf16 FLOPs (6 x algorithmic) against the 2.5 PF bf16 peak -- the roof
+    that binds it -- and `fp32_equivalent_tflops` = algorithmic FLOPs / time, which may exceed the 157.3 TF fp32-MFMA peak: that is the
+    point of the mode.  A launch that ran the exact-fp32 kernels (fp32s picks them for small T <= 32 batches) is priced as fp32."""
+    exact = precision == "fp32s" and ktimes and not any(n.endswith("_f32s") for n, _ in ktimes)
+    if exact:
+        precision = "fp32"
+    peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    issue = 6.0 if precision == "fp32s" else 1.0   # MFMA FLOPs issued per algorithmic FLOP
+    e = {"bf16": 2, "fp32s": 6}.get(precision, 4)
+    fwd_tflops = issue * flops_per_frame(T) * B * T / (ms_forward * 1e-3) / 1e12
+    one_tflops = issue * flops_per_frame(T) * B * T / ((ms_one_forward or ms_forward) * 1e-3) / 1e12
     if not ktimes:
         return {"bound": "mfma", "forward_achieved": round(fwd_tflops, 2), "forward_frac": round(fwd_tflops / peak, 4),
                 "forward_frac_one_forward": round(one_tflops / peak, 4), "peak": peak, "unit": "TFLOP/s"}
@@ -496,23 +512,33 @@ def roofline_block(ktimes, precision, B, T, ms_forward, profiled_shape=False, ms
     dom = max(by_name, key=lambda n: sum(by_name[n]))
     dom_ms = sum(by_name[dom]) / len(by_name[dom])
     dom_flops, dom_bytes = launch_work(dom, B, T, e)
-    ach = dom_flops / (dom_ms * 1e-3) / 1e12
+    ach = issue * dom_flops / (dom_ms * 1e-3) / 1e12
     per_kernel = {}
     prof_avg, prof_file = rocprof_averages(precision, B, T) if profiled_shape else ({}, None)
     for n, ts in by_name.items():
         fl, by = launch_work(n, B, T, e)
         ms_k = sum(ts) / len(ts)
-        per_kernel[n] = {"launches": len(ts), "ms": round(ms_k, 4), "tflops": round(fl / (ms_k * 1e-3) / 1e12, 2),
-                         "frac": round(fl / (ms_k * 1e-3) / 1e12 / peak, 4),
+        per_kernel[n] = {"launches": len(ts), "ms": round(ms_k, 4), "tflops": round(issue * fl / (ms_k * 1e-3) / 1e12, 2),
+                         "frac": round(issue * fl / (ms_k * 1e-3) / 1e12 / peak, 4),
                          "hbm_frac": round(by / (ms_k * 1e-3) / 1e12 / PEAK_HBM_TBPS, 4)}
         cands = ROCPROF_NAMES.get(n, ())
         ref_ns = next((prof_avg[c] for c in ((cands,) if isinstance(cands, str) else cands) if c in prof_avg), None)
         if ref_ns:  # this run's HIP-event duration over the committed rocprofv3 average of the same kernel on the same sources
             per_kernel[n]["rocprof_ms"] = round(ref_ns * 1e-6, 4)
             per_kernel[n]["event_over_rocprof"] = round(ms_k / (ref_ns * 1e-6), 3)
+    f32s = {}
+    if precision == "fp32s":
+        f32s = {"issued_over_algorithmic_flops": 6,
+                "fp32_equivalent_tflops": round(dom_flops / (dom_ms * 1e-3) / 1e12, 2),
+                "fp32_equivalent_over_fp32_mfma_peak": round(dom_flops / (dom_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "forward_fp32_equivalent_tflops": round(fwd_tflops / 6, 2), "forward_fp32_equivalent_tflops_one_forward": round(one_tflops / 6, 2),
+                "note": "achieved / frac / peak: ISSUED bf16 MFMA FLOPs (six products per algorithmic multiply-add) against the dense bf16 peak; "
+                        "fp32_equivalent_*: algorithmic FLOPs / time -- above the 157.3 TF fp32-MFMA peak by design"}
+    elif exact:
+        f32s = {"note": "precision fp32s ran the exact-fp32 kernels at this shape (small T <= 32 batch): priced against the fp32 MFMA peak"}
     return {
         "bound": "mfma", "kernel": f"{dom} ({len(by_name[dom])} launches per forward)",
-        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), **f32s,
         "traffic": measured_traffic(dom, precision, B, T),
         "traffic_unit": "bytes/launch (rocprofv3 PMC pass under profiles/, quoted only when its csrc_hash matches the running kernels)",
         "traffic_note": traffic_note(dom, precision, B, T),
@@ -717,18 +743,27 @@ def reference_mode_hour(state, dev, min_seconds):
     res = {"workload": f"reference mode, {seconds} s of audio on ONE GPU: feature matrix [{N},80] -> {windows} windows of 7 frames "
                        "(vad/predictor.py:169-224) -> forward -> boosted probabilities [N,7] (:238-258)", "audio_seconds": seconds,
            "frames": N, "windows": windows, "flops": windows * 7 * flops_per_frame(7)}
-    for prec in ("fp32", "bf16"):
+    ref32 = None
+    for prec in ("fp32", "fp32s", "bf16"):
         model.precision = prec
         pred = VADFromScratchPredictor(model, dev)
         med, mn, blocks, out = _event_blocks(lambda: pred.predict_probabilities_device(feat), 1 if prec == "fp32" else 4, min_seconds, warm=2)
         probs = out[0]
-        peak = PEAK_BF16_MFMA_TFLOPS if prec == "bf16" else PEAK_FP32_MFMA_TFLOPS
-        tf = res["flops"] / (med * 1e-3) / 1e12
+        peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        issue = 6.0 if prec == "fp32s" else 1.0   # fp32s: six bf16 MFMA products per algorithmic multiply-add
+        tf = issue * res["flops"] / (med * 1e-3) / 1e12
         res[prec] = {"ms_per_hour_of_audio": round(med, 4), "ms_min": round(mn, 4), "blocks": blocks, "rtf": round(med * 1e-3 / seconds, 10),
                      "windows_per_s": round(windows / (med * 1e-3), 1), "window_frames_per_s": round(windows * 7 / (med * 1e-3), 1),
                      "audio_frames_per_s": round(N / (med * 1e-3), 1),
                      "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
                      "finite": bool(torch.isfinite(probs).all().item())}
+        if prec == "fp32":
+            ref32 = probs.clone()
+        else:   # against the exact-fp32 run of the same call (fp32s: the fp32 bar; bf16: reported)
+            res[prec]["max_abs_dprob_vs_fp32"] = float((probs - ref32).abs().max())
+        if prec == "fp32s":
+            res[prec]["roofline"]["fp32_equivalent_tflops"] = round(tf / 6, 1)
+            res[prec]["within_1e-4_of_fp32"] = res[prec]["max_abs_dprob_vs_fp32"] < 1e-4
     model.precision = "fp32"
     return res
 
@@ -795,7 +830,7 @@ def stream_one_hour(state, dev, min_seconds):
     res = {"workload": f"BASELINE configs[4] on ONE GPU: {seconds} s of 16 kHz audio -> log-mel [{N},80] -> 900 windows T=800 hop=400 -> "
                        "forward -> overlap merge -> probabilities", "audio_seconds": seconds, "frames": N,
            "logmel_ms": round(mel_med, 4), "logmel_ms_min": round(mel_min, 4), "logmel_roofline": logmel_roofline(audio.numel(), N, mel_med)}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "fp32s", "bf16"):
         model.precision = prec
         sp = StreamingPredictor(model, dev, 800, 400, max_batch=256)
         med, mn, blocks, probs = _event_blocks(lambda: sp.predict_device(feat), 2 if prec == "fp32" else 8, min_seconds, warm=2)
@@ -813,14 +848,81 @@ def stream_one_hour(state, dev, min_seconds):
 
 def workload_label(precision, B, T):
     if (precision, B, T) == ("fp32", 32, 800):
-        tag = "BASELINE configs[1]"
+        tag = "BASELINE configs[1], exact-fp32 MFMA"
+    elif (precision, B, T) == ("fp32s", 32, 800):
+        tag = "BASELINE configs[1], fp32 arithmetic as split-bf16 operands (fp32s)"
     elif (precision, B, T) == ("bf16", 256, 800):
         tag = "BASELINE configs[2] (= the per-GPU shard of configs[3])"
-    elif (precision, T) == ("fp32", 7):
+    elif precision in ("fp32", "fp32s") and T == 7:
         tag = "the reference pipeline's window shape (vad/predictor.py:180-224)"
     else:
         tag = "custom shape"
     return f"{tag}: synthetic [B={B}, T={T}, F={F_MEL}] {precision} per GPU, SelfAttentiveVAD(80, 3, 128) forward -> log-probs [B,T,2]"
+
+
+DTYPE_LABEL = {"fp32": "f32", "fp32s": "f32 (bf16x6 split operands, f32 accumulate)", "bf16": "bf16 operands, f32 accumulate"}
+
+
+def collect_flags(obj, path=""):
+    """every self-check flag in a (nested) result: keys `finite`, `in_unit_interval`, `within_*` and `*equals*` -> {path: bool}"""
+    flags = {}
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            here = f"{path}.{k}" if path else k
+            if isinstance(v, bool) and (k in ("finite", "in_unit_interval") or "equals" in k or k.startswith("within_")):
+                flags[here] = v
+            elif isinstance(v, dict):
+                flags.update(collect_flags(v, here))
+    return flags
+
+
+def bench_summary(line, flags):
+    """{leg: {ms, frac}} for the headline and every secondary leg + the self-check flags, compact enough for a log's tail"""
+    def pair(ms, frac):
+        return {"ms": ms, "frac": frac}
+
+    rl = line.get("roofline", {})
+    out = {"headline": pair(line.get("ms_per_step"), rl.get("forward_frac")),
+           "headline_one_forward": pair(line.get("ms_one_forward"), rl.get("forward_frac_one_forward")),
+           "headline_dominant_kernel": pair(rl.get("ms_per_launch"), rl.get("frac"))}
+    if "fp32_equivalent_tflops" in rl:
+        out["headline_fp32_equivalent_tflops"] = {"forward": rl.get("forward_fp32_equivalent_tflops"), "one_forward": rl.get("forward_fp32_equivalent_tflops_one_forward"),
+                                                  "dominant_kernel": rl.get("fp32_equivalent_tflops")}
+    legs = dict(line.get("secondary", {}))
+    for k in ("config3", "config4"):
+        if k in line:
+            legs[k] = line[k]
+    for k, v in legs.items():
+        if not isinstance(v, dict):
+            continue
+        if "error" in v:
+            out[k] = {"error": str(v["error"])[:80]}
+        elif "ms_per_step" in v:
+            r2 = v.get("roofline", {})
+            out[k] = pair(v["ms_per_step"], r2.get("forward_frac"))
+            out[k]["ms_one_forward"] = v.get("ms_per_step_one_in_flight")
+        elif "ms_per_pass" in v:
+            out[k] = pair(v["ms_per_pass"], v.get("forward_frac_of_bf16_peak"))
+        elif "ms_per_clip" in v:
+            out[k] = {"ms": v["ms_per_clip"], **{kk: vv for kk, vv in v.items() if kk.endswith("_ms_per_clip")}}
+        else:   # per-precision legs (the reference-mode hour, the streamed hour)
+            sub = {}
+            for prec in ("fp32", "fp32s", "bf16"):
+                if isinstance(v.get(prec), dict):
+                    d = v[prec]
+                    ms = d.get("ms_per_hour_of_audio", d.get("ms_per_hour_of_audio_from_host_audio"))
+                    sub[prec] = pair(ms, d.get("roofline", {}).get("frac"))
+                    if "from_audio_ms" in d:
+                        sub[prec]["from_audio_ms"] = d["from_audio_ms"]
+            if "logmel_ms" in v:
+                sub["logmel"] = pair(v["logmel_ms"], v.get("logmel_roofline", {}).get("hbm_frac"))
+            if sub:
+                out[k] = sub
+    false = sorted(k for k, ok_ in flags.items() if not ok_)
+    out["flags_checked"] = len(flags)
+    out["false_flags"] = false
+    out["all_flags_true"] = not false
+    return out
 
 
 def summarize(walls, evs, steps, frames_per_step):
@@ -840,8 +942,11 @@ def main():
     ap.add_argument("--frames", type=int, default=800, help="T")
     ap.add_argument("--splits", type=int, default=0, help="attention key splits (0 = auto)")
     ap.add_argument("--row-mode", type=int, default=0, help="launch schedule knob (include/savad.h: savad_set_row_mode), 0 = automatic")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 = BASELINE configs[1] (default); bf16 = configs[2]: bf16 MFMA operands, bf16 features")
+    ap.add_argument("--precision", default="fp32s", choices=["fp32", "fp32s", "bf16"],
+                    help="fp32s (default) = BASELINE configs[1], the fp32 arithmetic on the bf16 matrix pipe (three-piece operands, six MFMA products, "
+                         "fp32 accumulate: the same 1e-4 parity bar as fp32); fp32 = the same config on the exact-fp32 MFMA; bf16 = configs[2]: "
+                         "bf16 MFMA operands, bf16 features")
+    ap.add_argument("--plant-false-flag", action="store_true", help=argparse.SUPPRESS)  # tests: a planted failing self-check must fail the run
     ap.add_argument("--min-seconds", type=float, default=0.5, help="timed work per measurement, in K-step blocks")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -976,6 +1081,7 @@ def main():
                 r.drain()
                 r.sp.set_in_flight(tuned)
             kt = [] if args.no_events else r.kernel_profile(10, s1["ms_per_step"])
+            delivered = r.delivered()   # BEFORE the batch-invariant timing below: that mode's last output differs from a default forward by design
             if prec == "bf16" and t2 > 32 and not stub and r.model is not None:
                 # the price of model.batch_invariant (savad_set_batch_invariant: the persistent attention kernel without key-split tail
                 # items, every batching the same bits), one forward at a time, same run
@@ -992,7 +1098,7 @@ def main():
             s.update({"workload": workload_label(prec, b2, t2), "global_batch": world * b2, "unit": "frames/s",
                       "in_flight": r.sp.in_flight, "in_flight_tuning_ms": r.tuning,
                       "ms_per_step_one_in_flight": s1["ms_per_step"], "value_one_in_flight": s1["value"],
-                      "finite": r.delivered(),
+                      "finite": delivered,
                       "roofline": roofline_block(kt, prec, b2, t2, s["ms_per_step"], profiled_shape=True, ms_one_forward=s1["ms_per_step"])})
             if gm:
                 s["parallelism"] = (f"batch-shard x{world} + 1 RCCL all_gather of [{b2},{t2},2] f32 per forward" if gm == "step" else
@@ -1002,10 +1108,16 @@ def main():
 
     if not args.no_secondary:
         if world == 1 and not use_dist and not stub:
+            if (args.precision, B, T) != ("fp32", 32, 800):
+                leg("configs1_exact_fp32_b32_t800", shape_leg("fp32", 32, 800, None))   # the same config on the exact-fp32 MFMA (rounds 1-5's headline)
+            if (args.precision, B, T) != ("fp32s", 32, 800):
+                leg("configs1_fp32s_b32_t800", shape_leg("fp32s", 32, 800, None))
             if (args.precision, B, T) != ("bf16", 256, 800):
                 leg("configs2_bf16_b256_t800", shape_leg("bf16", 256, 800, None))
             if (args.precision, B, T) != ("fp32", 1000, 7):
                 leg("pipeline_fp32_b1000_t7", shape_leg("fp32", 1000, 7, None))
+            leg("pipeline_fp32s_b16384_t7", shape_leg("fp32s", 16384, 7, None))   # the predictor's default chunk of windows: the fp32s single launch
+            leg("pipeline_fp32_b16384_t7", shape_leg("fp32", 16384, 7, None))
             if (args.precision, B, T) != ("bf16", 1000, 7):
                 leg("pipeline_bf16_b1000_t7", shape_leg("bf16", 1000, 7, None))
             leg("reference_mode_1h", lambda: reference_mode_hour(state, dev, args.min_seconds))
@@ -1025,21 +1137,24 @@ def main():
         all_counts = [None] * world
         dist.all_gather_object(all_counts, counts)
 
+    all_ok = True
     if rank == 0:
         one_fwd = one or head
         line = {
-            "metric": "audio frames/sec (whole node)", "value": head["value"], "unit": "frames/s",
+            "metric": "audio frames/sec (whole node)", "value": head["value"],
+            # SURVEY section 8d's own definition (wall time of ONE forward at a time) right beside the throughput figure `value`
+            "value_one_forward": one_fwd["value"], "ms_one_forward": one_fwd["ms_per_step"], "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "ms_per_step_min": head["ms_per_step_min"], "ms_per_step_hip_events_median": head["ms_per_step_hip_events_median"],
-            # SURVEY section 8d's own definition (wall time of ONE forward at a time) beside the throughput figure `value`
-            "value_one_forward": one_fwd["value"], "ms_one_forward": one_fwd["ms_per_step"],
             "timing": {"statistic": "median over blocks of exactly K steps (barrier + synchronize on both sides of every block; max over ranks)",
                        "blocks": head["blocks"], "timed_seconds": head["timed_seconds"],
                        "value_is": f"throughput with `in_flight` independent batches in flight; value_one_forward / ms_one_forward = one forward at a time"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate",
+            "dtype": DTYPE_LABEL[args.precision],
             "data": "synthetic (seeded U(-13.8,4.2) mel frames, seeded random-init weights)",
-            "config": {"workload": workload_label(args.precision, B, T), "global_batch": world * B, "frames_per_sequence": T,
+            "config": {"workload": workload_label(args.precision, B, T) + "; `value` = throughput with `in_flight` independent batches in flight, "
+                                   "`value_one_forward` / `ms_one_forward` = SURVEY.md section 8d's own definition (wall time of ONE forward at a time)",
+                       "global_batch": world * B, "frames_per_sequence": T,
                        "parallelism": f"batch-shard x{world}" + ((" + 1 RCCL all_gather of the [B,T,2] log-probs per forward" if args.gather == "step"
                                                                    else " + 1 RCCL all_gather of all K batches' log-probs per block") if use_dist else "")},
             "finite": ok,
@@ -1074,10 +1189,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not stub:
             line["cpu_baseline"] = cpu_baseline(state, B, T, args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+        # ---- every leg's self-checks folded into the top-level flag, and a compact summary as the LAST key of the line (the tail of the
+        # line is what a truncated log still shows): one {ms, frac} pair per BASELINE config / leg, every flag by name when it is false
+        if args.plant_false_flag:
+            line.setdefault("secondary", {})["planted"] = {"finite": False}
+        flags = collect_flags({k: v for k, v in line.items() if k != "finite"})
+        flags["headline.finite"] = bool(ok)
+        line["finite"] = all_ok = all(flags.values())
+        line["summary"] = bench_summary(line, flags)
         print(json.dumps(line), flush=True)
     if use_dist:
         vdist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not all_ok:
+        sys.exit(3)   # a self-check read false: the line above says which (summary.false_flags)
 
 
 if __name__ == "__main__":

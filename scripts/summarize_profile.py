@@ -15,11 +15,11 @@ def find(pattern):
 
 
 def short(name):
-    m = re.search(r"savad::(?:bf::|mel::)?(\w+)(<[^>]*>)?", name)
+    m = re.search(r"savad::(?:bf::|fs::|mel::)?(\w+)(<[^>]*>)?", name)
     if m:
         return m.group(1) + (m.group(2) or "")
     # rocprofv3 leaves some template instantiations mangled: _ZN5savad2bf15row_kernel_bf16ILb0ELi4EEEv...
-    m = re.match(r"_ZN5savad(?:2bf)?\d+([A-Za-z_0-9]+?)I((?:Lb[01]E|Li\d+E|DF16b|f)+)E", name)
+    m = re.match(r"_ZN5savad(?:2bf|2fs)?\d+([A-Za-z_0-9]+?)I((?:Lb[01]E|Li\d+E|DF16b|f)+)E", name)
     if m:
         args = []
         for a in re.findall(r"Lb[01]E|Li\d+E|DF16b|f", m.group(2)):

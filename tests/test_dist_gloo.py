@@ -307,3 +307,101 @@ def test_sharded_pipeline_without_a_process_group():
     sp.submit(torch.randn(4, 7, 80))       # another shape after a join: buffers follow
     assert tuple(sp.join()[0].shape) == (1, 4, 7, 2)
     assert collective_counts() == before
+
+
+def _bench_line(res):
+    import json
+
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_checks_fail_the_run(tmp_path):
+    """Every leg's self-check (`finite`, `*equals*`, `within_*`) is folded into the top-level `finite`, a compact `summary` is the LAST key
+    of the line (what a truncated log still shows), and a check that reads false ends the run with a non-zero exit code: planted here
+    (round 5's configs[2] leg printed finite = false and nothing noticed)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(repo / "bench.py"), "--gpus", "1", "--backend", "gloo", "--stub-forward", "--steps", "3", "--warmup", "1",
+           "--min-seconds", "0.01", "--batch", "2", "--frames", "40"]
+    ok = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    d = _bench_line(ok)
+    assert list(d)[-1] == "summary" and d["finite"] is True
+    assert d["summary"]["all_flags_true"] is True and d["summary"]["false_flags"] == [] and d["summary"]["flags_checked"] >= 1
+    assert list(d)[:4] == ["metric", "value", "value_one_forward", "ms_one_forward"] and "section 8d" in d["config"]["workload"]
+    assert {"headline", "headline_one_forward"} <= set(d["summary"])
+    bad = subprocess.run(cmd + ["--plant-false-flag"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=env)
+    assert bad.returncode == 3, (bad.returncode, bad.stderr[-2000:])
+    d = _bench_line(bad)
+    assert d["finite"] is False and d["summary"]["all_flags_true"] is False and d["summary"]["false_flags"] == ["secondary.planted.finite"]
+
+
+def test_bench_dry_run_at_the_real_rank_count(tmp_path):
+    """`python bench.py --gpus 8 --backend gloo --stub-forward`, plain (the file launches its own eight ranks): the control flow of the
+    driver's 8-GPU scaling run at the rank count it will use -- tuning agreed by eight ranks, both gather modes, the config3 leg with a
+    batch that does not divide by eight, ONE line, the same collective counts on all eight ranks, a clean exit."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, str(repo / "bench.py"), "--gpus", "8", "--backend", "gloo", "--stub-forward", "--steps", "2", "--warmup", "1",
+           "--min-seconds", "0.01", "--batch", "2", "--frames", "24", "--config3-shape", "3,16"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = _bench_line(res)
+    assert d["n_gpus"] == 8 and d["finite"] is True and d["config"]["global_batch"] == 16 and d["config3"]["global_batch"] == 24
+    counts = d["collective_counts"]
+    assert len(counts) == 8 and all(c == counts[0] for c in counts) and counts[0]["all_gather"] > 0
+    assert list(d)[-1] == "summary" and d["summary"]["all_flags_true"] is True
+
+
+def _hour_worker(rank, world, rendezvous, out_dir):
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world)
+    from voice_activity_detection_amd import distributed as vdist
+    from voice_activity_detection_amd.distributed import shard_bounds, sharded_rows
+
+    n_samples, T, hop = 16000 * 3600, 800, 400
+    N = 1 + n_samples // 160
+    W = 1 if N <= T else (N - T + hop - 1) // hop + 1          # savad_stream_window_count (csrc/savad.hip), restated: no library on the CPU
+    lo, hi = shard_bounds(W, rank, world)
+    f0, f1 = hop * lo, min(N, hop * (hi - 1) + T)              # StreamingPredictor.audio_shard_plan's frame span
+    spans = []
+
+    def windows_logp(a, b):   # stand-in for the rank's forwards: window w -> its index in channel 0, the last frame it really covers in channel 1
+        spans.append((a, b))
+        w = torch.arange(a, b, dtype=torch.float32)
+        out = torch.empty((b - a, T, 2), dtype=torch.float32)
+        out[..., 0] = w[:, None]
+        out[..., 1] = torch.minimum(hop * w + T, torch.tensor(float(N)))[:, None]
+        return out
+
+    logp = sharded_rows(W, windows_logp, (T, 2), torch.float32, torch.device("cpu"))
+    ok = logp.shape == (W, T, 2) and bool((logp[:, 0, 0] == torch.arange(W, dtype=torch.float32)).all()) and float(logp[-1, 0, 1]) == float(N)
+    np.save(os.path.join(out_dir, f"hour{rank}.npy"), np.array([W, lo, hi, f0, f1, int(ok), spans[0][0], spans[0][1], vdist.collective_counts()["all_gather"]]))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_hour_plan_and_ragged_gather(tmp_path):
+    """configs[4] at the rank count of a node: an hour of audio = 360 001 frames = 900 windows of 800 frames every 400 -> 112 or 113
+    windows per rank (contiguous), the last rank's last window zero-padded past the recording, ONE ragged all_gather of [n_r, 800, 2]
+    per rank (padded to 113 rows) that every rank reassembles to the same [900, 800, 2]; equal collective counts on all eight."""
+    world = 8
+    mp.spawn(_hour_worker, args=(world, str(tmp_path / "rendezvous"), str(tmp_path)), nprocs=world, join=True)
+    rows = [np.load(tmp_path / f"hour{r}.npy") for r in range(world)]
+    assert all(int(r[0]) == 900 for r in rows)
+    sizes = [int(r[2] - r[1]) for r in rows]
+    assert sum(sizes) == 900 and set(sizes) == {112, 113} and all(int(rows[i][2]) == int(rows[i + 1][1]) for i in range(world - 1))
+    assert all(int(r[5]) == 1 for r in rows)                                      # every rank holds the whole, correctly ordered result
+    assert all((int(r[6]), int(r[7])) == (int(r[1]), int(r[2])) for r in rows)    # each computed exactly its own span
+    assert int(rows[-1][4]) == 360001 and 400 * 899 + 800 > 360001                  # the tail window reaches past the recording: zero-padded
+    assert len({int(r[8]) for r in rows}) == 1 and int(rows[0][8]) == 1           # one collective each, the same on all ranks
