@@ -62,7 +62,13 @@ _LABEL = re.compile(r"^([.\w$]+):")
 _DSREAD = re.compile(r"^ds_read")
 _DSOP = re.compile(r"^ds_")
 # kernels whose LDS-DMA target cannot be what the wave reads between its last barrier and the DMA (substring of the symbol -> why)
+_F32S_PIECES = ("the twelve 1-KiB pieces of ring slot t + 2 are placed one at a time between the MFMAs of the step that reads slot t, on purpose "
+                "(savad_kernels_f32s.h, Ring3): one request, ordered by the barrier at the head of step t -- the slot they fill was last read "
+                "in step t - 1, which every wave has left")
 DMA_DISJOINT = {
+    "21input_qkv_kernel_f32s": _F32S_PIECES,
+    "25attention_row_kernel_f32s": _F32S_PIECES,
+    "26packed_forward_kernel_f32s": _F32S_PIECES,
     "logmel_fft_kernel": "the DMA fills the sample stage; between barrier 1 and the DMA statements the wave only reads the exchange "
                          "buffer Yl (its reads of the stage lie before barrier 1, the stage's next readers behind barrier 2)",
     "5savad16attention_kernelE": "the next tile's 16 KiB are four dma_piece statements placed between the MFMAs of the tile being "
@@ -414,7 +420,11 @@ def dma_barriers_in_flight(blocks, count_stores: bool = True, cap: int = 6):
 # symbol substring -> barriers a DMA may legitimately cross in flight (default 0: landed before the next barrier), and why
 _RUNTIME_WAITS = "the counted ring wait is picked at run time from the number of blocks still to come; the analysis cannot tie that to the loop's issue condition and sees paths that never wait"
 _LAST_PASS = "the tile loop's last pass requests nothing (`more` is false) and leaves through the hand-over barrier: the path 'requested, then left' is infeasible"
+_RING3 = "the 3-slot ring of the fp32s kernels runs two slots ahead: a slot's pieces cross the barrier of the slot in front of it"
 DMA_PUBLISH_BARRIERS = {
+    "21input_qkv_kernel_f32s": (1, _RING3),
+    "25attention_row_kernel_f32s": (1, _RING3),
+    "26packed_forward_kernel_f32s": (1, _RING3),
     "attention_pw_kernel_bf16": (99, "a generated instruction stream with a three-stage K / V pipeline; its waits and barriers are modelled instruction by instruction in scripts/gfx950_sim.py"),
     "5savad20attention_row_kernelI": (1, _LAST_PASS),
     "25attention_row_kernel_bf16ILb0ELi4E": (1, _LAST_PASS),

@@ -144,49 +144,104 @@ __device__ __forceinline__ void store_hblock32(float* hb, const f32x16 (&x)[4], 
         }
 }
 
-// ---- the ring: 3 slots of 48 KiB; a slot = two 24-KiB segments, each contiguous in global memory.  Wave w moves 12 KiB:
-// half (w & 1) of segment (w >> 1), as three groups of four 1-KiB DMA instructions.  Completion by counted vmcnt (vector
-// memory operations retire in order): "at most 12 k outstanding" = everything but the k newest slots has landed.
+// ---- the ring: 3 slots of 48 KiB; a slot = two 24-KiB segments, each contiguous in global memory.  Wave w moves 12 KiB of a slot:
+// half (w & 1) of segment (w >> 1), as twelve 1-KiB DMA instructions (global_load_lds_dwordx4).  The stream runs TWO slots ahead:
+//
+//      step t:   s_waitcnt vmcnt(12)   the newest slot's twelve pieces may stay in flight: slot t has landed (in-order retirement;
+//                                      vector stores / loads the wave issued since only make the wait longer, never shorter)
+//                s_barrier             slot t is published -- and every wave is done with slot t - 1, whose place
+//                DMA of slot t + 2     takes the pieces, ONE AT A TIME between the MFMAs of step t: issued back to back a DMA
+//                                      instruction stalls the wave for 60 - 180 cycles with the matrix pipe idle behind it
+//                                      (scripts/ubench/f32s_ablate.sh: 53 of 400 us per [32,800,80] forward before the interleave).
+//
+// Every wait is the same unconditional instruction (no run-time choice of the count: scripts/check_async_loads.py follows it
+// statically); the two waits at the END of a stream, where nothing younger is in flight, are vmcnt(0) at compile-time positions.
+struct DmaJob {
+    const char* src;  // wave-uniform: this wave's 12 KiB of the slot in global memory
+    unsigned ldsb;    // ... and their place in LDS (byte address)
+};
 struct Ring3 {
     static constexpr int PER = 12;
-    static constexpr int DEPTH = 2;
     char* base;
     int w, lane;
-    __device__ __forceinline__ char* slot(int t) const { return base + (t % NRING3) * SLOT_BYTES; }
-    template <class SegSrc>
-    __device__ __forceinline__ void issue(int t, SegSrc seg_src) const {
-        if (SAVAD_ABLATE & 1) return;
-        const unsigned slot0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot(t));
-        const unsigned off = (unsigned)lane * 16u;
-        const char* s0 = seg_src(w >> 1) + (size_t)(w & 1) * (BLK3_BYTES / 2);
-        const unsigned ldsb = slot0 + (unsigned)w * (BLK3_BYTES / 2);
-        bf::Ring<4>::dma4k<0>(s0, ldsb, off);
-        bf::Ring<4>::dma4k<4096>(s0, ldsb, off + 4096u);
-        bf::Ring<4>::dma4k<8192>(s0, ldsb, off + 8192u);
+    unsigned voff[3];  // lane * 16 + g * 4096
+
+    __device__ __forceinline__ Ring3(char* smem, int w_, int lane_) : base(smem), w(w_), lane(lane_) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) voff[g] = (unsigned)lane_ * 16u + 4096u * g;
     }
-    // slot t has landed for every wave.  newer = slots issued after slot t (0 .. 2); stores_after = this wave's vector stores
-    // issued after its newest DMA (they may stay in flight)
-    __device__ __forceinline__ void acquire(int newer, int stores_after = 0) const {
+    __device__ __forceinline__ char* slot(int t) const { return base + (t % NRING3) * SLOT_BYTES; }
+    // this wave's share of the slot whose two segments start at seg0 / seg1 (wave-uniform), landing in ring slot `t`
+    __device__ __forceinline__ DmaJob job(int t, const char* seg0, const char* seg1) const {
+        const unsigned slot0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot(t));
+        return DmaJob{((w >> 1) ? seg1 : seg0) + (size_t)(w & 1) * (BLK3_BYTES / 2), slot0 + (unsigned)w * (BLK3_BYTES / 2)};
+    }
+    // piece I of the job's twelve: the instruction's immediate offset moves the global source and the LDS destination together
+    template <int I>
+    __device__ __forceinline__ void piece(const DmaJob& j) const {
+        if (SAVAD_ABLATE & 1) return;
+        asm volatile(
+            "s_add_u32 m0, %2, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1 offset:%4"
+            :
+            : "v"(voff[I / 4]), "s"(j.src), "s"(j.ldsb), "n"((I / 4) * 4096), "n"((I % 4) * 1024)
+            : "memory", "scc");
+    }
+    __device__ __forceinline__ void issue_all(const DmaJob& j) const {  // prologues: nothing to hide the pieces behind yet
+        piece<0>(j); piece<1>(j); piece<2>(j); piece<3>(j); piece<4>(j); piece<5>(j);
+        piece<6>(j); piece<7>(j); piece<8>(j); piece<9>(j); piece<10>(j); piece<11>(j);
+    }
+    // slot t has landed for every wave.  NEWER = slots issued after slot t (1 in the stream, 0 for its last slot)
+    template <int NEWER>
+    __device__ __forceinline__ void acquire() const {
         if (SAVAD_ABLATE & 2) return;
-        const int n = PER * newer + stores_after;
-        if (n == 0) __builtin_amdgcn_s_waitcnt(bf::Ring<4>::vmcnt_imm(0));
-        else if (n == 12) __builtin_amdgcn_s_waitcnt(bf::Ring<4>::vmcnt_imm(12));
-        else if (n == 24) __builtin_amdgcn_s_waitcnt(bf::Ring<4>::vmcnt_imm(24));
-        else __builtin_amdgcn_s_waitcnt(bf::Ring<4>::vmcnt_imm(0));
+        __builtin_amdgcn_s_waitcnt(bf::Ring<4>::vmcnt_imm(NEWER ? PER : 0));
         asm volatile("" ::: "memory");
         __syncthreads();
     }
 };
 
-// acc[0..1] += W[the slot's two n-blocks] . x   (transposed form: lane = data row, registers = output features)
-template <bool SWAP>
-__device__ __forceinline__ void gemm_slot(f32x16& acc0, f32x16& acc1, const char* slot, const Tri (&xp)[8], int lane) {
+// acc0 / acc1 += W[the slot's two n-blocks] . x   (transposed form: lane = data row, registers = output features; SWAP: the V^T form).
+// The sixteen weight triples are read from LDS by HAND-issued ds_read_b128, one K-step (six fragments) ahead of the twelve MFMAs that
+// consume them, with counted lgkmcnt waits (the compiler keeps two fragments in flight and waits out an LDS round trip every few
+// MFMAs; LDS data returns in order and scalar-memory returns can only add to what a counted wait has seen complete, so "at most six
+// outstanding" means the older six have landed).  DMA: the twelve pieces of `job` go out between the K-steps.
+template <bool SWAP, bool DMA>
+__device__ __forceinline__ void gemm_slot(f32x16& acc0, f32x16& acc1, const char* slot, const Tri (&xp)[8], const Ring3& ring,
+                                          const DmaJob& job) {
+    if (SAVAD_ABLATE & 8) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const Tri w0 = (SAVAD_ABLATE & 8) ? xp[7 - ks] : ldtri(slot + ks * TFRAG_BYTES + lane * 16);
-        const Tri w1 = (SAVAD_ABLATE & 8) ? xp[ks ^ 1] : ldtri(slot + BLK3_BYTES + ks * TFRAG_BYTES + lane * 16);
-        mfma6x2<SWAP>(acc0, acc1, w0, w1, xp[ks]);
+        for (int ks = 0; ks < 8; ++ks) mfma6x2<SWAP>(acc0, acc1, xp[7 - ks], xp[ks ^ 1], xp[ks]);
+        return;
     }
+    const unsigned a = (unsigned)(size_t)slot + (unsigned)ring.lane * 16u;  // LDS byte address (low half of the flat address)
+    u32x4 f[2][6];
+#define SAVAD_G_LD(ks, i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[(ks) & 1][i]) : "v"(a), "n"(((i) / 3) * BLK3_BYTES + (ks) * TFRAG_BYTES + ((i) % 3) * FRAG_BYTES))
+#define SAVAD_G_LD6(ks) SAVAD_G_LD(ks, 0); SAVAD_G_LD(ks, 1); SAVAD_G_LD(ks, 2); SAVAD_G_LD(ks, 3); SAVAD_G_LD(ks, 4); SAVAD_G_LD(ks, 5)
+#define SAVAD_G_STEP(ks, P0, P1)                                                                                              \
+    {                                                                                                                         \
+        if constexpr ((ks) + 1 < 8) { SAVAD_G_LD6((ks) + 1); }                                                                \
+        asm volatile("s_waitcnt lgkmcnt(%6)"                                                                                  \
+                     : "+v"(f[(ks) & 1][0]), "+v"(f[(ks) & 1][1]), "+v"(f[(ks) & 1][2]), "+v"(f[(ks) & 1][3]), "+v"(f[(ks) & 1][4]), \
+                       "+v"(f[(ks) & 1][5])                                                                                   \
+                     : "n"((ks) + 1 < 8 ? 6 : 0));                                                                            \
+        const Tri w0_{__builtin_bit_cast(bf16x8, f[(ks) & 1][0]), __builtin_bit_cast(bf16x8, f[(ks) & 1][1]),                  \
+                      __builtin_bit_cast(bf16x8, f[(ks) & 1][2])};                                                            \
+        const Tri w1_{__builtin_bit_cast(bf16x8, f[(ks) & 1][3]), __builtin_bit_cast(bf16x8, f[(ks) & 1][4]),                  \
+                      __builtin_bit_cast(bf16x8, f[(ks) & 1][5])};                                                            \
+        mfma6x2<SWAP>(acc0, acc1, w0_, w1_, xp[ks]);                                                                          \
+        if constexpr (DMA) {                                                                                                  \
+            ring.template piece<P0>(job);                                                                                     \
+            if constexpr ((P1) >= 0) ring.template piece<((P1) >= 0 ? (P1) : 0)>(job);                                        \
+        }                                                                                                                     \
+    }
+    SAVAD_G_LD6(0);
+    SAVAD_G_STEP(0, 0, 1) SAVAD_G_STEP(1, 2, -1) SAVAD_G_STEP(2, 3, 4) SAVAD_G_STEP(3, 5, -1)
+    SAVAD_G_STEP(4, 6, 7) SAVAD_G_STEP(5, 8, -1) SAVAD_G_STEP(6, 9, 10) SAVAD_G_STEP(7, 11, -1)
+#undef SAVAD_G_STEP
+#undef SAVAD_G_LD6
+#undef SAVAD_G_LD
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -212,17 +267,18 @@ __global__ void pack_weight_frags3_kernel(const float* __restrict__ W, int N, in
     }
 }
 
-// One of the six QKV slots: slot s covers n-blocks 2 (s & 1), 2 (s & 1) + 1 of projection rb = s >> 1 (0 query, 1 key:
+// One of the six QKV slots: slot S covers n-blocks 2 (S & 1), 2 (S & 1) + 1 of projection rb = S >> 1 (0 query, 1 key:
 // transposed form; 2 value: swapped form -> V^T).  Q is stored PRE-SCALED by qscale = log2(e) / sqrt(D).
-__device__ __forceinline__ void qkv_slot(int s, const char* slot, const Tri (&xp)[8], const float* lbq, char* __restrict__ qf,
-                                         char* __restrict__ kf, char* __restrict__ vtf, int blk, int lane, float qscale, bool live) {
-    const int n = lane & 31, h = lane >> 5;
-    const int rb = s >> 1, nb0 = 2 * (s & 1);
+template <int S, bool DMA>
+__device__ __forceinline__ void qkv_slot(const char* slot, const Tri (&xp)[8], const float* lbq, char* __restrict__ qf, char* __restrict__ kf,
+                                         char* __restrict__ vtf, int blk, const Ring3& ring, const DmaJob& job, float qscale, bool live) {
+    const int lane = ring.lane, n = lane & 31, h = lane >> 5;
+    constexpr int rb = S >> 1, nb0 = 2 * (S & 1);
     f32x16 acc[2];
-    if (rb < 2) {
+    if constexpr (rb < 2) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[i] = bias_block(lbq + D * rb + 32 * (nb0 + i), h);
-        gemm_slot<false>(acc[0], acc[1], slot, xp, lane);
+        gemm_slot<false, DMA>(acc[0], acc[1], slot, xp, ring, job);
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -230,9 +286,9 @@ __device__ __forceinline__ void qkv_slot(int s, const char* slot, const Tri (&xp
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = bv;
         }
-        gemm_slot<true>(acc[0], acc[1], slot, xp, lane);
+        gemm_slot<true, DMA>(acc[0], acc[1], slot, xp, ring, job);
     }
-    if (rb == 0) {
+    if constexpr (rb == 0) {
         acc[0] *= qscale;
         acc[1] *= qscale;
     }
@@ -273,11 +329,10 @@ __global__ __launch_bounds__(256, 1) void input_qkv_kernel_f32s(const float* __r
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = blockIdx.x * 4 + w;
-    const Ring3 ring{smem, w, lane};
-    constexpr int NSLOT = 6;
-    auto issue = [&](int t) { ring.issue(t, [&](int sgm) { return wqkv_frag + (size_t)(2 * t + sgm) * BLK3_BYTES; }); };
-    issue(0);
-    issue(1);
+    const Ring3 ring(smem, w, lane);
+    auto job = [&](int t) { return ring.job(t, wqkv_frag + (size_t)(2 * t) * BLK3_BYTES, wqkv_frag + (size_t)(2 * t + 1) * BLK3_BYTES); };
+    ring.issue_all(job(0));
+    ring.issue_all(job(1));
     stage_bias(lbq, bqkv, 3 * D);
     size_t row;
     int t_frame;
@@ -305,31 +360,95 @@ __global__ __launch_bounds__(256, 1) void input_qkv_kernel_f32s(const float* __r
             mfma6x2<false>(h0[nb], h0[nb + 1], w0, w1, xf);
         }
     }
-    if (blk < nblk) store_hblock32(hbuf + (size_t)blk * (32 * D), h0, lane);
+    const bool live = blk < nblk;
+    if (live) store_hblock32(hbuf + (size_t)blk * (32 * D), h0, lane);
     f32x4 xg[16];
     layernorm_regs(h0, xg);
     Tri xp[8];
     split_row(xg, xp);
-#pragma unroll 1
-    for (int t = 0; t < NSLOT; ++t) {
-        ring.acquire(NSLOT - 1 - t < 1 ? NSLOT - 1 - t : 1);
-        if (t + 2 < NSLOT) issue(t + 2);
-        qkv_slot(t, ring.slot(t), xp, lbq, qf, kf, vtf, blk, lane, qscale, blk < nblk);
-    }
+    const DmaJob none{nullptr, 0u};
+#define SAVAD_IQ_STEP(T_)                                                                                                      \
+    ring.acquire<((T_) + 1 < 6) ? 1 : 0>();                                                                                    \
+    qkv_slot<T_, ((T_) + 2 < 6)>(ring.slot(T_), xp, lbq, qf, kf, vtf, blk, ring, (T_) + 2 < 6 ? job((T_) + 2) : none, qscale, live);
+    SAVAD_IQ_STEP(0) SAVAD_IQ_STEP(1) SAVAD_IQ_STEP(2) SAVAD_IQ_STEP(3) SAVAD_IQ_STEP(4) SAVAD_IQ_STEP(5)
+#undef SAVAD_IQ_STEP
 }
 
 // ---------------------------------------------------------------------------------------------
 // Attention on triples (vad/modeling/transformer.py:305-346,351-363), one 32-key tile:
 //   S^T = K Q^T as 8 K-steps x 6 products on two accumulators (negm rides in as C of one of them), the fp32 online softmax
 //   of savad_kernels_bf16.h, P split into its three pieces, O^T += V^T P^T as 4 x 2 x 6 products.
+// LDS: K triples read by hand two K-steps ahead of their MFMAs, V^T triples one group (two triples) ahead -- the first group is
+// requested BEFORE the softmax, so its round trip hides under the exponentials; DMA: the twelve pieces of `job` go out between the
+// PV groups.  GLOBAL = false: kblk / vtblk are LDS ring addresses; true (T <= 32, one tile, nothing shared): global memory.
 // ---------------------------------------------------------------------------------------------
-template <class Mask>
+template <bool DMA, class Mask>
 __device__ __forceinline__ void attn_tile3(AttnState& st, const Tri (&qp)[8], const char* kblk, const char* vtblk, Mask mask,
-                                           bool first, int lane) {
+                                           bool first, const Ring3& ring, const DmaJob& job) {
+    const unsigned ak = (unsigned)(size_t)kblk + (unsigned)ring.lane * 16u, av = (unsigned)(size_t)vtblk + (unsigned)ring.lane * 16u;
+    f32x16 sa = st.negm, sb = zero16();
+    u32x4 fk[3][3];
+#define SAVAD_A_LDK(ks, i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fk[(ks) % 3][i]) : "v"(ak), "n"((ks) * TFRAG_BYTES + (i) * FRAG_BYTES))
+#define SAVAD_A_LDK3(ks) SAVAD_A_LDK(ks, 0); SAVAD_A_LDK(ks, 1); SAVAD_A_LDK(ks, 2)
+#define SAVAD_A_QK(ks)                                                                                                         \
+    {                                                                                                                          \
+        if constexpr ((ks) + 2 < 8) { SAVAD_A_LDK3((ks) + 2); }                                                                \
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fk[(ks) % 3][0]), "+v"(fk[(ks) % 3][1]), "+v"(fk[(ks) % 3][2])             \
+                     : "n"((ks) + 2 < 8 ? 6 : ((ks) + 1 < 8 ? 3 : 0)));                                                        \
+        const bf16x8 kh_ = __builtin_bit_cast(bf16x8, fk[(ks) % 3][0]), km_ = __builtin_bit_cast(bf16x8, fk[(ks) % 3][1]),     \
+                     kl_ = __builtin_bit_cast(bf16x8, fk[(ks) % 3][2]);                                                        \
+        sa = SAVAD_MF(kh_, qp[ks].l, sa);                                                                                      \
+        sb = SAVAD_MF(kl_, qp[ks].h, sb);                                                                                      \
+        sa = SAVAD_MF(km_, qp[ks].m, sa);                                                                                      \
+        sb = SAVAD_MF(kh_, qp[ks].m, sb);                                                                                      \
+        sa = SAVAD_MF(km_, qp[ks].h, sa);                                                                                      \
+        sb = SAVAD_MF(kh_, qp[ks].h, sb);                                                                                      \
+    }
+    SAVAD_A_LDK3(0);
+    SAVAD_A_LDK3(1);
+    SAVAD_A_QK(0) SAVAD_A_QK(1) SAVAD_A_QK(2) SAVAD_A_QK(3) SAVAD_A_QK(4) SAVAD_A_QK(5) SAVAD_A_QK(6) SAVAD_A_QK(7)
+#undef SAVAD_A_QK
+#undef SAVAD_A_LDK3
+#undef SAVAD_A_LDK
+    // PV group g = 2 (nbd pair) + j: the triples of (nbd, j) and (nbd + 1, j), nbd = 2 (g >> 1), j = g & 1
+    u32x4 fv[2][6];
+#define SAVAD_A_LDV(g, i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fv[(g) & 1][i]) : "v"(av), "n"((((2 * ((g) >> 1) + (i) / 3) * 2 + ((g) & 1)) * 3 + (i) % 3) * FRAG_BYTES))
+#define SAVAD_A_LDV6(g) SAVAD_A_LDV(g, 0); SAVAD_A_LDV(g, 1); SAVAD_A_LDV(g, 2); SAVAD_A_LDV(g, 3); SAVAD_A_LDV(g, 4); SAVAD_A_LDV(g, 5)
+    SAVAD_A_LDV6(0);
+    f32x16 sc = sa + sb;
+    mask(sc);
+    if (!(SAVAD_ABLATE & 4)) online_softmax_shifted(sc, st, first);
+    const Tri p0 = split_half(sc, 0), p1 = split_half(sc, 1);
+#define SAVAD_A_PV(g, PJ)                                                                                                      \
+    {                                                                                                                          \
+        if constexpr ((g) + 1 < 4) { SAVAD_A_LDV6((g) + 1); }                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(%6)"                                                                                   \
+                     : "+v"(fv[(g) & 1][0]), "+v"(fv[(g) & 1][1]), "+v"(fv[(g) & 1][2]), "+v"(fv[(g) & 1][3]), "+v"(fv[(g) & 1][4]), \
+                       "+v"(fv[(g) & 1][5])                                                                                    \
+                     : "n"((g) + 1 < 4 ? 6 : 0));                                                                              \
+        const Tri v0_{__builtin_bit_cast(bf16x8, fv[(g) & 1][0]), __builtin_bit_cast(bf16x8, fv[(g) & 1][1]),                   \
+                      __builtin_bit_cast(bf16x8, fv[(g) & 1][2])};                                                             \
+        const Tri v1_{__builtin_bit_cast(bf16x8, fv[(g) & 1][3]), __builtin_bit_cast(bf16x8, fv[(g) & 1][4]),                   \
+                      __builtin_bit_cast(bf16x8, fv[(g) & 1][5])};                                                             \
+        mfma6x2<false>(st.O[2 * ((g) >> 1)], st.O[2 * ((g) >> 1) + 1], v0_, v1_, PJ);                                          \
+        if constexpr (DMA) {                                                                                                   \
+            ring.template piece<3 * (g)>(job);                                                                                 \
+            ring.template piece<3 * (g) + 1>(job);                                                                             \
+            ring.template piece<3 * (g) + 2>(job);                                                                             \
+        }                                                                                                                      \
+    }
+    SAVAD_A_PV(0, p0) SAVAD_A_PV(1, p1) SAVAD_A_PV(2, p0) SAVAD_A_PV(3, p1)
+#undef SAVAD_A_PV
+#undef SAVAD_A_LDV6
+#undef SAVAD_A_LDV
+}
+// the same tile with K / V^T in global memory (T <= 32: a block attends to itself; nothing to share, no ring)
+template <class Mask>
+__device__ __forceinline__ void attn_tile3_global(AttnState& st, const Tri (&qp)[8], const char* kblk, const char* vtblk, Mask mask, int lane) {
     f32x16 sa = st.negm, sb = zero16();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const Tri k = (SAVAD_ABLATE & 8) ? qp[7 - ks] : ldtri(kblk + ks * TFRAG_BYTES + lane * 16);
+        const Tri k = ldtri(kblk + ks * TFRAG_BYTES + lane * 16);
         sa = SAVAD_MF(k.h, qp[ks].l, sa);
         sb = SAVAD_MF(k.l, qp[ks].h, sb);
         sa = SAVAD_MF(k.m, qp[ks].m, sa);
@@ -339,28 +458,24 @@ __device__ __forceinline__ void attn_tile3(AttnState& st, const Tri (&qp)[8], co
     }
     f32x16 sc = sa + sb;
     mask(sc);
-    if (!(SAVAD_ABLATE & 4)) online_softmax_shifted(sc, st, first);
+    online_softmax_shifted(sc, st, true);
     const Tri p0 = split_half(sc, 0), p1 = split_half(sc, 1);
 #pragma unroll
     for (int nbd = 0; nbd < 4; nbd += 2) {
-        {
-            const Tri v0 = (SAVAD_ABLATE & 8) ? qp[nbd] : ldtri(vtblk + ((nbd * 2 + 0) * TFRAG_BYTES) + lane * 16);
-            const Tri v1 = (SAVAD_ABLATE & 8) ? qp[nbd + 1] : ldtri(vtblk + (((nbd + 1) * 2 + 0) * TFRAG_BYTES) + lane * 16);
-            mfma6x2<false>(st.O[nbd], st.O[nbd + 1], v0, v1, p0);
-        }
-        {
-            const Tri v0 = (SAVAD_ABLATE & 8) ? qp[4 + nbd] : ldtri(vtblk + ((nbd * 2 + 1) * TFRAG_BYTES) + lane * 16);
-            const Tri v1 = (SAVAD_ABLATE & 8) ? qp[5 + nbd] : ldtri(vtblk + (((nbd + 1) * 2 + 1) * TFRAG_BYTES) + lane * 16);
-            mfma6x2<false>(st.O[nbd], st.O[nbd + 1], v0, v1, p1);
-        }
+        mfma6x2<false>(st.O[nbd], st.O[nbd + 1], ldtri(vtblk + ((nbd * 2 + 0) * TFRAG_BYTES) + lane * 16),
+                       ldtri(vtblk + (((nbd + 1) * 2 + 0) * TFRAG_BYTES) + lane * 16), p0);
+        mfma6x2<false>(st.O[nbd], st.O[nbd + 1], ldtri(vtblk + ((nbd * 2 + 1) * TFRAG_BYTES) + lane * 16),
+                       ldtri(vtblk + (((nbd + 1) * 2 + 1) * TFRAG_BYTES) + lane * 16), p1);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Row chain of one block per wave (vad/modeling/transformer.py:347,234-238,366-382; LAST: :33 and
 // vad/models/self_attention.py:26-27): out-projection + residual -> LN -> FFN + residual -> next layer's LN + Q/K/V^T, or
-// the encoder LayerNorm + classifier + LogSoftmax.  Weight stream = ring slots
+// the encoder LayerNorm + classifier + LogSoftmax.  Weight stream = slots
 //   0,1: Wo | 2+4c, 3+4c: W1 chunk c | 4+4c, 5+4c: W2 chunk c (c = 0..3) | 18..23: Wq, Wk, Wv  (two n-blocks per slot)
+// at ring positions base + t.  PREFETCHED: slots 0 and 1 are already in flight (the fused launch requests them under its last two
+// key tiles, so that the chain does not start with an exposed DMA round trip).
 // ---------------------------------------------------------------------------------------------
 struct RowArgs3 {
     int B, T, nblk;
@@ -378,33 +493,35 @@ struct RowArgs3 {
     float* out;           // LAST
     float qscale;
 };
+// the two segments of row-chain slot t (compile-time t in the chain itself; 0 / 1 at run time for the fused launch's prefetch)
+__device__ __forceinline__ const char* row_seg(const RowArgs3& A, int t, int sgm) {
+    if (t < 2) return A.wo_frag + (size_t)(2 * t + sgm) * BLK3_BYTES;
+    if (t < 18) {
+        const int c = (t - 2) >> 2, r = (t - 2) & 3;
+        return r < 2 ? A.w1_frag + (size_t)(4 * c + 2 * r + sgm) * BLK3_BYTES
+                     : A.w2_frag + (size_t)((2 * (r - 2) + sgm) * 32 + 8 * c) * TFRAG_BYTES;  // n-block, K-steps 8c..8c+7
+    }
+    return A.wn_frag + (size_t)(2 * (t - 18) + sgm) * BLK3_BYTES;
+}
 
-template <bool LAST>
-__device__ __forceinline__ void row_stage_f32s(const RowArgs3& A, char* smem, Tri (&xp)[8], int blk, bool live, int lane, int w) {
+template <bool LAST, bool PREFETCHED>
+__device__ __forceinline__ void row_stage_f32s(const RowArgs3& A, char* smem, Tri (&xp)[8], int blk, bool live, const Ring3& ring, int base) {
     float* lbo = reinterpret_cast<float*>(smem + NRING3 * SLOT_BYTES);
     float* lb1 = lbo + D;
     float* lb2 = lb1 + DFF;
     float* lbn = lb2 + D;
-    const int m = lane & 31, h = lane >> 5;
-    const Ring3 ring{smem, w, lane};
+    const int lane = ring.lane, m = lane & 31, h = lane >> 5;
     constexpr int NSLOT = LAST ? 18 : 24;
-    auto issue = [&](int t) {
-        ring.issue(t, [&](int sgm) -> const char* {
-            if (t < 2) return A.wo_frag + (size_t)(2 * t + sgm) * BLK3_BYTES;
-            if (t < 18) {
-                const int c = (t - 2) >> 2, r = (t - 2) & 3;
-                return r < 2 ? A.w1_frag + (size_t)(4 * c + 2 * r + sgm) * BLK3_BYTES
-                             : A.w2_frag + (size_t)((2 * (r - 2) + sgm) * 32 + 8 * c) * TFRAG_BYTES;  // n-block, K-steps 8c..8c+7
-            }
-            return A.wn_frag + (size_t)(2 * (t - 18) + sgm) * BLK3_BYTES;
-        });
-    };
-    auto advance = [&](int t) {
-        ring.acquire(NSLOT - 1 - t < 1 ? NSLOT - 1 - t : 1);
-        if (t + 2 < NSLOT) issue(t + 2);
-    };
-    issue(0);
-    issue(1);
+    auto job = [&](int t) { return ring.job(base + t, row_seg(A, t, 0), row_seg(A, t, 1)); };
+    const DmaJob none{nullptr, 0u};
+    if (!PREFETCHED) {
+        ring.issue_all(job(0));
+        ring.issue_all(job(1));
+    }
+    // acquire slot T_, then acc0 / acc1 += slot . operand with the DMA of slot T_ + 2 between the MFMAs
+#define SAVAD_ROW_GEMM(T_, acc0, acc1, operand)                                                                               \
+    ring.acquire<((T_) + 1 < NSLOT) ? 1 : 0>();                                                                               \
+    gemm_slot<false, ((T_) + 2 < NSLOT)>(acc0, acc1, ring.slot(base + (T_)), operand, ring, (T_) + 2 < NSLOT ? job((T_) + 2) : none);
     const BiasPiece pieces[4] = {{lbo, A.bo, D}, {lb1, A.b1, DFF}, {lb2, A.b2, D}, {lbn, LAST ? A.wc : A.bn, LAST ? 2 * D : 3 * D}};
     const BiasRegs<4> breg = request_bias_pieces(pieces);
     const float bc = LAST ? A.bn[threadIdx.x & 1] : 0.0f;
@@ -415,13 +532,12 @@ __device__ __forceinline__ void row_stage_f32s(const RowArgs3& A, char* smem, Tr
     if (live) load_hblock32(h1, hb, lane);
     commit_bias_pieces(pieces, breg);
     if (LAST && threadIdx.x < 2) lbn[2 * D + threadIdx.x] = bc;
-    // ---- h1 = h + bo + ctx Wo^T
-    advance(0);
+    // ---- h1 = h + bo + ctx Wo^T   (the biases are published by slot 0's barrier)
+    ring.acquire<1>();
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) h1[nb] += bias_block(lbo + 32 * nb, h);
-    gemm_slot<false>(h1[0], h1[1], ring.slot(0), xp, lane);
-    advance(1);
-    gemm_slot<false>(h1[2], h1[3], ring.slot(1), xp, lane);
+    gemm_slot<false, true>(h1[0], h1[1], ring.slot(base), xp, ring, job(2));
+    SAVAD_ROW_GEMM(1, h1[2], h1[3], xp)
     f32x4 xg[16];
     layernorm_regs(h1, xg);
     split_row(xg, xp);
@@ -429,38 +545,34 @@ __device__ __forceinline__ void row_stage_f32s(const RowArgs3& A, char* smem, Tr
     f32x16(&o)[4] = h1;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) o[nb] += bias_block(lb2 + 32 * nb, h);
-#pragma unroll 1
-    for (int ch = 0; ch < 4; ++ch) {
-        const int t0 = 2 + 4 * ch;
-        f32x16 a[4];
-#pragma unroll
-        for (int nbl = 0; nbl < 4; ++nbl) a[nbl] = bias_block(lb1 + 128 * ch + 32 * nbl, h);
-        advance(t0);
-        gemm_slot<false>(a[0], a[1], ring.slot(t0), xp, lane);
-        advance(t0 + 1);
-        gemm_slot<false>(a[2], a[3], ring.slot(t0 + 1), xp, lane);
-        Tri ap[8];
-#pragma unroll
-        for (int nbl = 0; nbl < 4; ++nbl) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[nbl][r] = fmaxf(a[nbl][r], 0.0f);
-            ap[2 * nbl] = split_half(a[nbl], 0);
-            ap[2 * nbl + 1] = split_half(a[nbl], 1);
-        }
-        advance(t0 + 2);
-        gemm_slot<false>(o[0], o[1], ring.slot(t0 + 2), ap, lane);
-        advance(t0 + 3);
-        gemm_slot<false>(o[2], o[3], ring.slot(t0 + 3), ap, lane);
+#define SAVAD_ROW_FFN(ch)                                                                                                     \
+    {                                                                                                                         \
+        f32x16 a[4];                                                                                                          \
+        _Pragma("unroll") for (int nbl = 0; nbl < 4; ++nbl) a[nbl] = bias_block(lb1 + 128 * (ch) + 32 * nbl, h);              \
+        SAVAD_ROW_GEMM(2 + 4 * (ch), a[0], a[1], xp)                                                                          \
+        SAVAD_ROW_GEMM(3 + 4 * (ch), a[2], a[3], xp)                                                                          \
+        Tri ap[8];                                                                                                            \
+        _Pragma("unroll") for (int nbl = 0; nbl < 4; ++nbl) {                                                                 \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) a[nbl][r] = fmaxf(a[nbl][r], 0.0f);                                \
+            ap[2 * nbl] = split_half(a[nbl], 0);                                                                              \
+            ap[2 * nbl + 1] = split_half(a[nbl], 1);                                                                          \
+        }                                                                                                                     \
+        SAVAD_ROW_GEMM(4 + 4 * (ch), o[0], o[1], ap)                                                                          \
+        SAVAD_ROW_GEMM(5 + 4 * (ch), o[2], o[3], ap)                                                                          \
     }
+    SAVAD_ROW_FFN(0) SAVAD_ROW_FFN(1) SAVAD_ROW_FFN(2) SAVAD_ROW_FFN(3)
+#undef SAVAD_ROW_FFN
+#undef SAVAD_ROW_GEMM
     if (!LAST && live) store_hblock32(hb, o, lane);
     layernorm_regs(o, xg);
-    if (!LAST) {
+    if constexpr (!LAST) {
         split_row(xg, xp);
-#pragma unroll 1
-        for (int s = 0; s < 6; ++s) {
-            advance(18 + s);
-            qkv_slot(s, ring.slot(18 + s), xp, lbn, A.qf, A.kf, A.vtf, blk, lane, A.qscale, live);
-        }
+#define SAVAD_ROW_QKV(S_)                                                                                                     \
+    ring.acquire<(18 + (S_) + 1 < NSLOT) ? 1 : 0>();                                                                          \
+    qkv_slot<S_, (18 + (S_) + 2 < NSLOT)>(ring.slot(base + 18 + (S_)), xp, lbn, A.qf, A.kf, A.vtf, blk, ring,                 \
+                                          18 + (S_) + 2 < NSLOT ? job(18 + (S_) + 2) : none, A.qscale, live);
+        SAVAD_ROW_QKV(0) SAVAD_ROW_QKV(1) SAVAD_ROW_QKV(2) SAVAD_ROW_QKV(3) SAVAD_ROW_QKV(4) SAVAD_ROW_QKV(5)
+#undef SAVAD_ROW_QKV
     } else {
         float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
@@ -486,7 +598,8 @@ __device__ __forceinline__ void row_stage_f32s(const RowArgs3& A, char* smem, Tr
 // ---------------------------------------------------------------------------------------------
 // One launch per layer: attention of the wave's query block, immediately followed by its row chain.
 //   PACKED = false (T > 32): workgroup = (sequence, group of <= 4 query blocks); the sequence's key blocks go through the
-//            ring one per slot (K and V^T images), shared by the four waves; q/k/v^T double-buffered between layers.
+//            ring one per slot (K and V^T images), shared by the four waves, and the row chain's weight slots simply continue
+//            the stream (its first two are requested under the last two key tiles); q/k/v^T double-buffered between layers.
 //   PACKED = true (T <= 32): a block holds floor(32/T) whole sequences and attends to itself under a block-diagonal mask;
 //            its K / V^T triples come straight from global memory (nothing to share), 4 blocks per workgroup.
 // ---------------------------------------------------------------------------------------------
@@ -497,11 +610,11 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
     const int B = A.B, T = A.T;
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const Ring3 ring{smem, w, lane};
+    const Ring3 ring(smem, w, lane);
     AttnState st;
     attn_state_init(st);
     Tri qp[8];
-    int blk_q;
+    int blk_q, base = 0;
     bool active, qvalid;
     if constexpr (PACKED) {
         blk_q = blockIdx.x * 4 + w;
@@ -521,10 +634,10 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[r] = keyok[r] ? sc[r] : NEG_BIG;
             };
-            attn_tile3(st, qp, kf + (size_t)blk_q * BLK3_BYTES, vtf + (size_t)blk_q * BLK3_BYTES, mask, true, lane);
+            attn_tile3_global(st, qp, kf + (size_t)blk_q * BLK3_BYTES, vtf + (size_t)blk_q * BLK3_BYTES, mask, lane);
         }
     } else {
-        const int QB = (T + 31) / 32;
+        const int QB = (T + 31) / 32;  // >= 2
         int b, g;
         if (!xcd_balanced_map(B, NG, b, g)) return;
         const int qb0 = (g * QB) / NG, qb1 = ((g + 1) * QB) / NG;
@@ -532,31 +645,42 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
         active = qb < qb1;
         blk_q = b * QB + (active ? qb : qb0);
         qvalid = active && 32 * qb + m < T;
+        base = QB;
+        // stream index u: key tiles 0 .. QB-1, then the row chain's slots
+        auto job = [&](int u) {
+            if (u < QB) {
+                const size_t kb = (size_t)b * QB + u;
+                return ring.job(u, kf + kb * BLK3_BYTES, vtf + kb * BLK3_BYTES);
+            }
+            return ring.job(u, row_seg(A, u - QB, 0), row_seg(A, u - QB, 1));
+        };
+        ring.issue_all(job(0));
+        ring.issue_all(job(1));
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qp[ks] = ldtri(qf + (size_t)blk_q * BLK3_BYTES + ks * TFRAG_BYTES + lane * 16);
-        auto issue = [&](int stage) {
-            const size_t kb = (size_t)b * QB + stage;
-            ring.issue(stage, [&](int sgm) { return (sgm == 0 ? kf : vtf) + kb * BLK3_BYTES; });
-        };
-        issue(0);
-        if (QB > 1) issue(1);
+        if (active) {
 #pragma unroll 1
-        for (int jt = 0; jt < QB; ++jt) {
-            ring.acquire(QB - 1 - jt < 1 ? QB - 1 - jt : 1);
-            if (jt + 2 < QB) issue(jt + 2);
-            if (!active) continue;
-            const char* buf = ring.slot(jt);
-            auto mask = [&](f32x16& sc) {  // a REAL (wave-uniform) branch: only the last tile of a ragged sequence has missing keys
-                if (32 * jt + 32 > T) {
-                    asm volatile("" ::: "memory");
-                    const int lim = T - 32 * jt - 4 * h;
+            for (int jt = 0; jt < QB; ++jt) {
+                ring.acquire<1>();
+                const DmaJob nxt = job(jt + 2);
+                const char* buf = ring.slot(jt);
+                auto mask = [&](f32x16& sc) {  // a REAL (wave-uniform) branch: only the last tile of a ragged sequence has missing keys
+                    if (32 * jt + 32 > T) {
+                        asm volatile("" ::: "memory");
+                        const int lim = T - 32 * jt - 4 * h;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[r] = (8 * (r >> 2) + (r & 3) < lim) ? sc[r] : NEG_BIG;
-                }
-            };
-            attn_tile3(st, qp, buf, buf + BLK3_BYTES, mask, jt == 0, lane);
+                        for (int r = 0; r < 16; ++r) sc[r] = (8 * (r >> 2) + (r & 3) < lim) ? sc[r] : NEG_BIG;
+                    }
+                };
+                attn_tile3<true>(st, qp, buf, buf + BLK3_BYTES, mask, jt == 0, ring, nxt);
+            }
+        } else {  // a wave without a query block still moves its share of the stream and meets the others at every barrier
+#pragma unroll 1
+            for (int jt = 0; jt < QB; ++jt) {
+                ring.acquire<1>();
+                ring.issue_all(job(jt + 2));
+            }
         }
-        __syncthreads();  // everyone is done with the K/V ring: it becomes the weight ring
     }
     // normalised context -> B-operand triples, in registers (invalid slots and waves without a block: exact zeros)
     Tri xp[8];
@@ -570,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
             xp[2 * nbd + 1] = split_half(st.O[nbd], 1);
         }
     }
-    row_stage_f32s<LAST>(A, smem, xp, blk_q, active, lane, w);
+    row_stage_f32s<LAST, !PACKED>(A, smem, xp, blk_q, active, ring, base);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -579,8 +703,10 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
 // for ALL layers: Q, K and V^T are produced by the wave that consumes them, so the attention never leaves its registers; the fp32
 // residual stream waits in registers; nothing but x, the weight stream and the log-probabilities crosses the CU boundary.  The four
 // waves of a workgroup share the weight stream: 24 ring slots per layer -- Wq Wk Wv Wo (two slots each), then W1 / W2 chunks
-// alternating (two slots each).  Windowed mode (wo.w == T > 0): x is the predictor's feature MATRIX [N][F] and sequence s is its
-// window feature[win_base + s + wo.off[0..T-1]] (vad/predictor.py:180-220): the gather is an address computation.
+// alternating (two slots each); behind the last layer the stream re-requests that layer's first two slots (never read), so that every
+// step of the stream is the same wait + barrier + request.  Windowed mode (wo.w == T > 0): x is the predictor's feature MATRIX
+// [N][F] and sequence s is its window feature[win_base + s + wo.off[0..T-1]] (vad/predictor.py:180-220): the gather is an address
+// computation.
 // ---------------------------------------------------------------------------------------------
 constexpr int PACKED_F32S_MAX_LAYERS = 3;  // ring (144 KiB) + 3 x 4.5 KiB of biases + the classifier fit the 160 KiB of LDS
 struct PackedF32sLayer {
@@ -596,6 +722,13 @@ struct PackedF32sModel {
     int L;
 };
 inline constexpr int packed_f32s_lds_bytes(int L) { return NRING3 * SLOT_BYTES + (L * LBIAS + 2 * D + 4) * 4; }
+// the two segments of slot i (0 .. 23) of a layer's weight stream
+__device__ __forceinline__ const char* packed_seg(const PackedF32sLayer& Lw, int i, int sgm) {
+    if (i < 6) return Lw.wqkv + (size_t)(2 * i + sgm) * BLK3_BYTES;
+    if (i < 8) return Lw.wo + (size_t)(2 * (i - 6) + sgm) * BLK3_BYTES;
+    const int c = (i - 8) >> 2, r = (i - 8) & 3;
+    return r < 2 ? Lw.w1 + (size_t)(4 * c + 2 * r + sgm) * BLK3_BYTES : Lw.w2 + (size_t)((2 * (r - 2) + sgm) * 32 + 8 * c) * TFRAG_BYTES;
+}
 
 __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float* __restrict__ x, int B, int T, int F, int nblk,
                                                                      PackedF32sModel M, float qscale, float* __restrict__ out,
@@ -606,25 +739,16 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = blockIdx.x * 4 + w;
     const bool live = blk < nblk;  // wave-uniform; a wave without a block still moves its share of the weight stream
-    const Ring3 ring{smem, w, lane};
-    const int L = M.L, NS = 24 * L;
-    auto issue = [&](int t) {
-        const int l = t / 24, i = t - 24 * l;
-        const PackedF32sLayer Lw = M.layer[l];
-        ring.issue(t, [&](int sgm) -> const char* {
-            if (i < 6) return Lw.wqkv + (size_t)(2 * i + sgm) * BLK3_BYTES;
-            if (i < 8) return Lw.wo + (size_t)(2 * (i - 6) + sgm) * BLK3_BYTES;
-            const int c = (i - 8) >> 2, r = (i - 8) & 3;
-            return r < 2 ? Lw.w1 + (size_t)(4 * c + 2 * r + sgm) * BLK3_BYTES
-                         : Lw.w2 + (size_t)((2 * (r - 2) + sgm) * 32 + 8 * c) * TFRAG_BYTES;
-        });
+    const Ring3 ring(smem, w, lane);
+    const int L = M.L;
+    // slot i of layer l (24 % 3 == 0: slot i of any layer sits at ring position i % 3); i >= 24: the next layer's (behind the last: its own)
+    auto job = [&](int l, int i) {
+        const int ll = i < 24 ? l : (l + 1 < L ? l + 1 : l), ii = i < 24 ? i : i - 24;
+        const PackedF32sLayer Lw = M.layer[ll];
+        return ring.job(ii, packed_seg(Lw, ii, 0), packed_seg(Lw, ii, 1));
     };
-    auto advance = [&](int t) {
-        ring.acquire(NS - 1 - t < 1 ? NS - 1 - t : 1);
-        if (t + 2 < NS) issue(t + 2);
-    };
-    issue(0);
-    issue(1);
+    ring.issue_all(job(0, 0));
+    ring.issue_all(job(0, 1));
     for (int i = threadIdx.x * 4; i < L * LBIAS; i += 1024) st4(lbias + i, ld4(M.bias + i));  // published by the first ring barrier
     float* lwc = lbias + L * LBIAS;  // the classifier's folded weights [2][D] + bias [2] behind the biases
     for (int i = threadIdx.x * 4; i < 2 * D; i += 1024) st4(lwc + i, ld4(M.wc + i));
@@ -668,19 +792,20 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float
     Tri xp[8];
     split_row(xg, xp);
 
+    // acquire slot I_ of the layer, then acc0 / acc1 += slot . operand with the DMA of slot I_ + 2 between the MFMAs
+#define SAVAD_PK_GEMM(I_, SWAP_, acc0, acc1, operand)                                                                         \
+    ring.acquire<1>();                                                                                                        \
+    gemm_slot<SWAP_, true>(acc0, acc1, ring.slot(I_), operand, ring, job(l, (I_) + 2));
 #pragma unroll 1
     for (int l = 0; l < L; ++l) {
-        const int t0 = 24 * l;
         const float* lb = lbias + l * LBIAS;
         const float *lb1 = lb, *lb2 = lb + DFF, *lbn = lb + DFF + D, *lbo = lb + DFF + 4 * D;
         // ---- Q (pre-scaled by log2(e)/sqrt(D)) and K in row layout -> triples
         Tri qp[8], kp[8];
 #pragma unroll
         for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] = bias_block(lbn + 32 * nbl, h);
-        advance(t0);
-        gemm_slot<false>(acc[0], acc[1], ring.slot(t0), xp, lane);
-        advance(t0 + 1);
-        gemm_slot<false>(acc[2], acc[3], ring.slot(t0 + 1), xp, lane);
+        SAVAD_PK_GEMM(0, false, acc[0], acc[1], xp)
+        SAVAD_PK_GEMM(1, false, acc[2], acc[3], xp)
 #pragma unroll
         for (int nbl = 0; nbl < 4; ++nbl) {
             acc[nbl] *= qscale;
@@ -689,10 +814,8 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float
         }
 #pragma unroll
         for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] = bias_block(lbn + D + 32 * nbl, h);
-        advance(t0 + 2);
-        gemm_slot<false>(acc[0], acc[1], ring.slot(t0 + 2), xp, lane);
-        advance(t0 + 3);
-        gemm_slot<false>(acc[2], acc[3], ring.slot(t0 + 3), xp, lane);
+        SAVAD_PK_GEMM(2, false, acc[0], acc[1], xp)
+        SAVAD_PK_GEMM(3, false, acc[2], acc[3], xp)
 #pragma unroll
         for (int nbl = 0; nbl < 4; ++nbl) {
             kp[2 * nbl] = split_half(acc[nbl], 0);
@@ -734,10 +857,8 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nbl][r] = bv;
         }
-        advance(t0 + 4);
-        gemm_slot<true>(acc[0], acc[1], ring.slot(t0 + 4), xp, lane);
-        advance(t0 + 5);
-        gemm_slot<true>(acc[2], acc[3], ring.slot(t0 + 5), xp, lane);
+        SAVAD_PK_GEMM(4, true, acc[0], acc[1], xp)
+        SAVAD_PK_GEMM(5, true, acc[2], acc[3], xp)
         {
             const float inv = 1.0f / half_sum(l_run);
 #pragma unroll
@@ -760,39 +881,32 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float
         f32x16(&h1)[4] = hres;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) h1[nb] += bias_block(lbo + 32 * nb, h);
-        advance(t0 + 6);
-        gemm_slot<false>(h1[0], h1[1], ring.slot(t0 + 6), xp, lane);
-        advance(t0 + 7);
-        gemm_slot<false>(h1[2], h1[3], ring.slot(t0 + 7), xp, lane);
+        SAVAD_PK_GEMM(6, false, h1[0], h1[1], xp)
+        SAVAD_PK_GEMM(7, false, h1[2], h1[3], xp)
         layernorm_regs(h1, xg);
         split_row(xg, xp);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) h1[nb] += bias_block(lb2 + 32 * nb, h);
-#pragma unroll 1
-        for (int ch = 0; ch < 4; ++ch) {
-            const int tc = t0 + 8 + 4 * ch;
-#pragma unroll
-            for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] = bias_block(lb1 + 128 * ch + 32 * nbl, h);
-            advance(tc);
-            gemm_slot<false>(acc[0], acc[1], ring.slot(tc), xp, lane);
-            advance(tc + 1);
-            gemm_slot<false>(acc[2], acc[3], ring.slot(tc + 1), xp, lane);
-            Tri ap[8];
-#pragma unroll
-            for (int nbl = 0; nbl < 4; ++nbl) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nbl][r] = fmaxf(acc[nbl][r], 0.0f);
-                ap[2 * nbl] = split_half(acc[nbl], 0);
-                ap[2 * nbl + 1] = split_half(acc[nbl], 1);
-            }
-            advance(tc + 2);
-            gemm_slot<false>(h1[0], h1[1], ring.slot(tc + 2), ap, lane);
-            advance(tc + 3);
-            gemm_slot<false>(h1[2], h1[3], ring.slot(tc + 3), ap, lane);
-        }
+#define SAVAD_PK_FFN(ch)                                                                                                      \
+    {                                                                                                                         \
+        _Pragma("unroll") for (int nbl = 0; nbl < 4; ++nbl) acc[nbl] = bias_block(lb1 + 128 * (ch) + 32 * nbl, h);            \
+        SAVAD_PK_GEMM(8 + 4 * (ch), false, acc[0], acc[1], xp)                                                                \
+        SAVAD_PK_GEMM(9 + 4 * (ch), false, acc[2], acc[3], xp)                                                                \
+        Tri ap[8];                                                                                                            \
+        _Pragma("unroll") for (int nbl = 0; nbl < 4; ++nbl) {                                                                 \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[nbl][r] = fmaxf(acc[nbl][r], 0.0f);                            \
+            ap[2 * nbl] = split_half(acc[nbl], 0);                                                                            \
+            ap[2 * nbl + 1] = split_half(acc[nbl], 1);                                                                        \
+        }                                                                                                                     \
+        SAVAD_PK_GEMM(10 + 4 * (ch), false, h1[0], h1[1], ap)                                                                 \
+        SAVAD_PK_GEMM(11 + 4 * (ch), false, h1[2], h1[3], ap)                                                                 \
+    }
+        SAVAD_PK_FFN(0) SAVAD_PK_FFN(1) SAVAD_PK_FFN(2) SAVAD_PK_FFN(3)
+#undef SAVAD_PK_FFN
         layernorm_regs(hres, xg);
         if (l + 1 < L) split_row(xg, xp);
     }
+#undef SAVAD_PK_GEMM
     // ---- final LayerNorm (folded into the classifier) + Linear(D, 2) + log-softmax (vad/models/self_attention.py:26-28)
     float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
@@ -809,6 +923,7 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float
     const float mx = fmaxf(z0, z1);
     const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
     if (h == 0 && valid) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+    wait_vmem_all();  // the two slots requested behind the last layer are never read, but must have landed before the LDS is released
 }
 
 }  // namespace fs
