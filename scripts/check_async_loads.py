@@ -424,6 +424,8 @@ _RING3 = "the 3-slot ring of the fp32s kernels runs two slots ahead: a slot's pi
 DMA_PUBLISH_BARRIERS = {
     "21input_qkv_kernel_f32s": (1, _RING3),
     "25attention_row_kernel_f32s": (1, _RING3),
+    "25attention_row_kernel_f32sILb0ELb0E": (2, _RING3 + "; its prologue requests THREE slots (K(0) alone in front of the stream): the third crosses the first two barriers"),
+    "25attention_row_kernel_f32sILb1ELb0E": (2, _RING3 + "; its prologue requests THREE slots (K(0) alone in front of the stream): the third crosses the first two barriers"),
     "26packed_forward_kernel_f32s": (1, _RING3),
     "attention_pw_kernel_bf16": (99, "a generated instruction stream with a three-stage K / V pipeline; its waits and barriers are modelled instruction by instruction in scripts/gfx950_sim.py"),
     "5savad20attention_row_kernelI": (1, _LAST_PASS),

@@ -192,11 +192,12 @@ struct Ring3 {
         piece<0>(j); piece<1>(j); piece<2>(j); piece<3>(j); piece<4>(j); piece<5>(j);
         piece<6>(j); piece<7>(j); piece<8>(j); piece<9>(j); piece<10>(j); piece<11>(j);
     }
-    // slot t has landed for every wave.  NEWER = slots issued after slot t (1 in the stream, 0 for its last slot)
+    // slot t has landed for every wave.  NEWER = slots issued after slot t (1 in the stream, 2 behind a three-slot prologue, 0 for the
+    // stream's last slot)
     template <int NEWER>
     __device__ __forceinline__ void acquire() const {
         if (SAVAD_ABLATE & 2) return;
-        __builtin_amdgcn_s_waitcnt(bf::Ring<4>::vmcnt_imm(NEWER ? PER : 0));
+        __builtin_amdgcn_s_waitcnt(bf::Ring<4>::vmcnt_imm(NEWER * PER));
         asm volatile("" ::: "memory");
         __syncthreads();
     }
@@ -375,26 +376,97 @@ __global__ __launch_bounds__(256, 1) void input_qkv_kernel_f32s(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// Attention on triples (vad/modeling/transformer.py:305-346,351-363), one 32-key tile:
-//   S^T = K Q^T as 8 K-steps x 6 products on two accumulators (negm rides in as C of one of them), the fp32 online softmax
-//   of savad_kernels_bf16.h, P split into its three pieces, O^T += V^T P^T as 4 x 2 x 6 products.
-// LDS: K triples read by hand two K-steps ahead of their MFMAs, V^T triples one group (two triples) ahead -- the first group is
-// requested BEFORE the softmax, so its round trip hides under the exponentials; DMA: the twelve pieces of `job` go out between the
-// PV groups.  GLOBAL = false: kblk / vtblk are LDS ring addresses; true (T <= 32, one tile, nothing shared): global memory.
+// Attention on triples (vad/modeling/transformer.py:305-346,351-363), SOFTWARE-PIPELINED over the key tiles: with one wave per SIMD
+// nothing else covers the ~190 VALU instructions a tile's softmax and the split of its probabilities cost, so step j of a wave runs
+//
+//      region A:   S(j+1)^T = K(j+1) Q^T   48 MFMAs on two accumulators (the standing reference -negm rides in as C of one of them)
+//                  || exponentials, row sums and the three-piece split of tile j's probabilities (VALU, two scores per K-step)
+//      region B:   O^T += V(j)^T P(j)^T    48 MFMAs on the four context accumulators
+//                  || row maxima of S(j+1) against the reference, the DMA pieces of ring slot j + 2
+//      (rare)      a row maximum left the 2^16 window: move the reference -- rescale O and l, shift S(j+1)
+//
+// in ONE ring slot: slot j of the stream holds V(j)^T and K(j+1) (K(0) travels in a slot of its own in front).  LDS: K triples are
+// read by hand two K-steps ahead of their MFMAs, V^T triples one group (two triples) ahead, the first group before region A ends.
+// The arithmetic is attn_tile's of savad_kernels_bf16.h, value for value (the same reference rule, the same order of sums).
 // ---------------------------------------------------------------------------------------------
-template <bool DMA, class Mask>
-__device__ __forceinline__ void attn_tile3(AttnState& st, const Tri (&qp)[8], const char* kblk, const char* vtblk, Mask mask,
-                                           bool first, const Ring3& ring, const DmaJob& job) {
-    const unsigned ak = (unsigned)(size_t)kblk + (unsigned)ring.lane * 16u, av = (unsigned)(size_t)vtblk + (unsigned)ring.lane * 16u;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> their three bf16 pieces, packed pairwise (the dwords of a fragment)
+__device__ __forceinline__ void split_pair(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+    __bf16 h0, m0, l0, h1, m1, l1;
+    split1(a0, h0, m0, l0);
+    split1(a1, h1, m1, l1);
+    h = __builtin_bit_cast(unsigned, bf16x2{h0, h1});
+    m = __builtin_bit_cast(unsigned, bf16x2{m0, m1});
+    l = __builtin_bit_cast(unsigned, bf16x2{l0, l1});
+}
+// row maxima of a fresh score tile against the standing reference; the reference moves when a maximum drifts more than
+// 2^RESCALE_LOG2 above it (first tile: away from 0 in either direction) -- online_softmax_shifted's first half
+__device__ __forceinline__ void settle_reference(f32x16& sc, AttnState& st, bool first /* wave-uniform */) {
+    float mx = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+    mx = half_max(mx);
+    const bool move = (mx > RESCALE_LOG2) || (first && mx < -RESCALE_LOG2);
+    if (__any(move)) {
+        const float d = move ? mx : 0.0f;  // new reference = old + d: the row maximum becomes 0
+        if (!first) {                      // on the first tile O and l are still zero (and 2^-d may overflow)
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            st.l_run *= alpha;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) st.O[nb] *= alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] -= d;
+            st.negm[r] -= d;
+        }
+    }
+}
+// scores of key tile 0 (prologue: nothing to overlap with yet); kblk = LDS address of the K triples
+__device__ __forceinline__ f32x16 qk_tile3(const AttnState& st, const Tri (&qp)[8], const char* kblk, int lane) {
     f32x16 sa = st.negm, sb = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const Tri k = ldtri(kblk + ks * TFRAG_BYTES + lane * 16);
+        sa = SAVAD_MF(k.h, qp[ks].l, sa);
+        sb = SAVAD_MF(k.l, qp[ks].h, sb);
+        sa = SAVAD_MF(k.m, qp[ks].m, sa);
+        sb = SAVAD_MF(k.h, qp[ks].m, sb);
+        sa = SAVAD_MF(k.m, qp[ks].h, sa);
+        sb = SAVAD_MF(k.h, qp[ks].h, sb);
+    }
+    return sa + sb;
+}
+// One pipelined step on ring slot `slot` = [V(j)^T | K(j+1)].  sc: in = tile j's scores relative to the settled reference, out = tile
+// j+1's (HAVE_NEXT), masked by `mask_next` and settled.  DMA: the pieces of `job` go out in region B.
+template <bool HAVE_NEXT, bool DMA, class MaskNext>
+__device__ __forceinline__ void attn_step3(AttnState& st, const Tri (&qp)[8], f32x16& sc, const char* slot, MaskNext mask_next,
+                                           const Ring3& ring, const DmaJob& job) {
+    const unsigned av = (unsigned)(size_t)slot + (unsigned)ring.lane * 16u, ak = av + BLK3_BYTES;
+    f32x16 sa = st.negm, sb = zero16();
+    unsigned ph[8], pm[8], pl[8];   // the dwords of p0 (0..3) and p1 (4..7), piece by piece
+    float rs = 0.0f;
     u32x4 fk[3][3];
+    u32x4 fv[2][6];
 #define SAVAD_A_LDK(ks, i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fk[(ks) % 3][i]) : "v"(ak), "n"((ks) * TFRAG_BYTES + (i) * FRAG_BYTES))
 #define SAVAD_A_LDK3(ks) SAVAD_A_LDK(ks, 0); SAVAD_A_LDK(ks, 1); SAVAD_A_LDK(ks, 2)
+#define SAVAD_A_LDV(g, i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fv[(g) & 1][i]) : "v"(av), "n"((((2 * ((g) >> 1) + (i) / 3) * 2 + ((g) & 1)) * 3 + (i) % 3) * FRAG_BYTES))
+#define SAVAD_A_LDV6(g) SAVAD_A_LDV(g, 0); SAVAD_A_LDV(g, 1); SAVAD_A_LDV(g, 2); SAVAD_A_LDV(g, 3); SAVAD_A_LDV(g, 4); SAVAD_A_LDV(g, 5)
+    // the VALU slice of K-step ks: scores 2 ks, 2 ks + 1 of tile j -> probabilities, row sum, pieces
+#define SAVAD_A_SOFT(ks)                                                                                                       \
+    {                                                                                                                          \
+        const float e0_ = (SAVAD_ABLATE & 4) ? sc[2 * (ks)] : __builtin_amdgcn_exp2f(sc[2 * (ks)]);                            \
+        const float e1_ = (SAVAD_ABLATE & 4) ? sc[2 * (ks) + 1] : __builtin_amdgcn_exp2f(sc[2 * (ks) + 1]);                    \
+        rs += e0_;                                                                                                             \
+        rs += e1_;                                                                                                             \
+        split_pair(e0_, e1_, ph[ks], pm[ks], pl[ks]);                                                                          \
+    }
 #define SAVAD_A_QK(ks)                                                                                                         \
     {                                                                                                                          \
         if constexpr ((ks) + 2 < 8) { SAVAD_A_LDK3((ks) + 2); }                                                                \
+        if constexpr ((ks) == 6) { SAVAD_A_LDV6(0); }                                                                          \
         asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fk[(ks) % 3][0]), "+v"(fk[(ks) % 3][1]), "+v"(fk[(ks) % 3][2])             \
-                     : "n"((ks) + 2 < 8 ? 6 : ((ks) + 1 < 8 ? 3 : 0)));                                                        \
+                     : "n"((ks) + 2 < 8 ? 6 : ((ks) == 6 ? 9 : 6)));                                                           \
         const bf16x8 kh_ = __builtin_bit_cast(bf16x8, fk[(ks) % 3][0]), km_ = __builtin_bit_cast(bf16x8, fk[(ks) % 3][1]),     \
                      kl_ = __builtin_bit_cast(bf16x8, fk[(ks) % 3][2]);                                                        \
         sa = SAVAD_MF(kh_, qp[ks].l, sa);                                                                                      \
@@ -403,22 +475,29 @@ __device__ __forceinline__ void attn_tile3(AttnState& st, const Tri (&qp)[8], co
         sb = SAVAD_MF(kh_, qp[ks].m, sb);                                                                                      \
         sa = SAVAD_MF(km_, qp[ks].h, sa);                                                                                      \
         sb = SAVAD_MF(kh_, qp[ks].h, sb);                                                                                      \
+        SAVAD_A_SOFT(ks)                                                                                                       \
     }
-    SAVAD_A_LDK3(0);
-    SAVAD_A_LDK3(1);
-    SAVAD_A_QK(0) SAVAD_A_QK(1) SAVAD_A_QK(2) SAVAD_A_QK(3) SAVAD_A_QK(4) SAVAD_A_QK(5) SAVAD_A_QK(6) SAVAD_A_QK(7)
+    // ---- region A
+    if constexpr (HAVE_NEXT) {
+        SAVAD_A_LDK3(0);
+        SAVAD_A_LDK3(1);
+        // waits: K-steps 0..5 leave the two younger K-steps' six reads in flight; K-step 6 the last K-step's three and the six of
+        // V group 0 (requested just before it); K-step 7 those six
+        SAVAD_A_QK(0) SAVAD_A_QK(1) SAVAD_A_QK(2) SAVAD_A_QK(3) SAVAD_A_QK(4) SAVAD_A_QK(5) SAVAD_A_QK(6) SAVAD_A_QK(7)
+    } else {
+        SAVAD_A_LDV6(0);
+        SAVAD_A_SOFT(0) SAVAD_A_SOFT(1) SAVAD_A_SOFT(2) SAVAD_A_SOFT(3) SAVAD_A_SOFT(4) SAVAD_A_SOFT(5) SAVAD_A_SOFT(6) SAVAD_A_SOFT(7)
+    }
 #undef SAVAD_A_QK
+#undef SAVAD_A_SOFT
 #undef SAVAD_A_LDK3
 #undef SAVAD_A_LDK
-    // PV group g = 2 (nbd pair) + j: the triples of (nbd, j) and (nbd + 1, j), nbd = 2 (g >> 1), j = g & 1
-    u32x4 fv[2][6];
-#define SAVAD_A_LDV(g, i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fv[(g) & 1][i]) : "v"(av), "n"((((2 * ((g) >> 1) + (i) / 3) * 2 + ((g) & 1)) * 3 + (i) % 3) * FRAG_BYTES))
-#define SAVAD_A_LDV6(g) SAVAD_A_LDV(g, 0); SAVAD_A_LDV(g, 1); SAVAD_A_LDV(g, 2); SAVAD_A_LDV(g, 3); SAVAD_A_LDV(g, 4); SAVAD_A_LDV(g, 5)
-    SAVAD_A_LDV6(0);
-    f32x16 sc = sa + sb;
-    mask(sc);
-    if (!(SAVAD_ABLATE & 4)) online_softmax_shifted(sc, st, first);
-    const Tri p0 = split_half(sc, 0), p1 = split_half(sc, 1);
+    st.l_run += rs;  // this lane's half of the row sum: the two halves meet once, when the context is normalised
+    const Tri p0{__builtin_bit_cast(bf16x8, u32x4{ph[0], ph[1], ph[2], ph[3]}), __builtin_bit_cast(bf16x8, u32x4{pm[0], pm[1], pm[2], pm[3]}),
+                 __builtin_bit_cast(bf16x8, u32x4{pl[0], pl[1], pl[2], pl[3]})};
+    const Tri p1{__builtin_bit_cast(bf16x8, u32x4{ph[4], ph[5], ph[6], ph[7]}), __builtin_bit_cast(bf16x8, u32x4{pm[4], pm[5], pm[6], pm[7]}),
+                 __builtin_bit_cast(bf16x8, u32x4{pl[4], pl[5], pl[6], pl[7]})};
+    // ---- region B: PV group g = the triples of (nbd, j) and (nbd + 1, j), nbd = 2 (g >> 1), j = g & 1
 #define SAVAD_A_PV(g, PJ)                                                                                                      \
     {                                                                                                                          \
         if constexpr ((g) + 1 < 4) { SAVAD_A_LDV6((g) + 1); }                                                                  \
@@ -437,10 +516,16 @@ __device__ __forceinline__ void attn_tile3(AttnState& st, const Tri (&qp)[8], co
             ring.template piece<3 * (g) + 2>(job);                                                                             \
         }                                                                                                                      \
     }
-    SAVAD_A_PV(0, p0) SAVAD_A_PV(1, p1) SAVAD_A_PV(2, p0) SAVAD_A_PV(3, p1)
+    SAVAD_A_PV(0, p0) SAVAD_A_PV(1, p1)
+    if constexpr (HAVE_NEXT) {   // tile j + 1's scores leave the accumulators while the last PV groups run
+        sc = sa + sb;
+        mask_next(sc);
+    }
+    SAVAD_A_PV(2, p0) SAVAD_A_PV(3, p1)
 #undef SAVAD_A_PV
 #undef SAVAD_A_LDV6
 #undef SAVAD_A_LDV
+    if constexpr (HAVE_NEXT) settle_reference(sc, st, false);
 }
 // the same tile with K / V^T in global memory (T <= 32: a block attends to itself; nothing to share, no ring)
 template <class Mask>
@@ -646,35 +731,45 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
         blk_q = b * QB + (active ? qb : qb0);
         qvalid = active && 32 * qb + m < T;
         base = QB;
-        // stream index u: key tiles 0 .. QB-1, then the row chain's slots
+        // stream index u: slot u = [V(u)^T | K(u+1)] for the key tiles 0 .. QB-1 (K(0) in a slot of its own in front: u = -1, at ring
+        // position 2), then the row chain's slots; behind the last key tile K is a re-read of that tile (never used)
         auto job = [&](int u) {
             if (u < QB) {
-                const size_t kb = (size_t)b * QB + u;
-                return ring.job(u, kf + kb * BLK3_BYTES, vtf + kb * BLK3_BYTES);
+                const size_t kb = (size_t)b * QB;
+                const int uv = u < 0 ? 0 : u, uk = u + 1 < QB ? u + 1 : QB - 1;
+                return ring.job(u + 3, vtf + (kb + uv) * BLK3_BYTES, kf + (kb + uk) * BLK3_BYTES);
             }
             return ring.job(u, row_seg(A, u - QB, 0), row_seg(A, u - QB, 1));
         };
-        ring.issue_all(job(0));
-        ring.issue_all(job(1));
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qp[ks] = ldtri(qf + (size_t)blk_q * BLK3_BYTES + ks * TFRAG_BYTES + lane * 16);
-        if (active) {
-#pragma unroll 1
-            for (int jt = 0; jt < QB; ++jt) {
-                ring.acquire<1>();
-                const DmaJob nxt = job(jt + 2);
-                const char* buf = ring.slot(jt);
-                auto mask = [&](f32x16& sc) {  // a REAL (wave-uniform) branch: only the last tile of a ragged sequence has missing keys
-                    if (32 * jt + 32 > T) {
-                        asm volatile("" ::: "memory");
-                        const int lim = T - 32 * jt - 4 * h;
+        ring.issue_all(job(-1));
+        ring.issue_all(job(0));
+        ring.issue_all(job(1));
+        const int lim = T - 32 * (QB - 1) - 4 * h;   // keys of the last tile that exist, from this lane's first one
+        auto no_mask = [](f32x16&) {};
+        auto tail_mask = [&](f32x16& sc) {   // (only the last tile of a ragged sequence has missing keys)
+            if (32 * QB > T) {
+                asm volatile("" ::: "memory");
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) sc[r] = (8 * (r >> 2) + (r & 3) < lim) ? sc[r] : NEG_BIG;
-                    }
-                };
-                attn_tile3<true>(st, qp, buf, buf + BLK3_BYTES, mask, jt == 0, ring, nxt);
+                for (int r = 0; r < 16; ++r) sc[r] = (8 * (r >> 2) + (r & 3) < lim) ? sc[r] : NEG_BIG;
             }
+        };
+        if (active) {
+            ring.acquire<2>();   // K(0) has landed; slots 0 and 1 may still be in flight
+            f32x16 sc = qk_tile3(st, qp, ring.slot(2) + BLK3_BYTES, lane);
+            settle_reference(sc, st, true);
+#pragma unroll 1
+            for (int jt = 0; jt + 2 < QB; ++jt) {
+                ring.acquire<1>();
+                attn_step3<true, true>(st, qp, sc, ring.slot(jt), no_mask, ring, job(jt + 2));
+            }
+            ring.acquire<1>();
+            attn_step3<true, true>(st, qp, sc, ring.slot(QB - 2), tail_mask, ring, job(QB));        // -> the last tile's scores, masked
+            ring.acquire<1>();
+            attn_step3<false, true>(st, qp, sc, ring.slot(QB - 1), no_mask, ring, job(QB + 1));
         } else {  // a wave without a query block still moves its share of the stream and meets the others at every barrier
+            ring.acquire<2>();
 #pragma unroll 1
             for (int jt = 0; jt < QB; ++jt) {
                 ring.acquire<1>();
