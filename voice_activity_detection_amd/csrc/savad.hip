@@ -2035,6 +2035,11 @@ SAVAD_EXPORT int savad_optimal_split(const double* pred, const double* probs, lo
 
 #ifdef SAVAD_TIMING
 // experiments only: read the phase stamps of the last row_kernel_m launch
+SAVAD_EXPORT int savad_debug_wg_stamps(long long* out, int n) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(savad::g_savad_wg), sizeof(long long) * n));
+    return SAVAD_OK;
+}
 SAVAD_EXPORT int savad_debug_stamps(long long* out, int n) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(savad::g_savad_dbg), sizeof(long long) * n));

@@ -31,6 +31,9 @@
 #include "savad_kernels_bf16.h"
 
 namespace savad {
+#ifdef SAVAD_TIMING
+__device__ long long g_savad_wg[1024][4];   // per workgroup of the fp32s fused launch: s_memtime at start / end, s_memrealtime at start / end
+#endif
 namespace fs {
 
 using bf::bf16x8;
@@ -113,12 +116,21 @@ __device__ __forceinline__ Tri zero_tri() {
 // its producer waits ~6 cycles: 43 against 37.6 cycles per MFMA with one wave per SIMD, scripts/ubench/split6_probe.hip).
 // SWAP: operands exchanged (acc = B . A^T form: the V^T projection)
 template <bool SWAP>
-__device__ __forceinline__ void mfma6x2(f32x16& acc0, f32x16& acc1, const Tri& a0, const Tri& a1, const Tri& b) {
+__device__ __forceinline__ void mfma6x2_lo(f32x16& acc0, f32x16& acc1, const Tri& a0, const Tri& a1, const Tri& b) {
 #define SAVAD_MF2(pa, pb)                                                           \
     acc0 = SWAP ? SAVAD_MF(b.pb, a0.pa, acc0) : SAVAD_MF(a0.pa, b.pb, acc0);        \
     acc1 = SWAP ? SAVAD_MF(b.pb, a1.pa, acc1) : SAVAD_MF(a1.pa, b.pb, acc1);
-    SAVAD_MF2(h, l) SAVAD_MF2(l, h) SAVAD_MF2(m, m) SAVAD_MF2(h, m) SAVAD_MF2(m, h) SAVAD_MF2(h, h)
+    SAVAD_MF2(h, l) SAVAD_MF2(l, h) SAVAD_MF2(m, m)
+}
+template <bool SWAP>
+__device__ __forceinline__ void mfma6x2_hi(f32x16& acc0, f32x16& acc1, const Tri& a0, const Tri& a1, const Tri& b) {
+    SAVAD_MF2(h, m) SAVAD_MF2(m, h) SAVAD_MF2(h, h)
 #undef SAVAD_MF2
+}
+template <bool SWAP>
+__device__ __forceinline__ void mfma6x2(f32x16& acc0, f32x16& acc1, const Tri& a0, const Tri& a1, const Tri& b) {
+    mfma6x2_lo<SWAP>(acc0, acc1, a0, a1, b);
+    mfma6x2_hi<SWAP>(acc0, acc1, a0, a1, b);
 }
 
 // ---- residual stream blocks (fp32, fragment-major: every access a contiguous 1 KiB wave access)
@@ -156,6 +168,9 @@ __device__ __forceinline__ void store_hblock32(float* hb, const f32x16 (&x)[4], 
 //
 // Every wait is the same unconditional instruction (no run-time choice of the count: scripts/check_async_loads.py follows it
 // statically); the two waits at the END of a stream, where nothing younger is in flight, are vmcnt(0) at compile-time positions.
+#ifndef SAVAD_PIECE_FENCE
+#define SAVAD_PIECE_FENCE 0x6   // __builtin_amdgcn_sched_barrier mask around a DMA piece: only VALU / SALU may move across it
+#endif
 struct DmaJob {
     const char* src;  // wave-uniform: this wave's 12 KiB of the slot in global memory
     unsigned ldsb;    // ... and their place in LDS (byte address)
@@ -180,6 +195,12 @@ struct Ring3 {
     template <int I>
     __device__ __forceinline__ void piece(const DmaJob& j) const {
         if (SAVAD_ABLATE & 1) return;
+        __builtin_amdgcn_sched_barrier(SAVAD_PIECE_FENCE);   // the piece stays where the source puts it: ONE between two groups of MFMAs
+        piece_raw<I>(j);
+        __builtin_amdgcn_sched_barrier(SAVAD_PIECE_FENCE);
+    }
+    template <int I>
+    __device__ __forceinline__ void piece_raw(const DmaJob& j) const {
         asm volatile(
             "s_add_u32 m0, %2, %3\n\t"
             "s_nop 0\n\t"
@@ -189,8 +210,9 @@ struct Ring3 {
             : "memory", "scc");
     }
     __device__ __forceinline__ void issue_all(const DmaJob& j) const {  // prologues: nothing to hide the pieces behind yet
-        piece<0>(j); piece<1>(j); piece<2>(j); piece<3>(j); piece<4>(j); piece<5>(j);
-        piece<6>(j); piece<7>(j); piece<8>(j); piece<9>(j); piece<10>(j); piece<11>(j);
+        if (SAVAD_ABLATE & 1) return;
+        piece_raw<0>(j); piece_raw<1>(j); piece_raw<2>(j); piece_raw<3>(j); piece_raw<4>(j); piece_raw<5>(j);
+        piece_raw<6>(j); piece_raw<7>(j); piece_raw<8>(j); piece_raw<9>(j); piece_raw<10>(j); piece_raw<11>(j);
     }
     // slot t has landed for every wave.  NEWER = slots issued after slot t (1 in the stream, 2 behind a three-slot prologue, 0 for the
     // stream's last slot)
@@ -231,15 +253,15 @@ __device__ __forceinline__ void gemm_slot(f32x16& acc0, f32x16& acc1, const char
                       __builtin_bit_cast(bf16x8, f[(ks) & 1][2])};                                                            \
         const Tri w1_{__builtin_bit_cast(bf16x8, f[(ks) & 1][3]), __builtin_bit_cast(bf16x8, f[(ks) & 1][4]),                  \
                       __builtin_bit_cast(bf16x8, f[(ks) & 1][5])};                                                            \
-        mfma6x2<SWAP>(acc0, acc1, w0_, w1_, xp[ks]);                                                                          \
-        if constexpr (DMA) {                                                                                                  \
-            ring.template piece<P0>(job);                                                                                     \
-            if constexpr ((P1) >= 0) ring.template piece<((P1) >= 0 ? (P1) : 0)>(job);                                        \
-        }                                                                                                                     \
+        mfma6x2_lo<SWAP>(acc0, acc1, w0_, w1_, xp[ks]);                                                                       \
+        if constexpr (DMA && (P1) >= 0) ring.template piece<((P1) >= 0 ? (P1) : 0)>(job);                                     \
+        mfma6x2_hi<SWAP>(acc0, acc1, w0_, w1_, xp[ks]);                                                                       \
+        if constexpr (DMA) ring.template piece<P0>(job);                                                                      \
     }
     SAVAD_G_LD6(0);
-    SAVAD_G_STEP(0, 0, 1) SAVAD_G_STEP(1, 2, -1) SAVAD_G_STEP(2, 3, 4) SAVAD_G_STEP(3, 5, -1)
-    SAVAD_G_STEP(4, 6, 7) SAVAD_G_STEP(5, 8, -1) SAVAD_G_STEP(6, 9, 10) SAVAD_G_STEP(7, 11, -1)
+    // (P0 behind the K-step's twelve MFMAs, P1 -- every other K-step -- in their middle: one piece per six or twelve MFMAs)
+    SAVAD_G_STEP(0, 1, 0) SAVAD_G_STEP(1, 2, -1) SAVAD_G_STEP(2, 4, 3) SAVAD_G_STEP(3, 5, -1)
+    SAVAD_G_STEP(4, 7, 6) SAVAD_G_STEP(5, 8, -1) SAVAD_G_STEP(6, 10, 9) SAVAD_G_STEP(7, 11, -1)
 #undef SAVAD_G_STEP
 #undef SAVAD_G_LD6
 #undef SAVAD_G_LD
@@ -589,6 +611,32 @@ __device__ __forceinline__ const char* row_seg(const RowArgs3& A, int t, int sgm
     return A.wn_frag + (size_t)(2 * (t - 18) + sgm) * BLK3_BYTES;
 }
 
+// the row chain's biases (LAST: the classifier's folded weights and bias in the Q/K/V slot) -> LDS behind the ring; called at the head
+// of the kernel, so that their round trip to memory is long over when the chain starts; published by any workgroup barrier
+template <bool LAST>
+struct RowBiases {
+    BiasPiece pieces[4];
+    BiasRegs<4> regs;
+    float bc;
+    float* lbn;
+    __device__ __forceinline__ RowBiases(const RowArgs3& A, char* smem) {   // requests the loads
+        float* lbo = reinterpret_cast<float*>(smem + NRING3 * SLOT_BYTES);
+        float* lb1 = lbo + D;
+        float* lb2 = lb1 + DFF;
+        lbn = lb2 + D;
+        pieces[0] = BiasPiece{lbo, A.bo, D};
+        pieces[1] = BiasPiece{lb1, A.b1, DFF};
+        pieces[2] = BiasPiece{lb2, A.b2, D};
+        pieces[3] = BiasPiece{lbn, LAST ? A.wc : A.bn, LAST ? 2 * D : 3 * D};
+        regs = request_bias_pieces(pieces);
+        bc = LAST ? A.bn[threadIdx.x & 1] : 0.0f;
+    }
+    __device__ __forceinline__ void commit() const {   // ... and writes them to LDS
+        commit_bias_pieces(pieces, regs);
+        if (LAST && threadIdx.x < 2) lbn[2 * D + threadIdx.x] = bc;
+    }
+};
+
 template <bool LAST, bool PREFETCHED>
 __device__ __forceinline__ void row_stage_f32s(const RowArgs3& A, char* smem, Tri (&xp)[8], int blk, bool live, const Ring3& ring, int base) {
     float* lbo = reinterpret_cast<float*>(smem + NRING3 * SLOT_BYTES);
@@ -605,27 +653,31 @@ __device__ __forceinline__ void row_stage_f32s(const RowArgs3& A, char* smem, Tr
     }
     // acquire slot T_, then acc0 / acc1 += slot . operand with the DMA of slot T_ + 2 between the MFMAs
 #define SAVAD_ROW_GEMM(T_, acc0, acc1, operand)                                                                               \
+    if ((T_) < 8) SAVAD_STAMP(24 + 3 * (T_));                                                                                 \
     ring.acquire<((T_) + 1 < NSLOT) ? 1 : 0>();                                                                               \
-    gemm_slot<false, ((T_) + 2 < NSLOT)>(acc0, acc1, ring.slot(base + (T_)), operand, ring, (T_) + 2 < NSLOT ? job((T_) + 2) : none);
-    const BiasPiece pieces[4] = {{lbo, A.bo, D}, {lb1, A.b1, DFF}, {lb2, A.b2, D}, {lbn, LAST ? A.wc : A.bn, LAST ? 2 * D : 3 * D}};
-    const BiasRegs<4> breg = request_bias_pieces(pieces);
-    const float bc = LAST ? A.bn[threadIdx.x & 1] : 0.0f;
+    if ((T_) < 8) SAVAD_STAMP(25 + 3 * (T_));                                                                                 \
+    gemm_slot<false, ((T_) + 2 < NSLOT)>(acc0, acc1, ring.slot(base + (T_)), operand, ring, (T_) + 2 < NSLOT ? job((T_) + 2) : none); \
+    if ((T_) < 8) SAVAD_STAMP(26 + 3 * (T_));
     float* hb = A.hbuf + (size_t)blk * (32 * D);
+    // the residual block is requested here and added BEHIND the out-projection's MFMAs: its round trip to memory hides under them
+    // ---- h1 = h + (bo + ctx Wo^T)   (the biases were staged by stage_row_biases at the head of the kernel; any barrier since publishes them)
+    ring.acquire<1>();
+    f32x16 hres[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) hres[nb] = zero16();
+    if (live) load_hblock32(hres, hb, lane);
     f32x16 h1[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) h1[nb] = zero16();
-    if (live) load_hblock32(h1, hb, lane);
-    commit_bias_pieces(pieces, breg);
-    if (LAST && threadIdx.x < 2) lbn[2 * D + threadIdx.x] = bc;
-    // ---- h1 = h + bo + ctx Wo^T   (the biases are published by slot 0's barrier)
-    ring.acquire<1>();
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) h1[nb] += bias_block(lbo + 32 * nb, h);
+    for (int nb = 0; nb < 4; ++nb) h1[nb] = bias_block(lbo + 32 * nb, h);
     gemm_slot<false, true>(h1[0], h1[1], ring.slot(base), xp, ring, job(2));
     SAVAD_ROW_GEMM(1, h1[2], h1[3], xp)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) h1[nb] += hres[nb];
+    SAVAD_STAMP(5);
     f32x4 xg[16];
     layernorm_regs(h1, xg);
     split_row(xg, xp);
+    SAVAD_STAMP(6);
     // ---- FFN; its accumulators start from the residual stream (h1 + b2)
     f32x16(&o)[4] = h1;
 #pragma unroll
@@ -636,14 +688,17 @@ __device__ __forceinline__ void row_stage_f32s(const RowArgs3& A, char* smem, Tr
         _Pragma("unroll") for (int nbl = 0; nbl < 4; ++nbl) a[nbl] = bias_block(lb1 + 128 * (ch) + 32 * nbl, h);              \
         SAVAD_ROW_GEMM(2 + 4 * (ch), a[0], a[1], xp)                                                                          \
         SAVAD_ROW_GEMM(3 + 4 * (ch), a[2], a[3], xp)                                                                          \
+        if ((ch) == 0) SAVAD_STAMP(20);                                                                                       \
         Tri ap[8];                                                                                                            \
         _Pragma("unroll") for (int nbl = 0; nbl < 4; ++nbl) {                                                                 \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) a[nbl][r] = fmaxf(a[nbl][r], 0.0f);                                \
             ap[2 * nbl] = split_half(a[nbl], 0);                                                                              \
             ap[2 * nbl + 1] = split_half(a[nbl], 1);                                                                          \
         }                                                                                                                     \
+        if ((ch) == 0) SAVAD_STAMP(21);                                                                                       \
         SAVAD_ROW_GEMM(4 + 4 * (ch), o[0], o[1], ap)                                                                          \
         SAVAD_ROW_GEMM(5 + 4 * (ch), o[2], o[3], ap)                                                                          \
+        SAVAD_STAMP(7 + (ch));                                                                                                \
     }
     SAVAD_ROW_FFN(0) SAVAD_ROW_FFN(1) SAVAD_ROW_FFN(2) SAVAD_ROW_FFN(3)
 #undef SAVAD_ROW_FFN
@@ -652,10 +707,12 @@ __device__ __forceinline__ void row_stage_f32s(const RowArgs3& A, char* smem, Tr
     layernorm_regs(o, xg);
     if constexpr (!LAST) {
         split_row(xg, xp);
+        SAVAD_STAMP(11);
 #define SAVAD_ROW_QKV(S_)                                                                                                     \
     ring.acquire<(18 + (S_) + 1 < NSLOT) ? 1 : 0>();                                                                          \
     qkv_slot<S_, (18 + (S_) + 2 < NSLOT)>(ring.slot(base + 18 + (S_)), xp, lbn, A.qf, A.kf, A.vtf, blk, ring,                 \
-                                          18 + (S_) + 2 < NSLOT ? job(18 + (S_) + 2) : none, A.qscale, live);
+                                          18 + (S_) + 2 < NSLOT ? job(18 + (S_) + 2) : none, A.qscale, live);                 \
+    SAVAD_STAMP(12 + (S_));
         SAVAD_ROW_QKV(0) SAVAD_ROW_QKV(1) SAVAD_ROW_QKV(2) SAVAD_ROW_QKV(3) SAVAD_ROW_QKV(4) SAVAD_ROW_QKV(5)
 #undef SAVAD_ROW_QKV
     } else {
@@ -701,7 +758,16 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
     Tri qp[8];
     int blk_q, base = 0;
     bool active, qvalid;
+    SAVAD_STAMP(0);
+#ifdef SAVAD_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_savad_wg[blockIdx.x][0] = __builtin_readcyclecounter();
+        g_savad_wg[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    const RowBiases<LAST> biases(A, smem);   // requested first: their round trip is over long before the row chain wants them
     if constexpr (PACKED) {
+        biases.commit();
         blk_q = blockIdx.x * 4 + w;
         active = blk_q < A.nblk;
         const int G = 32 / T;
@@ -741,11 +807,12 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
             }
             return ring.job(u, row_seg(A, u - QB, 0), row_seg(A, u - QB, 1));
         };
+        ring.issue_all(job(-1));   // K(0) first: the prologue's scores wait for it
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qp[ks] = ldtri(qf + (size_t)blk_q * BLK3_BYTES + ks * TFRAG_BYTES + lane * 16);
-        ring.issue_all(job(-1));
         ring.issue_all(job(0));
         ring.issue_all(job(1));
+        biases.commit();
         const int lim = T - 32 * (QB - 1) - 4 * h;   // keys of the last tile that exist, from this lane's first one
         auto no_mask = [](f32x16&) {};
         auto tail_mask = [&](f32x16& sc) {   // (only the last tile of a ragged sequence has missing keys)
@@ -755,10 +822,12 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
                 for (int r = 0; r < 16; ++r) sc[r] = (8 * (r >> 2) + (r & 3) < lim) ? sc[r] : NEG_BIG;
             }
         };
+        ring.acquire<2>();   // K(0) has landed; slots 0 and 1 may still be in flight
+        SAVAD_STAMP(1);
         if (active) {
-            ring.acquire<2>();   // K(0) has landed; slots 0 and 1 may still be in flight
             f32x16 sc = qk_tile3(st, qp, ring.slot(2) + BLK3_BYTES, lane);
             settle_reference(sc, st, true);
+            SAVAD_STAMP(2);
 #pragma unroll 1
             for (int jt = 0; jt + 2 < QB; ++jt) {
                 ring.acquire<1>();
@@ -768,8 +837,8 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
             attn_step3<true, true>(st, qp, sc, ring.slot(QB - 2), tail_mask, ring, job(QB));        // -> the last tile's scores, masked
             ring.acquire<1>();
             attn_step3<false, true>(st, qp, sc, ring.slot(QB - 1), no_mask, ring, job(QB + 1));
+            SAVAD_STAMP(3);
         } else {  // a wave without a query block still moves its share of the stream and meets the others at every barrier
-            ring.acquire<2>();
 #pragma unroll 1
             for (int jt = 0; jt < QB; ++jt) {
                 ring.acquire<1>();
@@ -789,7 +858,15 @@ __global__ __launch_bounds__(256, 1) void attention_row_kernel_f32s(const char* 
             xp[2 * nbd + 1] = split_half(st.O[nbd], 1);
         }
     }
+    SAVAD_STAMP(4);
     row_stage_f32s<LAST, !PACKED>(A, smem, xp, blk_q, active, ring, base);
+    SAVAD_STAMP(18);
+#ifdef SAVAD_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_savad_wg[blockIdx.x][1] = __builtin_readcyclecounter();
+        g_savad_wg[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
