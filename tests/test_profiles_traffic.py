@@ -13,7 +13,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 
 # profile name pattern -> (precision, B, T, bytes per element of q / k / v / ctx)
-WORKLOADS = [("bf16_b256", ("bf16", 256, 800, 2)), ("t7_bf16_big", ("bf16", 65536, 7, 2)), ("t7_bf16", ("bf16", 1000, 7, 2)), ("t7", ("fp32", 1000, 7, 4)),
+WORKLOADS = [("fp32s", ("fp32s", 32, 800, 6)), ("bf16_b256", ("bf16", 256, 800, 2)), ("t7_bf16_big", ("bf16", 65536, 7, 2)), ("t7_bf16", ("bf16", 1000, 7, 2)), ("t7", ("fp32", 1000, 7, 4)),
              ("t50", ("fp32", 512, 50, 4)), ("logmel", ("logmel", 57_600_000, 360_001, 4)), ("", ("fp32", 32, 800, 4))]
 # rocprofv3 kernel name (as scripts/summarize_profile.py shortens it) -> bench.py launch label
 LABELS = {
@@ -26,6 +26,8 @@ LABELS = {
     "packed_forward_kernel_bf16<4, 4, 4>": "packed_forward_bf16", "packed_forward_kernel_bf16<4, 2, 0>": "packed_forward_bf16",
     "packed_forward_kernel_bf16_ns": "packed_forward_bf16",
     "logmel_fft_kernel": "logmel",
+    "attention_row_kernel_f32s<false, false>": "attention_row_f32s", "attention_row_kernel_f32s<true, false>": "attention_row_last_f32s",
+    "input_qkv_kernel_f32s": "input_qkv_f32s",
 }
 # explained excesses: kernel -> (bound, why)
 KNOWN = {
