@@ -588,28 +588,26 @@ def clip_pipeline(state, dev, seconds, min_seconds):
         per_call.append(ms / 50)
         spent += ms * 1e-3
     med = statistics.median(per_call)
-    # the same chain with bf16 operands (the single-launch T <= 32 forward in its latency variant), and both as a captured HIP graph
-    # (four launches per clip: at this size the host side is a visible share of the call)
+    # the same chain with bf16 / fp32s operands, and all three as a replayed HIP graph THROUGH THE PRODUCT API
+    # (VADFromScratchPredictor(graph=True).predict_audio_device: four launches per clip -- at this size the host side is a visible
+    # share of the call); the replayed results must be the eager call's bits
     extra = {}
     try:
-        model.precision = "bf16"
-        m16, mn16, _, _ = _event_blocks(chain, 50, min_seconds / 2, warm=30)
-        extra["bf16_ms_per_clip"] = round(m16, 4)
-        for prec in ("fp32", "bf16"):
+        for prec in ("bf16", "fp32s"):
             model.precision = prec
-            for _ in range(3):
-                chain()
-            torch.cuda.synchronize()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                chain()
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                gp, _ = chain()
-            mg, _, _, _ = _event_blocks(g.replay, 50, min_seconds / 2, warm=5)
+            mp, _, _, _ = _event_blocks(chain, 50, min_seconds / 2, warm=30)
+            extra[f"{prec}_ms_per_clip"] = round(mp, 4)
+        pred_g = VADFromScratchPredictor(model, dev, graph=True)
+        same = True
+        for prec in ("fp32", "fp32s", "bf16"):
+            model.precision = prec
+            want, want_mean = chain()
+            got, got_mean = pred_g.predict_audio_device(audio)
+            same = same and bool(torch.equal(got, want)) and bool(torch.equal(got_mean, want_mean))
+            mg, _, _, _ = _event_blocks(lambda: pred_g.predict_audio_device(audio), 50, min_seconds / 2, warm=5)
             extra[f"{prec}_graph_ms_per_clip"] = round(mg, 4)
+        extra["graph_equals_eager_bits"] = same
+        extra["graph_stats"] = dict(pred_g.graph_stats)
     except Exception as exc:   # (a capture problem must not take the leg down)
         extra["graph_error"] = f"{type(exc).__name__}: {exc}"[:200]
     finally:

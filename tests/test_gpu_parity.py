@@ -688,6 +688,38 @@ def test_streaming_long_form(torch_cuda, model, state1234, n, T, hop, fp32_mode)
     assert got.shape == (n,) and np.abs(got - ref).max() < TIGHT
 
 
+@pytest.mark.parametrize("d_model,F,T,hop,n", [(128, 80, 32, 16, 500), (128, 80, 7, 3, 100), (64, 80, 96, 48, 700), (256, 80, 96, 32, 333),
+                                               (128, 40, 96, 48, 700), (128, 13, 64, 32, 257)])
+def test_streaming_shapes_without_an_in_place_kernel(torch_cuda, d_model, F, T, hop, n, fp32_mode):
+    """StreamingPredictor on the shapes savad_forward_strided refuses (windows of T <= 32 frames, feature sizes that need the padded
+    copy, model widths served by the generic kernels): model.forward_windows gathers the windows once and runs the plain forward
+    (round 5's advisor finding: these raised SavadError).  Against the oracle; in-flight replicas and the one-at-a-time path."""
+    from oracle import oracle
+    from voice_activity_detection_amd import StreamingPredictor
+    from voice_activity_detection_amd.seeded import seeded_state_dict
+
+    torch = torch_cuda
+    st = seeded_state_dict(9000 + d_model + F, feature_size=F, num_layers=2, d_model=d_model)
+    m = make_model(torch, st, F, 2, d_model)
+    if d_model != 128 and fp32_mode != "fp32":
+        pytest.skip("the generic-width kernels are exact fp32 only")
+    feat = feats(2000 + n, (n, F))
+    ref, _ = oracle.predict_streaming(st, feat, T, hop)
+    m.precision = fp32_mode
+    try:
+        for in_flight in (2, 1):
+            got = StreamingPredictor(m, "cuda", T, hop, max_batch=5, in_flight=in_flight).predict(feat)
+            assert got.shape == (n,) and np.abs(got - ref).max() < TIGHT
+        fd = torch.from_numpy(feat).cuda()
+        W = (n - T) // hop + 1
+        y = m.forward_windows(fd, T, hop, 1, W - 1)
+        win = torch.stack([fd[hop * w:hop * w + T] for w in range(1, W)])
+        with torch.no_grad():
+            assert torch.equal(y, m(features=win))
+    finally:
+        m.precision = "fp32"
+
+
 # ---- bf16 operands (BASELINE configs[2..3]): judged on AUC and a loose log-prob bound, not on 1e-4 ----------
 BF16_TOL = 1.2e-2  # 2x the measured 5.7e-3 max-abs log-prob error over these shapes and all launch schedules (scripts/ubench/bf16_tol_probe.py,
                    # round 4; fp32 residual arithmetic + statistics); torch-CPU bf16 end-to-end shows 1.5e-2 (BASELINE.md section 2)
@@ -1151,6 +1183,57 @@ def _chirp(n, seed):
          + 0.05 * rng.standard_normal(n)).astype(np.float32)
     y[: n // 3] *= 0.001
     return y
+
+
+def test_predictor_graph_mode_cache_key_and_bits(torch_cuda, state1234):
+    """VADFromScratchPredictor(graph=True): clip-sized audio replays a HIP graph of log-mel -> windows -> forward -> boost captured per
+    (length, knobs).  The replay gives the eager call's bits (numpy and device input, all three precisions); the cache key separates
+    lengths and precisions; the same key replays without a new capture; a weight change (in place, load_state_dict) re-captures and serves
+    the NEW weights; the least recently used graph goes when the cache is full; inputs beyond graph_max_seconds run eagerly; predict()
+    end to end equals the eager predictor's VoiceActivity."""
+    from voice_activity_detection_amd import VADFromScratchPredictor, VADPredictParameters, seeded_state_dict
+
+    torch = torch_cuda
+    m = make_model(torch, {k: v.copy() for k, v in state1234.items()})
+    eager = VADFromScratchPredictor(m, "cuda")
+    pg = VADFromScratchPredictor(m, "cuda", graph=True, graph_max_seconds=30.0, graph_cache=3)
+    a10, a3 = _chirp(160000, 1), _chirp(48000 + 77, 2)
+    try:
+        for prec in ("fp32", "fp32s", "bf16"):
+            m.precision = prec
+            for a in (a10, a3):
+                want, want_mean = eager.predict_audio_device(a)
+                for src in (a, torch.from_numpy(a).cuda()):
+                    got, got_mean = pg.predict_audio_device(src)
+                    assert torch.equal(got, want) and torch.equal(got_mean, want_mean), (prec, len(a))
+        # 6 keys went through a cache of 3: 6 captures, the rest replays; the survivors are the three most recent keys
+        assert pg.graph_stats["captures"] == 6 and pg.graph_stats["replays"] == 12 and len(pg._graphs) == 3
+        m.precision = "bf16"
+        pg.predict_audio_device(a3)
+        assert pg.graph_stats["captures"] == 6          # still cached
+        m.precision = "fp32"
+        pg.predict_audio_device(a10)
+        assert pg.graph_stats["captures"] == 7          # evicted earlier: captured again
+        # weights change behind a cached graph
+        before = pg.predict_audio_device(a10)[0].clone()
+        with torch.no_grad():
+            m.classifier.bias.add_(torch.tensor([0.7, -0.7], device="cuda"))
+        got = pg.predict_audio_device(a10)[0]
+        assert pg.graph_stats["captures"] == 8 and not torch.equal(got, before)
+        assert torch.equal(got, eager.predict_audio_device(a10)[0])
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state_dict(4321).items()})
+        got = pg.predict_audio_device(a10)[0]
+        assert pg.graph_stats["captures"] == 9 and torch.equal(got, eager.predict_audio_device(a10)[0])
+        # too long for the graph mode: eager, same bits
+        along = _chirp(16000 * 31, 5)
+        n_eager = pg.graph_stats["eager"]
+        assert torch.equal(pg.predict_audio_device(along)[0], eager.predict_audio_device(along)[0]) and pg.graph_stats["eager"] == n_eager + 1
+        # the reference's entry point, end to end
+        params = VADPredictParameters(split_max_seconds=4.0, threshold=0.5, min_vally_ms=30, min_hill_ms=30, return_probs=True, probs_sample_rate=100)
+        va_g, va_e = pg.predict(a10, params), eager.predict(a10, params)
+        assert va_g == va_e
+    finally:
+        m.precision = "fp32"
 
 
 def test_logmel_factored_against_one_gemm_and_unaligned_audio(torch_cuda):
@@ -1700,6 +1783,11 @@ def test_pipeline_replicas_follow_weight_changes(torch_cuda, state1234):
     check()
     m.to("cpu")                               # (5) storage moves: the replicas must not keep pushing from freed pointers
     m.to("cuda")
+    check()
+    lin = torch.nn.Linear(128, 2).cuda()      # (6) a replaced submodule: the replicas' cached parameter walks are of the old one
+    m.classifier = lin
+    st["classifier.weight"] = lin.weight.detach().cpu().numpy()
+    st["classifier.bias"] = lin.bias.detach().cpu().numpy()
     check()
 
 

@@ -28,6 +28,15 @@ def main(argv=None) -> int:
     p.add_argument("--return-probs", action="store_true")
     p.add_argument("--probs-sample-rate", type=int, default=None)
     p.add_argument("--device", default="cuda")
+    p.add_argument("--precision", choices=("fp32", "fp32s", "bf16"), default="fp32",
+                   help="not in the reference: fp32 = exact-fp32 matrix cores; fp32s = the same results to fp32 rounding on the bf16 matrix "
+                        "pipe (split operands, ~1.8x faster on long sequences); bf16 = bf16 operands (AUC parity, log-probs to ~1e-2). "
+                        "bf16 results depend on how windows are batched (<= 3e-3 in log-probs) unless --batch-invariant is given.")
+    p.add_argument("--batch-invariant", action="store_true",
+                   help="bf16 only: the same window gives the same bits in every batching (+4 %% on large forwards); off by default.")
+    p.add_argument("--graph", action="store_true",
+                   help="replay clip-sized chunks (<= 120 s) as a captured HIP graph: pays when many chunks have the same length "
+                        "(--split-max-seconds), same results.")
     e = sub.add_parser("evaluate", help="frame metrics over a labelled data list (vad/evaluate.py:20-29)")
     e.add_argument("eval_path", type=Path)
     e.add_argument("checkpoint_path", type=Path)
@@ -50,6 +59,7 @@ def main(argv=None) -> int:
     from .predictor import VADFromScratchPredictor, VADPredictParameters
 
     predictor = VADFromScratchPredictor.from_checkpoint(args.checkpoint_path, args.device)
+    predictor.model.precision, predictor.model.batch_invariant, predictor.graph = args.precision, args.batch_invariant, args.graph
     voice_activity = predictor.predict_from_path(
         args.audio_path,
         VADPredictParameters(args.split_max_seconds, args.threshold, args.min_vally_ms, args.min_hill_ms, args.hang_before_ms,

@@ -198,9 +198,12 @@ class SelfAttentiveVAD(nn.Module):
     def __setattr__(self, name, value):
         # a replaced SUBMODULE (model.classifier = nn.Linear(...)) after the first forward: the cached walk above would keep serving
         # the old module's parameters
+        # (the generation bump carries the change to a PipelinedVAD's replicas: shallow copies that share _modules but hold their own
+        # cached walk; an assignment into a nested container -- model.layers[i] = ... -- bypasses this hook: sync_weights(force=True))
         if isinstance(value, nn.Module) and "_param_dicts" in self.__dict__:
             self.__dict__["_param_dicts"] = None
             self.__dict__["_synced_versions"] = None
+            self.__dict__["_weights_generation"] = self.__dict__.get("_weights_generation", 0) + 1
         super().__setattr__(name, value)
 
     def sync_weights(self, force: bool = False):
@@ -215,6 +218,7 @@ class SelfAttentiveVAD(nn.Module):
         if self._seen_generation != self._weights_generation:   # (a replica of a PipelinedVAD sees the base module's counter)
             self._seen_generation = self._weights_generation
             self._synced_versions = None
+            self._param_dicts = None   # (a replaced submodule on the base module: this replica's cached walk is of the old one)
         if self._handle is None:   # a forced re-push on a module that has not run yet (its replicas may have): nothing to push to yet
             if force:
                 pdev = self.classifier.weight.device
@@ -343,6 +347,22 @@ class SelfAttentiveVAD(nn.Module):
             out = torch.empty((count, T, 2), dtype=torch.float32, device=device)
         elif tuple(out.shape) != (count, T, 2) or out.dtype != torch.float32 or out.device != device or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous float32 [{count}, {T}, 2] tensor on {device}")
+        if T <= 32 or F % 16 or self.d_model != 128:
+            # savad_forward_strided reads windows in place only where a kernel takes the sequence stride (T > 32, no feature padding,
+            # the d_model = 128 kernels); everything else goes through one gathered copy of the windows and the plain forward
+            if F % 4:   # (savad_gather_strided moves 16-byte pieces: odd feature sizes take a strided view's copy)
+                win = feature.as_strided((count, T, F), (hop * F, F, 1), first * hop * F).contiguous()
+            else:
+                win = torch.empty((count, T, F), dtype=torch.float32, device=device)
+                with torch.cuda.device(device):
+                    lib = self._prepare_call(device)
+                    stream = torch.cuda.current_stream(device).cuda_stream
+                    _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feature.data_ptr()), N, F, T, hop, first, count,
+                                                        ctypes.c_void_p(win.data_ptr()), ctypes.c_void_p(stream)))
+            if out.data_ptr() % 16 == 0:
+                return self(features=win, out=out)
+            out.copy_(self(features=win))   # (a slice of a larger result that starts off a 16-byte boundary: odd T x odd window count)
+            return out
         with torch.cuda.device(device):
             lib = self._prepare_call(device)
             ws = self._workspace_for(self._workspace_bytes(lib, count, T), device)

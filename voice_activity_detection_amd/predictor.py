@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+from collections import OrderedDict
 from dataclasses import dataclass
 from datetime import timedelta
 from typing import Optional
@@ -66,7 +67,15 @@ class VADFromScratchPredictor:
     hop_ms, window_ms = 10, 25  # the reference's only transform config (tests/configs/vad/train_config.yaml:21-22)
 
     def __init__(self, model: SelfAttentiveVAD, device: torch.device, context: ContextResolution = ContextResolution(),
-                 chunk_size: int = 16384):
+                 chunk_size: int = 16384, graph: bool = False, graph_max_seconds: float = 120.0, graph_cache: int = 8):
+        """`graph=True` (not in the reference's signature): clip-sized inputs -- up to `graph_max_seconds` of audio -- run as a
+        replayed HIP graph of the whole chain log-mel -> window gather -> forward -> boost, captured on first use per (length, model
+        knobs) and re-captured when the weights change; at most `graph_cache` graphs are kept (least recently used goes).  For a 10 s
+        clip the four launches take less time than the Python and the library calls around them: the replay halves the time per clip,
+        same bits (predict_audio_device)."""
+        self.graph, self.graph_max_seconds, self.graph_cache = bool(graph), float(graph_max_seconds), int(graph_cache)
+        self._graphs: "OrderedDict[tuple, dict]" = OrderedDict()
+        self.graph_stats = {"captures": 0, "replays": 0, "eager": 0}
         self.model = model
         self.device = torch.device(device)
         self.context_window_half_frames = context.context_window_half_frames
@@ -95,10 +104,22 @@ class VADFromScratchPredictor:
                 continue
         import pickle
 
-        trusted = trust or os.environ.get("SAVAD_TRUST_CHECKPOINT") == "1"
+        by_env = not trust and os.environ.get("SAVAD_TRUST_CHECKPOINT") == "1"
+        trusted = trust or by_env
+
+        def full_unpickle():
+            if by_env:   # a process-wide switch is easy to forget: say which file it just applied to
+                import warnings
+                warnings.warn(f"SAVAD_TRUST_CHECKPOINT=1: unpickling {checkpoint_path} in full (code embedded in the file can run); "
+                              "prefer trust_checkpoint=True on the calls that need it", RuntimeWarning, stacklevel=3)
+            try:
+                return torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+            except TypeError:   # torch < 1.13: no weights_only keyword
+                return torch.load(checkpoint_path, map_location="cpu")
+
         if not hasattr(torch.serialization, "safe_globals"):
             if trusted:   # an older torch: the explicit opt-in still loads (what the reference's plain torch.load does)
-                return torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+                return full_unpickle()
             raise RuntimeError("this torch build has no torch.serialization.safe_globals: checkpoints cannot be loaded with weights_only=True "
                                "(pass trust_checkpoint=True / set SAVAD_TRUST_CHECKPOINT=1 if you trust the file)")
         try:
@@ -110,7 +131,7 @@ class VADFromScratchPredictor:
                     f"{checkpoint_path}: not loadable with weights_only=True ({str(exc).splitlines()[0]}). If you trust the "
                     "file, pass trust_checkpoint=True / set SAVAD_TRUST_CHECKPOINT=1 to unpickle it in full "
                     "(this can execute code embedded in the file).") from exc
-        return torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        return full_unpickle()
 
     @classmethod
     def from_checkpoint(cls, checkpoint_path, device, trust_checkpoint: bool = False):
@@ -180,8 +201,10 @@ class VADFromScratchPredictor:
             start_sample = int(ci * adjusted * SAMPLE_RATE)
             end_sample = int((ci + 1) * adjusted * SAMPLE_RATE)
             chunk = audio[start_sample:end_sample]
-            feature = features_fn(chunk) if features_fn is not None else log_mel(chunk, self.device)
-            probs_dev, mean_dev = self.predict_probabilities_device(feature)
+            if features_fn is not None:
+                probs_dev, mean_dev = self.predict_probabilities_device(features_fn(chunk))
+            else:
+                probs_dev, mean_dev = self.predict_audio_device(chunk)   # (a replayed HIP graph for clip-sized chunks when graph=True)
             # float64 mean of the float32 [N, 7] matrix, like numpy's probs.mean(axis=1) on the host (:95)
             boosted = probs_dev.cpu().numpy().mean(axis=1)
             predictions = boosted > parameters.threshold
@@ -228,6 +251,70 @@ class VADFromScratchPredictor:
             raise ValueError("feature must be [N, F]")
         self.model.eval()
         return self.model.predict_windows(feat, self.context_window_half_frames, self.context_window_jump_frames, self.chunk_size)
+
+    @torch.no_grad()
+    def predict_audio_device(self, audio):
+        """audio: 1-D float32 mono @16 kHz (numpy or tensor) -> (probs [N, W], mean [N]) on the device, N = 1 + len // 160: the GPU
+        log-mel front-end (vad/acoustics/transforms/log_mel_spectrogram.py:19-32) followed by predict_probabilities_device
+        (vad/predictor.py:159-262) -- what `predict` runs per chunk.  With `graph=True` a clip-sized input replays a captured HIP
+        graph (same kernels, same bits); the returned tensors then belong to the graph and are overwritten by the next call with
+        the same length and knobs: copy them if they must outlive it."""
+        from .features import SAMPLE_RATE, log_mel
+
+        if self.device.type != "cuda":
+            raise _lib.SavadError("the MI355X predictor needs a HIP device (no CPU fallback)")
+        n = int(audio.shape[0]) if hasattr(audio, "shape") and len(audio.shape) == 1 else -1
+        if not self.graph or n < 1 or n > self.graph_max_seconds * SAMPLE_RATE or self.model.training:
+            self.graph_stats["eager"] += 1
+            return self.predict_probabilities_device(log_mel(audio, self.device))
+        model = self.model
+        dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            model._prepare_call(dev)   # weights pushed, knobs set: the walk over the parameters' versions costs ~8 us
+            key = (n, dev.index, model._pushed_knobs, self.context_window_half_frames, self.context_window_jump_frames, self.chunk_size)
+            entry = self._graphs.get(key)
+            if entry is not None and entry["weights"] is not model._synced_versions:
+                # the weights were pushed again since the capture: the library re-folds / re-packs them inside its NEXT call, which a
+                # replay never makes -- every graph of this predictor is stale
+                self._graphs.clear()
+                entry = None
+            if entry is None:
+                entry = self._capture(key, n, dev)
+            else:
+                self._graphs.move_to_end(key)
+            src = audio if isinstance(audio, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32))
+            entry["audio"].copy_(src, non_blocking=True)
+            entry["graph"].replay()
+            self.graph_stats["replays"] += 1
+        return entry["probs"], entry["mean"]
+
+    def _capture(self, key, n: int, dev: torch.device) -> dict:
+        from .features import log_mel
+
+        static_audio = torch.zeros(n, dtype=torch.float32, device=dev)
+
+        def chain():
+            return self.model.predict_windows(log_mel(static_audio, dev), self.context_window_half_frames,
+                                              self.context_window_jump_frames, self.chunk_size)
+
+        # eager runs first, on a side stream like the capture itself: positional-encoding table, packed weights and the cached
+        # workspace reach their final sizes, so that the captured call launches nothing but its own kernels
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                chain()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            probs, mean = chain()
+        entry = {"graph": g, "audio": static_audio, "probs": probs, "mean": mean, "weights": self.model._synced_versions,
+                 "workspace": self.model._workspace}   # (the graph holds the workspace's address: keep the block alive)
+        self._graphs[key] = entry
+        while len(self._graphs) > max(self.graph_cache, 1):
+            self._graphs.popitem(last=False)
+        self.graph_stats["captures"] += 1
+        return entry
 
     @torch.no_grad()
     def predict_probabilities_device_stepwise(self, feature):
@@ -321,9 +408,14 @@ class StreamingPredictor:
             count = min(self.max_batch, full_end - first)
             self._pipe.submit_windows(feat, T, hop, first - frame0 // hop, count, out=local[first - lo:first - lo + count])
         for w in range(max(lo, full_end), hi):   # at most one: the padded tail
-            win = torch.empty((1, T, F), dtype=torch.float32, device=self.device)
-            _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), n_local, F, T, hop, w - frame0 // hop, 1,
-                                                ctypes.c_void_p(win.data_ptr()), stream))
+            if F % 4:   # (savad_gather_strided moves 16-byte pieces)
+                win = torch.zeros((1, T, F), dtype=torch.float32, device=self.device)
+                f_lo = hop * (w - frame0 // hop)
+                win[0, :max(min(T, n_local - f_lo), 0)] = feat[f_lo:f_lo + T]
+            else:
+                win = torch.empty((1, T, F), dtype=torch.float32, device=self.device)
+                _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), n_local, F, T, hop, w - frame0 // hop, 1,
+                                                    ctypes.c_void_p(win.data_ptr()), stream))
             self._pipe.submit(win, out=local[w - lo:w - lo + 1])
         self._pipe.join()
         return local
