@@ -1114,7 +1114,9 @@ def main():
                 leg("configs2_bf16_b256_t800", shape_leg("bf16", 256, 800, None))
             if (args.precision, B, T) != ("fp32", 1000, 7):
                 leg("pipeline_fp32_b1000_t7", shape_leg("fp32", 1000, 7, None))
-            leg("pipeline_fp32s_b16384_t7", shape_leg("fp32s", 16384, 7, None))   # the predictor's default chunk of windows: the fp32s single launch
+            if (args.precision, B, T) != ("fp32s", 1000, 7):
+                leg("pipeline_fp32s_b1000_t7", shape_leg("fp32s", 1000, 7, None))   # the reference's chunk of windows: the fp32s single launch, latency variant
+            leg("pipeline_fp32s_b16384_t7", shape_leg("fp32s", 16384, 7, None))   # the predictor's default chunk of windows: the fp32s single launch, a wave per block
             leg("pipeline_fp32_b16384_t7", shape_leg("fp32", 16384, 7, None))
             if (args.precision, B, T) != ("bf16", 1000, 7):
                 leg("pipeline_bf16_b1000_t7", shape_leg("bf16", 1000, 7, None))

@@ -141,7 +141,12 @@ int savad_set_attention_splits(savad_handle h, int splits);
  *        packed block for all layers, csrc/savad_packed_bf16.h; same bits as the per-layer launches of 1 - 3) in the variant
  *        the number of blocks suggests; 5 / 6 / 7 / 8 pin a variant (8-wave workgroups / 4 waves + 4 that move the weight stream
  *        through a 4-slot ring / 4 waves with a 2-slot ring / ONE block per workgroup, its four waves splitting every GEMM's
- *        output features: the latency variant, picked up to one block per CU) */
+ *        output features: the latency variant, picked up to one block per CU)
+ *   fp32s (split-bf16 operands), T <= 32: 0 and 4 run the WHOLE forward in one launch (csrc/savad_kernels_f32s.h) -- the latency
+ *        variant (ONE packed block per workgroup, its four waves splitting every GEMM's output features, weights straight from L2
+ *        into registers) up to two blocks per CU, a wave per block with the weight stream shared through the LDS ring beyond;
+ *        8 pins the latency variant, 5 - 7 the wave-per-block one, 1 - 3 keep the per-layer launches.  The two variants agree to
+ *        fp32 rounding (one fp32 sum is taken in another order), each is deterministic and independent of the batch. */
 int savad_set_row_mode(savad_handle h, int mode);
 /* bf16 operands: results that do not depend on the batch a sequence is evaluated in (0 = off, the default; 1 = on).  Every bf16 launch
  * schedule computes a frame with the same arithmetic, bit for bit -- with one exception: the persistent attention kernel that automatic

@@ -281,38 +281,45 @@ def test_single_launch_packed_forward(torch_cuda, model, golden, state1234):
 
 
 def test_fp32s_launch_schedules(torch_cuda, model, golden, state1234):
-    """precision "fp32s" at T <= 32: its single launch (a wave per packed block, all layers: row_mode 4, automatic from 384 blocks up),
-    its per-layer launches (row_mode 1) and the automatic choice (exact-fp32 kernels for small batches) -- all three against the
-    goldens / the oracle at the fp32 tolerance for every tile shape, a batch of several rounds of the CUs, odd feature sizes, depths
-    beyond the single launch's layer table; results must not depend on what else shares a tile or the batch."""
+    """precision "fp32s" at T <= 32: its single launch in both variants -- a wave per packed block with the weight stream shared through
+    LDS (row_mode 7) and the latency variant, one block per workgroup with the output features split over its four waves (row_mode 8,
+    round 6) --, its per-layer launches (row_mode 1) and the automatic choice (row_mode 0 / 4: the latency variant up to two blocks
+    per CU, a wave per block beyond) -- all against the goldens / the oracle at the fp32 tolerance for every tile shape, a batch of
+    several rounds of the CUs, odd feature sizes, depths beyond the single launch's layer table; results must not depend on what else
+    shares a tile or the batch."""
     from oracle import oracle
     from voice_activity_detection_amd import seeded_state_dict
 
     torch = torch_cuda
-    for rm in (0, 1, 4):
+    for rm in (0, 1, 7, 8):
         assert np.abs(run(torch, model, feats(101, (4, 7, 80)), row_mode=rm, precision="fp32s") - golden["g1_out"]).max() < TIGHT
         y = run(torch, model, feats(78, (1000, 7, 80)), row_mode=rm, precision="fp32s")
         assert np.abs(y[:8] - golden["g4_B1000T7_head"]).max() < TIGHT and np.abs(y[-8:] - golden["g4_B1000T7_tail"]).max() < TIGHT
+        assert np.abs(y.astype(np.float64).sum(axis=(1, 2)) - golden["g4_B1000T7_seqsum"]).max() < 2e-5, rm
         for T in (1, 2, 5, 10, 11, 16, 17, 31, 32):
             y = run(torch, model, feats(400 + T, (3, T, 80)), row_mode=rm, precision="fp32s")
             assert np.abs(y - golden[f"g4_T{T}"]).max() < TIGHT, (rm, T)
     for shape in [(5, 7, 80), (37, 3, 80), (1, 1, 80), (33, 1, 80), (9, 32, 80), (7, 13, 80), (1700, 7, 80), (300, 16, 80), (5000, 7, 80)]:
         x = feats(7 + shape[0], shape)
         ref = oracle.forward(state1234, x, threads=8)
-        y = run(torch, model, x, row_mode=4, precision="fp32s")
-        assert np.abs(y - ref).max() < TIGHT, shape
-        assert np.array_equal(y, run(torch, model, x, row_mode=4, precision="fp32s")), shape  # deterministic
+        for rm in (7, 8, 4):
+            y = run(torch, model, x, row_mode=rm, precision="fp32s")
+            assert np.abs(y - ref).max() < TIGHT, (shape, rm)
+            assert np.array_equal(y, run(torch, model, x, row_mode=rm, precision="fp32s")), (shape, rm)  # deterministic
         assert np.abs(run(torch, model, x, row_mode=1, precision="fp32s") - ref).max() < TIGHT, shape
         assert np.abs(run(torch, model, x, row_mode=0, precision="fp32s") - ref).max() < TIGHT, shape
     x = feats(91, (41, 7, 80))
-    whole = run(torch, model, x, row_mode=4, precision="fp32s")
-    assert np.array_equal(run(torch, model, x[4:12], row_mode=4, precision="fp32s"), whole[4:12])  # whole tiles move together
-    assert np.array_equal(run(torch, model, x[8:9], row_mode=4, precision="fp32s")[0], whole[8])   # same tile slot: same bits
-    assert np.abs(run(torch, model, x[9:10], row_mode=4, precision="fp32s")[0] - whole[9]).max() < 2e-6
+    for rm in (7, 8):
+        whole = run(torch, model, x, row_mode=rm, precision="fp32s")
+        assert np.array_equal(run(torch, model, x[4:12], row_mode=rm, precision="fp32s"), whole[4:12])  # whole tiles move together
+        assert np.array_equal(run(torch, model, x[8:9], row_mode=rm, precision="fp32s")[0], whole[8])   # same tile slot: same bits
+        assert np.abs(run(torch, model, x[9:10], row_mode=rm, precision="fp32s")[0] - whole[9]).max() < 2e-6
+    # the two variants differ only in the order of FFN2's fp32 sum (two half-range accumulators in the latency variant)
+    assert np.abs(run(torch, model, x, row_mode=8, precision="fp32s") - run(torch, model, x, row_mode=7, precision="fp32s")).max() < 2e-6
     for F in (257, 13):  # zero-padded K of the input Linear, K > 128
         st = seeded_state_dict(900 + F, feature_size=F)
         xf = feats(901 + F, (5, 7, F))
-        for rm in (1, 4):   # (padded features: row_mode 4 runs the per-layer launches on the padded copy)
+        for rm in (1, 4, 8):   # (padded features: the single-launch modes run the per-layer launches on the padded copy)
             assert np.abs(run(torch, make_model(torch, st, F=F), xf, row_mode=rm, precision="fp32s") - oracle.forward(st, xf)).max() < TIGHT, F
         xl = feats(902 + F, (3, 70, F))
         assert np.abs(run(torch, make_model(torch, st, F=F), xl, precision="fp32s") - oracle.forward(st, xl)).max() < TIGHT, F
@@ -320,13 +327,13 @@ def test_fp32s_launch_schedules(torch_cuda, model, golden, state1234):
     x = feats(56, (6, 7, 80))
     xl = feats(57, (2, 100, 80))
     m5 = make_model(torch, st, L=5)
-    for rm in (0, 1, 4):
+    for rm in (0, 1, 4, 8):
         assert np.abs(run(torch, m5, x, row_mode=rm, precision="fp32s") - oracle.forward(st, x)).max() < TIGHT, rm
     assert np.abs(run(torch, m5, xl, precision="fp32s") - oracle.forward(st, xl)).max() < TIGHT
     # nothing but x, the weights and `out` is touched by the single launch; the per-layer launches survive a poisoned workspace
     model.precision = "fp32s"
     try:
-        for rm, shape in ((4, (13, 7, 80)), (1, (13, 7, 80)), (0, (3, 801, 80)), (0, (2000, 7, 80))):
+        for rm, shape in ((7, (13, 7, 80)), (8, (13, 7, 80)), (1, (13, 7, 80)), (0, (3, 801, 80)), (0, (2000, 7, 80)), (0, (5000, 7, 80))):
             model.row_mode = rm
             xt = torch.from_numpy(feats(5, shape)).cuda()
             with torch.no_grad():
@@ -528,10 +535,11 @@ def test_predictor_level_golden(torch_cuda, model, golden, tag, n, seed, fp32_mo
         # chunking is an implementation detail: one big chunk gives the same answer
         big = VADFromScratchPredictor(model, "cuda", chunk_size=1 << 20)
         assert np.abs(big.predict_probabilities(feat) - probs).max() < 1e-6
-        if fp32_mode == "fp32s":   # ... and so is the kernel: the fp32s single launch forced (automatic below 384 packed blocks: exact fp32)
-            model.row_mode = 4
-            forced = VADFromScratchPredictor(model, "cuda").predict_probabilities(feat)
-            assert np.abs(forced - golden[f"{tag}_probs"]).max() < TIGHT and (forced == 0.5).sum() == (golden[f"{tag}_probs"] == 0.5).sum()
+        if fp32_mode == "fp32s":   # ... and so is the kernel: both variants of the fp32s single launch (automatic: by the window count)
+            for rm in (7, 8):
+                model.row_mode = rm
+                forced = VADFromScratchPredictor(model, "cuda").predict_probabilities(feat)
+                assert np.abs(forced - golden[f"{tag}_probs"]).max() < TIGHT and (forced == 0.5).sum() == (golden[f"{tag}_probs"] == 0.5).sum()
     finally:
         model.precision, model.row_mode = "fp32", 0
 
@@ -554,8 +562,8 @@ def test_one_call_predictor_matches_the_three_entry_points(torch_cuda, model, pr
             p0, m0 = pred.predict_probabilities_device_stepwise(feat)
             torch.cuda.synchronize()
             if precision == "fp32s":
-                # the one call picks its kernel by the CLIP's window count, the stepwise forwards by the chunk's (exact-fp32 kernels below
-                # 384 packed blocks, split-bf16 above): two fp32-parity kernels, equal to fp32 rounding
+                # the one call picks its kernel by the CLIP's window count, the stepwise forwards by the chunk's (the latency variant up to
+                # two packed blocks per CU, a wave per block above): two fp32-parity kernels, equal to fp32 rounding
                 assert p1.shape == p0.shape == (n, 7) and float((p1 - p0).abs().max()) < 2e-6 and torch.equal(p1 == 0.5, p0 == 0.5), (n, chunk)
                 continue
             assert p1.shape == p0.shape == (n, 7) and torch.equal(p1, p0) and torch.equal(m1, m0), (n, chunk)

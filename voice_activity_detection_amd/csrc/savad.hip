@@ -404,17 +404,20 @@ BlockPlan3 plan_blocks3(const savad_model* m, int B, int T) {
     return p;
 }
 
-// T <= 32 in precision 2: the single-launch wave-per-block kernel from `SAVAD_F32S_PACKED_MIN_BLOCKS` packed blocks up (four blocks
-// per workgroup share the weight stream; a block's chain is 7 320 bf16 MFMAs); below that the chain's latency is the forward's time
-// and the exact-fp32 kernels of precision 0 (which split a block's GEMMs over four waves) are faster -- "fp32s" promises the fp32
-// result at the best speed the library has, not a particular instruction.
+// T <= 32 in precision 2: ONE launch for the whole forward -- the latency variant (one packed block per workgroup, its four waves
+// splitting every GEMM's output features; round 6) while the blocks fill the CUs at most SAVAD_F32S_NS_MAX_ROUNDS times, the
+// wave-per-block kernel (four blocks per workgroup share the weight stream through the LDS ring; a block's chain is 7 320 bf16 MFMAs)
+// beyond.  (Until the latency variant existed, short clips ran the exact-fp32 kernels of precision 0: SAVAD_F32S_PACKED_MIN_BLOCKS.)
 #ifndef SAVAD_F32S_PACKED_MIN_BLOCKS
-#define SAVAD_F32S_PACKED_MIN_BLOCKS 384
+#define SAVAD_F32S_PACKED_MIN_BLOCKS 0
 #endif
 bool packed_f32s_applies(const savad_model* m, int B, int T) {
+    // row_mode 0 (automatic) and 4: the single launch in the variant the number of blocks suggests (launch_packed_forward_f32s);
+    // 5 - 7: the wave-per-block variant, 8: the latency variant (one block per workgroup); 1 - 3 keep the per-layer launches
+    // (the cross-check of the tests).  SAVAD_F32S_PACKED_MIN_BLOCKS > 0 (experiment builds): exact-fp32 kernels below that many blocks
     if (T > 32 || m->cfg.num_layers > fs::PACKED_F32S_MAX_LAYERS) return false;
     const long nblk = ((long)B + 32 / T - 1) / (32 / T);
-    return m->row_mode == 4 || (m->row_mode == 0 && nblk >= SAVAD_F32S_PACKED_MIN_BLOCKS);
+    return m->row_mode >= 4 || (m->row_mode == 0 && nblk >= SAVAD_F32S_PACKED_MIN_BLOCKS);
 }
 // precision 2 shapes that run the exact-fp32 kernels: T <= 32 below the single launch's break-even (row_mode 1 - 3 force the fp32s
 // per-layer launches: the tests' cross-check)
@@ -1151,10 +1154,14 @@ int prepare_f32s_launch(savad_model* m) {
     if ((rc = allow_lds(fs::attention_row_kernel_f32s<false, true>, fs::ROW_LDS_BYTES))) return rc;
     if ((rc = allow_lds(fs::attention_row_kernel_f32s<true, true>, fs::ROW_LDS_BYTES))) return rc;
     if ((rc = allow_lds(fs::packed_forward_kernel_f32s, fs::packed_f32s_lds_bytes(fs::PACKED_F32S_MAX_LAYERS)))) return rc;
+    if ((rc = allow_lds(fs::packed_forward_kernel_f32s_ns, fs::nsf_lds_bytes(fs::PACKED_F32S_MAX_LAYERS)))) return rc;
     m->lds_attrs3_set = true;
     return SAVAD_OK;
 }
 
+#ifndef SAVAD_F32S_NS_MAX_ROUNDS
+#define SAVAD_F32S_NS_MAX_ROUNDS 2   // blocks per CU up to which one block per workgroup beats a wave per block (scripts/ubench/f32s_check_t7.py)
+#endif
 void launch_packed_forward_f32s(savad_model* m, hipStream_t st, const float* x, int B, int T, int F, float* out, const WindowOffsets& wo,
                                 int win_base) {
     const int L = m->cfg.num_layers;
@@ -1173,8 +1180,14 @@ void launch_packed_forward_f32s(savad_model* m, hipStream_t st, const float* x, 
     pm.bc = m->d_packed + m->p_bc;
     pm.L = L;
     const float c = (float)(1.4426950408889634 / sqrt((double)D));
-    hipLaunchKernelGGL(fs::packed_forward_kernel_f32s, dim3((nblk + 3) / 4), dim3(256), fs::packed_f32s_lds_bytes(L), st, x, B, T, F, nblk, pm, c,
-                       out, wo, win_base);
+    // the latency variant (one block per workgroup, its four waves splitting the output features) up to SAVAD_F32S_NS_MAX_ROUNDS blocks
+    // per CU; beyond, a wave per block with the weight stream shared through the LDS ring
+    const bool ns = m->row_mode >= 5 ? m->row_mode == 8 : nblk <= SAVAD_F32S_NS_MAX_ROUNDS * m->n_cu;
+    if (ns)
+        hipLaunchKernelGGL(fs::packed_forward_kernel_f32s_ns, dim3(nblk), dim3(256), fs::nsf_lds_bytes(L), st, x, B, T, F, nblk, pm, c, out, wo, win_base);
+    else
+        hipLaunchKernelGGL(fs::packed_forward_kernel_f32s, dim3((nblk + 3) / 4), dim3(256), fs::packed_f32s_lds_bytes(L), st, x, B, T, F, nblk, pm, c,
+                           out, wo, win_base);
 }
 
 // fp32s forward (precision 2): input_qkv -> [attention + row chain] x L, every GEMM as six bf16 MFMA products of three-piece operands

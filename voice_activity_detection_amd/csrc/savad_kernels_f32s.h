@@ -29,6 +29,7 @@
 // Reference being restated: vad/models/self_attention.py:23-28, vad/modeling/transformer.py:24-61,227-238,258-363,366-382.
 #pragma once
 #include "savad_kernels_bf16.h"
+#include <type_traits>
 
 namespace savad {
 #ifdef SAVAD_TIMING
@@ -1097,6 +1098,355 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float
     if (h == 0 && valid) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
     wait_vmem_all();  // the two slots requested behind the last layer are never read, but must have landed before the LDS is released
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// T <= 32, the LATENCY variant (round 6; the fp32s edition of packed_forward_kernel_bf16_ns): ONE packed block per workgroup, its
+// four waves split every GEMM's OUTPUT features -- wave w: features [32w, 32w + 32) of Q, K, V^T, the out-projection and FFN2,
+// hidden units [128w, 128w + 128) of FFN1 -- so a block's chain is 636 MFMAs per wave and layer instead of 2 400 and the 250 blocks
+// of the reference's 1000-window chunk (vad/predictor.py:180) run on 250 CUs instead of 63.  What a wave does not own it gets
+// through LDS: full fp32 rows for the LayerNorms, the Q / K triples for the scores (every wave computes the whole 32 x 32 score
+// tile: 48 MFMAs, redundant but identical), the context triples, the ReLU'd hidden triples -- five barriers per layer.
+// Weights: a wave reads only ITS triples, straight from L2 into AGPRs in chunks of two K-steps (six fragments, 6 KiB), requested
+// by hand FIVE chunks (~60 MFMAs) ahead through an eight-chunk register ring behind counted waits: the chain has no other vector
+// memory traffic, loads retire in order, so "30 younger loads may be in flight" means the chunk has landed.  A layer's stream starts
+// at the top of the layer (under its first LayerNorm) and is drained at its end.
+// Two independent accumulators take turns wherever the chain offers them (Q / K / V^T; two FFN1 blocks; FFN2's K range in two
+// halves that are summed at the end -- the one place where the order of an fp32 sum differs from the wave-per-block kernel).
+// ---------------------------------------------------------------------------------------------
+struct WC6 {
+    u32x4 v[6];
+};
+__device__ __forceinline__ void wc_load(WC6& c, const char* __restrict__ base /* wave-uniform: 6 consecutive fragments */, unsigned voff /* lane * 16 */) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(c.v[i]) : "v"(voff), "s"(base + (i >> 2) * 4096), "n"((i & 3) * 1024));
+}
+template <int PENDING>  // younger requests allowed to stay in flight
+__device__ __forceinline__ void wc_wait(WC6& c) {
+    asm volatile("s_waitcnt vmcnt(%6)" : "+a"(c.v[0]), "+a"(c.v[1]), "+a"(c.v[2]), "+a"(c.v[3]), "+a"(c.v[4]), "+a"(c.v[5]) : "n"(PENDING));
+}
+__device__ __forceinline__ Tri wc_tri(const WC6& c, int j) {
+    return Tri{__builtin_bit_cast(bf16x8, c.v[3 * j]), __builtin_bit_cast(bf16x8, c.v[3 * j + 1]), __builtin_bit_cast(bf16x8, c.v[3 * j + 2])};
+}
+template <int B_, int E_, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B_ < E_) {
+        f(std::integral_constant<int, B_>{});
+        static_for<B_ + 1, E_>(f);
+    }
+}
+// acc += a . b: the six products in mfma6x2's order (hl, lh, mm, hm, mh, hh)
+#define SAVAD_MF6_STEP(acc, a, b, pa, pb) acc = SAVAD_MF((a).pa, (b).pb, acc)
+__device__ __forceinline__ void mf6(f32x16& acc, const Tri& a, const Tri& b) {
+    SAVAD_MF6_STEP(acc, a, b, h, l); SAVAD_MF6_STEP(acc, a, b, l, h); SAVAD_MF6_STEP(acc, a, b, m, m);
+    SAVAD_MF6_STEP(acc, a, b, h, m); SAVAD_MF6_STEP(acc, a, b, m, h); SAVAD_MF6_STEP(acc, a, b, h, h);
+}
+// acc0 += a0 . b0, acc1 += a1 . b1, taking turns
+__device__ __forceinline__ void mf6x2(f32x16& acc0, f32x16& acc1, const Tri& a0, const Tri& b0, const Tri& a1, const Tri& b1) {
+#define SAVAD_MF6_2(pa, pb) SAVAD_MF6_STEP(acc0, a0, b0, pa, pb); SAVAD_MF6_STEP(acc1, a1, b1, pa, pb);
+    SAVAD_MF6_2(h, l) SAVAD_MF6_2(l, h) SAVAD_MF6_2(m, m) SAVAD_MF6_2(h, m) SAVAD_MF6_2(m, h) SAVAD_MF6_2(h, h)
+#undef SAVAD_MF6_2
+}
+
+#ifndef SAVAD_NSF_PENDING   // younger loads behind chunk c of a layer (experiment builds: 0 = every chunk waits out the whole stream)
+#define SAVAD_NSF_PENDING(c) (6 * ((c) + NSF_AHEAD < NSF_CHUNKS ? NSF_AHEAD : NSF_CHUNKS - 1 - (c)))
+#endif
+constexpr int NSF_XB_FLOATS = TILE * XLD;          // one fp32 row-exchange buffer
+constexpr int NSF_TRI_BYTES = 32 * TFRAG_BYTES;    // 32 triples: the hidden activations; Q / K (16) and the context (8) alias them
+inline constexpr int nsf_lds_bytes(int L) { return 2 * NSF_XB_FLOATS * 4 + NSF_TRI_BYTES + (L * LBIAS + 2 * D + 4) * 4; }
+constexpr int NSF_CHUNKS = 48;   // chunks per layer and wave: 12 Q/K/V (interleaved), 4 Wo, 16 W1, 16 W2
+// (up to three chunks are live at once -- Q, K, V of a K-step pair -- and the request that follows the third one's wait must not land in
+// the first one's registers: AHEAD + 3 <= RING)
+constexpr int NSF_AHEAD = 3, NSF_RING = 6;
+static_assert(NSF_AHEAD + 3 <= NSF_RING && NSF_CHUNKS % NSF_RING == 0, "weight chunk ring");
+
+__global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s_ns(const float* __restrict__ x, int B, int T, int F, int nblk,
+                                                                        PackedF32sModel M, float qscale, float* __restrict__ out,
+                                                                        WindowOffsets wo, int win_base) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xb0 = reinterpret_cast<float*>(smem);
+    float* xb1 = xb0 + NSF_XB_FLOATS;
+    char* tbuf = smem + 2 * NSF_XB_FLOATS * 4;
+    float* lbias = reinterpret_cast<float*>(tbuf + NSF_TRI_BYTES);
+    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned voff = (unsigned)lane * 16u;
+    const int blk = blockIdx.x, L = M.L;
+    float* lwc = lbias + L * LBIAS;  // the classifier's folded weights [2][D] + bias [2], staged with the biases
+    SAVAD_STAMP(40);
+
+    // slot j of the block = sequence blk * G + j / T, frame j % T.  j / T for j < 32, T <= 32 through a float reciprocal: (j + 0.5) / T lies
+    // at least 1 / 64 away from an integer, the rounding error of the product is < 1e-5 -- seventeen integer divisions cost the
+    // prologue ~1 500 cycles
+    const float inv_t = 1.0f / (float)T;
+    auto div_t = [&](int j) { return (int)(((float)j + 0.5f) * inv_t); };
+    const int G = 32 / T, sq = div_t(m), seq = blk * G + sq, t_frame = m - sq * T;
+    const bool valid = blk < nblk && m < G * T && seq < B;
+    const size_t row = valid ? (size_t)seq * T + t_frame : 0;
+    bool keyok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int jk = 8 * (r >> 2) + 4 * h + (r & 3), jq = div_t(jk);
+        keyok[r] = (jk < G * T) && (jq == sq) && (blk * G + jq < B);
+    }
+    // ---- this wave's weight stream: chunk c of layer l
+    WC6 ring[NSF_RING];
+    auto chunk_addr = [&](int l, int cc) -> const char* {
+        const PackedF32sLayer Lw = M.layer[l];
+        if (cc < 12) return Lw.wqkv + (size_t)(((cc % 3) * 4 + w) * 8 + 2 * (cc / 3)) * TFRAG_BYTES;
+        if (cc < 16) return Lw.wo + (size_t)(w * 8 + 2 * (cc - 12)) * TFRAG_BYTES;
+        if (cc < 32) {
+            const int i = cc - 16, b = 2 * (i >> 3) + (i & 1), s2 = (i & 7) >> 1;
+            return Lw.w1 + (size_t)((4 * w + b) * 8 + 2 * s2) * TFRAG_BYTES;
+        }
+        const int i = cc - 32;
+        return Lw.w2 + (size_t)(w * 32 + 16 * (i & 1) + 2 * (i >> 1)) * TFRAG_BYTES;
+    };
+#define SAVAD_NSF_REQ(l_, c_) wc_load(ring[(c_) % NSF_RING], chunk_addr(l_, c_), voff)
+    // chunk c_ of the layer: request the chunk NSF_AHEAD further down the layer's stream, then wait for this one.  The stream does NOT
+    // run across the layer loop's back edge: registers with a load in flight at a loop header make hipcc copy them between the
+    // prologue's and the loop's allocations while the load is still out (scripts/check_async_loads.py flags exactly that)
+#define SAVAD_NSF_GET(l_, c_)                                                                            \
+    if constexpr ((c_) + NSF_AHEAD < NSF_CHUNKS) { SAVAD_NSF_REQ(l_, (c_) + NSF_AHEAD); }                \
+    wc_wait<SAVAD_NSF_PENDING((c_))>(ring[(c_) % NSF_RING])
+    // ---- input Linear + positional encoding: this wave's 32 features
+    f32x16 own = zero16();
+    {
+        const size_t src_row = wo.w > 0 ? (size_t)win_base + (valid ? seq : 0) + wo.off[valid ? t_frame : 0] : row;
+        const float* xr = x + src_row * (size_t)F;
+        const int KS = F / 16;
+        add_bias(own, M.bin + 32 * w, h);
+        add_block(own, M.pe + (size_t)(valid ? t_frame : 0) * D + 32 * w, h);
+        constexpr int NBT = (PACKED_F32S_MAX_LAYERS * LBIAS / 4 + 255) / 256 + 1;
+        const int nb4 = (L * LBIAS + 2 * D + 4) / 4;   // biases, then wc [2][D], then bc (+ 2 floats of padding)
+        f32x4 bt[NBT];
+#pragma unroll
+        for (int j = 0; j < NBT; ++j) {
+            const int i4 = (int)threadIdx.x + 256 * j;
+            if (i4 < nb4) {
+                const int i = 4 * i4;
+                bt[j] = i < L * LBIAS ? ld4(M.bias + i) : (i < L * LBIAS + 2 * D ? ld4(M.wc + (i - L * LBIAS)) : f32x4{M.bc[0], M.bc[1], 0.0f, 0.0f});
+            }
+        }
+        // every global load of the input GEMM is requested before the first use of any (F <= 128: the loop below takes what is beyond)
+        constexpr int KSMAX = 8;
+        f32x4 xa[KSMAX], xc[KSMAX];
+        Tri wf[KSMAX];
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            const int kc = ks < KS ? ks : KS - 1;
+            const float* px = xr + 32 * (kc >> 1) + 16 * (kc & 1) + 4 * h;
+            xa[ks] = ld4(px);
+            xc[ks] = ld4(px + 8);
+            wf[ks] = ldtri(M.win + (size_t)(w * KS + kc) * TFRAG_BYTES + lane * 16);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks)
+            if (ks < KS) {
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    t[e] = valid ? xa[ks][e] : 0.0f;
+                    t[4 + e] = valid ? xc[ks][e] : 0.0f;
+                }
+                mf6(own, wf[ks], split8(t));
+            }
+        for (int ks = KSMAX; ks < KS; ++ks) {
+            const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
+            mf6(own, ldtri(M.win + (size_t)(w * KS + ks) * TFRAG_BYTES + lane * 16), load_x_tri(xr + f0, valid));
+        }
+#pragma unroll
+        for (int j = 0; j < NBT; ++j) {
+            const int i4 = (int)threadIdx.x + 256 * j;
+            if (i4 < nb4) st4(lbias + 4 * i4, bt[j]);   // published by the first barrier
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's loads are out of the way: from here on only the weight stream counts
+    SAVAD_STAMP(41);
+    // full rows through LDS -> layernorm_regs on the wave-per-block kernel's register image -> the 8 K-step triples
+    f32x4 xg[16];
+    Tri xp[8];
+    auto rows_ln = [&](float* xb, const f32x16& mine, bool split) {
+        store_block(xb + m * XLD + 32 * w, mine, h);
+        __syncthreads();
+        f32x16 full[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 t = ld4(xb + m * XLD + 32 * nb + 8 * g + 4 * h);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) full[nb][4 * g + s] = t[s];
+            }
+        layernorm_regs(full, xg);
+        if (split) split_row(xg, xp);
+    };
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {
+        static_for<0, NSF_AHEAD>([&](auto c) { SAVAD_NSF_REQ(l, decltype(c)::value); });   // (their round trip to L2 runs under the LayerNorm)
+        rows_ln(xb0, own, true);   // (its barrier also retires the previous layer's hidden triples' readers)
+        SAVAD_STAMP(42);
+        const float* lb = lbias + l * LBIAS;
+        const float *lb1 = lb, *lb2 = lb + DFF, *lbn = lb + DFF + D, *lbo = lb + DFF + 4 * D;
+        // ---- Q (pre-scaled), K, V^T of this wave's 32 features, the three accumulators taking turns
+        Tri vt0, vt1;
+        {
+            f32x16 aq = bias_block(lbn + 32 * w, h), ak = bias_block(lbn + D + 32 * w, h), av;
+            const float bv = lbn[2 * D + 32 * w + m];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) av[r] = bv;
+            static_for<0, 4>([&](auto sc_) {
+                constexpr int s2 = decltype(sc_)::value;
+                SAVAD_NSF_GET(l, 3 * s2);
+                SAVAD_NSF_GET(l, 3 * s2 + 1);
+                SAVAD_NSF_GET(l, 3 * s2 + 2);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const Tri wq = wc_tri(ring[(3 * s2) % NSF_RING], j), wk = wc_tri(ring[(3 * s2 + 1) % NSF_RING], j),
+                              wv = wc_tri(ring[(3 * s2 + 2) % NSF_RING], j);
+                    const Tri& xo = xp[2 * s2 + j];
+#define SAVAD_QKV3(pa, pb)                       \
+    aq = SAVAD_MF(wq.pa, xo.pb, aq);             \
+    ak = SAVAD_MF(wk.pa, xo.pb, ak);             \
+    av = SAVAD_MF(xo.pb, wv.pa, av);
+                    SAVAD_QKV3(h, l) SAVAD_QKV3(l, h) SAVAD_QKV3(m, m) SAVAD_QKV3(h, m) SAVAD_QKV3(m, h) SAVAD_QKV3(h, h)
+#undef SAVAD_QKV3
+                }
+            });
+            aq *= qscale;
+            sttri(tbuf + (2 * w + 0) * TFRAG_BYTES + lane * 16, split_half(aq, 0));
+            sttri(tbuf + (2 * w + 1) * TFRAG_BYTES + lane * 16, split_half(aq, 1));
+            sttri(tbuf + (8 + 2 * w + 0) * TFRAG_BYTES + lane * 16, split_half(ak, 0));
+            sttri(tbuf + (8 + 2 * w + 1) * TFRAG_BYTES + lane * 16, split_half(ak, 1));
+            vt0 = split_half(av, 0);
+            vt1 = split_half(av, 1);
+        }
+        SAVAD_STAMP(43);
+        __syncthreads();  // Q and K triples of all four waves
+        SAVAD_STAMP(44);
+        // ---- the whole score tile in every wave (same operands, same order: the same bits), softmax, this wave's O^T block
+        f32x16 sa = zero16(), sb = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const Tri kk = ldtri(tbuf + (8 + ks) * TFRAG_BYTES + lane * 16), qq = ldtri(tbuf + ks * TFRAG_BYTES + lane * 16);
+            sa = SAVAD_MF(kk.h, qq.l, sa);
+            sb = SAVAD_MF(kk.l, qq.h, sb);
+            sa = SAVAD_MF(kk.m, qq.m, sa);
+            sb = SAVAD_MF(kk.h, qq.m, sb);
+            sa = SAVAD_MF(kk.m, qq.h, sa);
+            sb = SAVAD_MF(kk.h, qq.h, sb);
+        }
+        f32x16 sc = sa + sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = keyok[r] ? sc[r] : NEG_BIG;
+        float l_run;
+        {
+            float mx = sc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+            mx = half_max(mx);
+            float rs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[r] = __builtin_amdgcn_exp2f(sc[r] - mx);
+                rs += sc[r];
+            }
+            l_run = rs;
+        }
+        {
+            const Tri p0 = split_half(sc, 0), p1 = split_half(sc, 1);
+            const float inv = 1.0f / half_sum(l_run);
+            f32x16 O = zero16();
+            mf6(O, vt0, p0);
+            mf6(O, vt1, p1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[r] = valid ? O[r] * inv : 0.0f;
+            __syncthreads();  // every wave has read the Q / K triples: the context triples may take their place
+            sttri(tbuf + (2 * w + 0) * TFRAG_BYTES + lane * 16, split_half(O, 0));
+            sttri(tbuf + (2 * w + 1) * TFRAG_BYTES + lane * 16, split_half(O, 1));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xp[ks] = ldtri(tbuf + ks * TFRAG_BYTES + lane * 16);
+        SAVAD_STAMP(45);
+        // ---- h1 = h + bo + ctx Wo^T (this wave's block), LN2
+        f32x16 h1 = own;
+        h1 += bias_block(lbo + 32 * w, h);
+        static_for<0, 4>([&](auto sc_) {
+            constexpr int s2 = decltype(sc_)::value;
+            SAVAD_NSF_GET(l, 12 + s2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mf6(h1, wc_tri(ring[(12 + s2) % NSF_RING], j), xp[2 * s2 + j]);
+        });
+        SAVAD_STAMP(46);
+        rows_ln(xb1, h1, true);  // (its barrier also retires the context triples' readers)
+        SAVAD_STAMP(47);
+        // ---- FFN1: hidden units [128 w, 128 w + 128) as two pairs of blocks, ReLU'd triples 8 w .. 8 w + 7 of the exchange
+        static_for<0, 2>([&](auto pc_) {
+            constexpr int pr = decltype(pc_)::value;
+            f32x16 a0 = bias_block(lb1 + 128 * w + 32 * (2 * pr), h), a1 = bias_block(lb1 + 128 * w + 32 * (2 * pr + 1), h);
+            static_for<0, 4>([&](auto sc_) {
+                constexpr int s2 = decltype(sc_)::value, c0 = 16 + 8 * pr + 2 * s2;
+                SAVAD_NSF_GET(l, c0);
+                SAVAD_NSF_GET(l, c0 + 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    mf6x2(a0, a1, wc_tri(ring[c0 % NSF_RING], j), xp[2 * s2 + j], wc_tri(ring[(c0 + 1) % NSF_RING], j), xp[2 * s2 + j]);
+            });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                a0[r] = fmaxf(a0[r], 0.0f);
+                a1[r] = fmaxf(a1[r], 0.0f);
+            }
+            sttri(tbuf + (8 * w + 4 * pr + 0) * TFRAG_BYTES + lane * 16, split_half(a0, 0));
+            sttri(tbuf + (8 * w + 4 * pr + 1) * TFRAG_BYTES + lane * 16, split_half(a0, 1));
+            sttri(tbuf + (8 * w + 4 * pr + 2) * TFRAG_BYTES + lane * 16, split_half(a1, 0));
+            sttri(tbuf + (8 * w + 4 * pr + 3) * TFRAG_BYTES + lane * 16, split_half(a1, 1));
+        });
+        SAVAD_STAMP(48);
+        __syncthreads();
+        SAVAD_STAMP(49);
+        // ---- FFN2 on top of the residual stream: K-steps 0..15 into o, 16..31 into o2, taking turns
+        f32x16 o = h1, o2 = zero16();
+        o += bias_block(lb2 + 32 * w, h);
+        static_for<0, 8>([&](auto sc_) {
+            constexpr int s2 = decltype(sc_)::value, c0 = 32 + 2 * s2;
+            SAVAD_NSF_GET(l, c0);
+            SAVAD_NSF_GET(l, c0 + 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                mf6x2(o, o2, wc_tri(ring[c0 % NSF_RING], j), ldtri(tbuf + (2 * s2 + j) * TFRAG_BYTES + lane * 16),
+                      wc_tri(ring[(c0 + 1) % NSF_RING], j), ldtri(tbuf + (16 + 2 * s2 + j) * TFRAG_BYTES + lane * 16));
+        });
+        own = o + o2;
+        SAVAD_STAMP(50);
+    }
+    SAVAD_STAMP(51);
+#undef SAVAD_NSF_REQ
+#undef SAVAD_NSF_GET
+    // ---- final LayerNorm (folded into the classifier) + Linear(D, 2) + log-softmax (vad/models/self_attention.py:26-28)
+    rows_ln(xb0, own, false);
+    if (w == 0) {
+        float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+        for (int Gq = 0; Gq < 16; ++Gq) {
+            const f32x4 c0 = ld4(lwc + 8 * Gq + 4 * h), c1 = ld4(lwc + D + 8 * Gq + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z0 = __builtin_fmaf(xg[Gq][e], c0[e], z0);
+                z1 = __builtin_fmaf(xg[Gq][e], c1[e], z1);
+            }
+        }
+        z0 = half_sum(z0) + lwc[2 * D];
+        z1 = half_sum(z1) + lwc[2 * D + 1];
+        const float mx = fmaxf(z0, z1);
+        const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+        if (h == 0 && valid) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{z0 - lse, z1 - lse};
+    }
+    SAVAD_STAMP(52);
+}
+#undef SAVAD_MF6_STEP
 
 }  // namespace fs
 }  // namespace savad
