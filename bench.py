@@ -618,6 +618,33 @@ def clip_pipeline(state, dev, seconds, min_seconds):
             "finite": bool(torch.isfinite(probs).all().item()), "blocks": len(per_call)}
 
 
+def _wall_blocks(fn, min_seconds, warm=2, max_calls=40):
+    """median / min wall ms per call of fn() -- host clock around the call and a device synchronize on both sides: for paths that start
+    in HOST memory (uploads are part of the call)"""
+    for _ in range(warm):
+        out = fn()
+    torch.cuda.synchronize()
+    per_call = []
+    while len(per_call) < 5 or (sum(per_call) * 1e-3 < min_seconds and len(per_call) < max_calls):
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        per_call.append((time.perf_counter() - t0) * 1e3)
+    return statistics.median(per_call), min(per_call), len(per_call), out
+
+
+def _synthetic_pcm_hour(seconds, dev):
+    """(pinned int16 PCM on the host, the same samples as float32 on the device, pure upload times): Gaussian noise at -20 dBFS"""
+    pcm = np.clip(np.round(np.random.default_rng(0).standard_normal(16000 * seconds, dtype=np.float32) * (0.1 * 32768.0)), -32768, 32767).astype(np.int16)
+    pinned = torch.from_numpy(pcm).pin_memory()
+    audio = (pinned.to(dev, non_blocking=True).float() / 32768.0).contiguous()
+    pinned_f32 = (torch.from_numpy(pcm.astype(np.float32)) / 32768.0).pin_memory()
+    h2d16, _, _, _ = _wall_blocks(lambda: pinned.to(dev, non_blocking=True), 0.1, warm=2)
+    h2d32, _, _, _ = _wall_blocks(lambda: pinned_f32.to(dev, non_blocking=True), 0.1, warm=2)
+    return pinned, audio, {"h2d_pcm16_ms": round(h2d16, 4), "h2d_pcm16_GBps": round(pcm.nbytes / (h2d16 * 1e-3) / 1e9, 1),
+                           "h2d_f32_ms": round(h2d32, 4), "h2d_f32_GBps": round(4 * pcm.size / (h2d32 * 1e-3) / 1e9, 1)}
+
+
 def _event_blocks(fn, calls, min_seconds, warm=3):
     """median / min ms per call of fn() over blocks of `calls` calls (HIP events on the current stream, >= 5 blocks and
     >= min_seconds of timed work)"""
@@ -733,14 +760,15 @@ def reference_mode_hour(state, dev, min_seconds):
     model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(dev).eval()
-    rng = np.random.default_rng(0)
-    audio = torch.from_numpy((rng.standard_normal(16000 * seconds, dtype=np.float32) * 0.1)).to(dev)
+    pinned_pcm, audio, h2d = _synthetic_pcm_hour(seconds, dev)
     feat = log_mel(audio, dev)
     N = int(feat.shape[0])
     windows = N - 38
     res = {"workload": f"reference mode, {seconds} s of audio on ONE GPU: feature matrix [{N},80] -> {windows} windows of 7 frames "
-                       "(vad/predictor.py:169-224) -> forward -> boosted probabilities [N,7] (:238-258)", "audio_seconds": seconds,
-           "frames": N, "windows": windows, "flops": windows * 7 * flops_per_frame(7)}
+                       "(vad/predictor.py:169-224) -> forward -> boosted probabilities [N,7] (:238-258); from_host_ms: the same from pinned "
+                       "16-bit PCM in host memory (VADFromScratchPredictor.predict_audio_host: chunked upload on a copy stream under the "
+                       "previous chunk's log-mel + forwards)", "audio_seconds": seconds,
+           "frames": N, "windows": windows, "flops": windows * 7 * flops_per_frame(7), **h2d}
     ref32 = None
     for prec in ("fp32", "fp32s", "bf16"):
         model.precision = prec
@@ -755,6 +783,13 @@ def reference_mode_hour(state, dev, min_seconds):
                      "audio_frames_per_s": round(N / (med * 1e-3), 1),
                      "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
                      "finite": bool(torch.isfinite(probs).all().item())}
+        if prec != "fp32":   # end to end from host memory (the exact-fp32 hour is 30 ms of kernels: nothing to learn from its upload)
+            dev_ms, _, _, dev_out = _event_blocks(lambda: pred.predict_audio_device(audio), 4, min_seconds / 2, warm=1)
+            host_ms, host_min, _, host_out = _wall_blocks(lambda: pred.predict_audio_host(pinned_pcm), min_seconds / 2, warm=1)
+            res[prec].update({"from_audio_ms": round(dev_ms, 4), "from_host_ms": round(host_ms, 4), "from_host_ms_min": round(host_min, 4),
+                              "from_host_equals_device_bits": bool(torch.equal(host_out[0], dev_out[0]) and torch.equal(host_out[1], dev_out[1])),
+                              "from_host_over_max_of_h2d_and_device": round(host_ms / max(h2d["h2d_pcm16_ms"], dev_ms), 3),
+                              "rtf_from_host": round(host_ms * 1e-3 / seconds, 10)})
         if prec == "fp32":
             ref32 = probs.clone()
         else:   # against the exact-fp32 run of the same call (fp32s: the fp32 bar; bf16: reported)
@@ -821,12 +856,13 @@ def stream_one_hour(state, dev, min_seconds):
     model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(dev).eval()
-    rng = np.random.default_rng(0)
-    audio = torch.from_numpy((rng.standard_normal(16000 * seconds, dtype=np.float32) * 0.1)).to(dev)
+    pinned_pcm, audio, h2d = _synthetic_pcm_hour(seconds, dev)
     mel_med, mel_min, _, feat = _event_blocks(lambda: log_mel(audio, dev), 4, min_seconds / 2, warm=2)
     N = int(feat.shape[0])
     res = {"workload": f"BASELINE configs[4] on ONE GPU: {seconds} s of 16 kHz audio -> log-mel [{N},80] -> 900 windows T=800 hop=400 -> "
-                       "forward -> overlap merge -> probabilities", "audio_seconds": seconds, "frames": N,
+                       "forward -> overlap merge -> probabilities; from_host_ms: end to end from pinned 16-bit PCM in host memory "
+                       "(StreamingPredictor.predict_audio_host: spans of 256 windows, span c + 1 uploaded on a copy stream under span c's "
+                       "log-mel + forwards; wall clock)", "audio_seconds": seconds, "frames": N, **h2d,
            "logmel_ms": round(mel_med, 4), "logmel_ms_min": round(mel_min, 4), "logmel_roofline": logmel_roofline(audio.numel(), N, mel_med)}
     for prec in ("fp32", "fp32s", "bf16"):
         model.precision = prec
@@ -840,6 +876,11 @@ def stream_one_hour(state, dev, min_seconds):
                      "rtf_without_logmel": round(med * 1e-3 / seconds, 10), "rtf_with_logmel": round((med + mel_med) * 1e-3 / seconds, 10),
                      "frames_per_s": round(N / (med * 1e-3), 1), "finite": bool(torch.isfinite(probs).all().item()),
                      "in_unit_interval": bool(((probs >= 0) & (probs <= 1)).all().item())}
+        host_ms, host_min, _, probs3 = _wall_blocks(lambda: sp.predict_audio_host(pinned_pcm), min_seconds / 2, warm=1)
+        res[prec].update({"from_host_ms": round(host_ms, 4), "from_host_ms_min": round(host_min, 4),
+                          "from_host_equals_device_bits": bool(torch.equal(probs3, probs2)),
+                          "from_host_over_max_of_h2d_and_device": round(host_ms / max(h2d["h2d_pcm16_ms"], e2e), 3),
+                          "rtf_from_host": round(host_ms * 1e-3 / seconds, 10)})
     model.precision = "fp32"
     return res
 
@@ -910,8 +951,9 @@ def bench_summary(line, flags):
                     d = v[prec]
                     ms = d.get("ms_per_hour_of_audio", d.get("ms_per_hour_of_audio_from_host_audio"))
                     sub[prec] = pair(ms, d.get("roofline", {}).get("frac"))
-                    if "from_audio_ms" in d:
-                        sub[prec]["from_audio_ms"] = d["from_audio_ms"]
+                    for kk in ("from_audio_ms", "from_host_ms"):
+                        if kk in d:
+                            sub[prec][kk] = d[kk]
             if "logmel_ms" in v:
                 sub["logmel"] = pair(v["logmel_ms"], v.get("logmel_roofline", {}).get("hbm_frac"))
             if sub:

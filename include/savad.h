@@ -229,6 +229,11 @@ int savad_logmel(const float* audio, int n_samples, float* workspace, float* fea
  * 4, so that a slice cut there keeps the 16-byte alignment of the direct reads (any other slice is copied first).
  * workspace: savad_logmel_span_workspace_bytes(frame_count) bytes, 16-byte aligned. */
 int savad_logmel_span_samples(long n_samples, int frame_first, int frame_count, long* first, long* count);
+/* 16-bit PCM (device) -> float32 samples in [-1, 1): sample / 32768, exactly what the reference's AudioData.load obtains from
+ * soundfile for a PCM16 source (vad/data_models/audio_data.py:21-24,32).  For uploads from the host: PCM16 is half the bytes
+ * of the float signal the log-mel entry points take (StreamingPredictor.predict_audio_host).  pcm: 2-byte aligned (8-byte
+ * aligned slices move four samples per load); audio: 16-byte aligned. */
+int savad_pcm16_to_f32(const short* pcm, long n_samples, float* audio, void* stream);
 size_t savad_logmel_span_workspace_bytes(int frame_count);
 int savad_logmel_span(const float* audio, long audio_first, long audio_count, long n_samples, int frame_first,
                       int frame_count, float* workspace, float* features, void* stream);

@@ -1244,6 +1244,53 @@ def test_predictor_graph_mode_cache_key_and_bits(torch_cuda, state1234):
         m.precision = "fp32"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32s", "bf16"])
+def test_end_to_end_from_host_audio(torch_cuda, model, precision):
+    """Round 6: the pipelines that start in HOST memory.  16-bit PCM is uploaded as it is and converted on the device (sample / 32768:
+    what soundfile hands the reference, vad/data_models/audio_data.py:21-24) -- log_mel(int16) gives log_mel(float)'s bits.
+    StreamingPredictor.predict_audio_host (configs[4]: spans of max_batch windows, span c + 1 uploaded on a copy stream under span c's
+    log-mel and forwards) gives predict_audio_device's bits from pinned and pageable, int16 and float32 sources, recordings that end on
+    a window boundary or need the zero-padded last window; VADFromScratchPredictor.predict_audio_host (the reference's mode, chunks of
+    output frames with a halo of 2 x half feature frames) gives predict_audio_device's probabilities [N, 7] -- bit for bit where both
+    run the same kernel variant."""
+    from voice_activity_detection_amd import StreamingPredictor, VADFromScratchPredictor
+    from voice_activity_detection_amd.features import log_mel
+
+    torch = torch_cuda
+    model.precision = precision
+    try:
+        for n in (160 * (800 + 400 * 7), 160 * (800 + 400 * 5) + 160 * 173 + 55, 160 * 500 + 7):
+            pcm = np.clip(np.round(_chirp(n, n % 89) * 32768.0), -32768, 32767).astype(np.int16)
+            as_float = pcm.astype(np.float32) / 32768.0
+            fd = torch.from_numpy(as_float).cuda()
+            assert torch.equal(log_mel(pcm), log_mel(fd)) and torch.equal(log_mel(torch.from_numpy(pcm).cuda()), log_mel(fd))
+            sp = StreamingPredictor(model, "cuda", 800, 400, max_batch=3, in_flight=2)
+            want = sp.predict_audio_device(fd)
+            pinned = torch.from_numpy(pcm).pin_memory()
+            for src in (pcm, pinned, as_float, torch.from_numpy(as_float).pin_memory()):
+                got = sp.predict_audio_host(src)
+                assert got.shape == want.shape and torch.equal(got, want), (n, type(src), getattr(src, "dtype", None))
+            if precision != "bf16":   # (bf16: another batching may run another attention kernel; fp32 / fp32s: a window's result does not depend on its batch)
+                assert torch.equal(sp.predict_audio_host(pinned, windows_per_chunk=2), want)
+        # the reference's mode
+        n = 16000 * 75 + 321
+        pcm = np.clip(np.round(_chirp(n, 11) * 32768.0), -32768, 32767).astype(np.int16)
+        fd = torch.from_numpy(pcm.astype(np.float32) / 32768.0).cuda()
+        pred = VADFromScratchPredictor(model, "cuda")
+        want, want_mean = pred.predict_audio_device(fd)
+        for per in (4096, 2500, 1 << 20):
+            got, got_mean = pred.predict_audio_host(torch.from_numpy(pcm).pin_memory(), frames_per_chunk=per)
+            assert got.shape == want.shape and torch.equal(got == 0.5, want == 0.5)
+            if precision == "fp32":    # (the windowed kernel up to 4096 windows, gathered windows through the per-layer launches beyond)
+                assert float((got - want).abs().max()) < 2e-6 and float((got_mean - want_mean).abs().max()) < 2e-6, per
+            else:                      # every chunk here is past two blocks per CU: the same kernel variant as the whole recording
+                assert torch.equal(got, want) and torch.equal(got_mean, want_mean), per
+        small, _ = pred.predict_audio_host(pcm, frames_per_chunk=500)   # chunks of ~144 packed blocks: the latency variants
+        assert float((small - want).abs().max()) < (2e-6 if precision != "bf16" else 1e-2) and torch.equal(small == 0.5, want == 0.5)
+    finally:
+        model.precision = "fp32"
+
+
 def test_logmel_factored_against_one_gemm_and_unaligned_audio(torch_cuda):
     """Round 5's factored DFT (algorithm 0, the default) against the DFT-as-one-GEMM kernel of rounds 1-4 (algorithm 1) on the
     same device, and an audio pointer that is not 16-byte aligned (the direct reads need alignment: such a call takes the

@@ -47,6 +47,7 @@ SYMBOLS = {
     "savad_predict_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "savad_predict_probabilities": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "savad_stream_window_count": (c_int, [c_int, c_int, c_int]),
+    "savad_pcm16_to_f32": (c_int, [c_void_p, ctypes.c_long, c_void_p, c_void_p]),
     "savad_gather_strided": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "savad_overlap_merge": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "savad_logmel_frames": (c_int, [c_int]),

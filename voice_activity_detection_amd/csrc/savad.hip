@@ -1937,6 +1937,28 @@ SAVAD_EXPORT int savad_logmel_tables_host(float* t1, float* t3, float* tm) {
     memcpy(tm, c.data(), c.size() * sizeof(float));
     return SAVAD_OK;
 }
+// 16-bit PCM -> float32 in [-1, 1): sample / 32768 (exact), what soundfile hands the reference for a PCM16 file
+// (vad/data_models/audio_data.py:21-24,32).  The source format of an upload from the host: half the bytes of the float signal.
+__global__ void pcm16_to_f32_kernel(const short* __restrict__ pcm, long n, float* __restrict__ out) {
+    const long n4 = ((uintptr_t)pcm & 7) == 0 ? n / 4 : 0;   // 8-byte pieces when the slice starts on one
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const short4 v = reinterpret_cast<const short4*>(pcm)[i];
+        st4(out + 4 * i, f32x4{v.x * (1.0f / 32768.0f), v.y * (1.0f / 32768.0f), v.z * (1.0f / 32768.0f), v.w * (1.0f / 32768.0f)});
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = pcm[i] * (1.0f / 32768.0f);
+}
+SAVAD_EXPORT int savad_pcm16_to_f32(const short* pcm, long n_samples, float* audio, void* stream) {
+    if (n_samples == 0) return SAVAD_OK;
+    if (!pcm || !audio || n_samples < 0) return fail(SAVAD_E_INVALID, "bad argument");
+    if (((uintptr_t)pcm & 1) || ((uintptr_t)audio & 15)) return fail(SAVAD_E_INVALID, "pcm must be 2-byte, audio 16-byte aligned");
+    const long work = (n_samples + 3) / 4;
+    const int grid = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pcm16_to_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pcm, n_samples, audio);
+    HIP_TRY(hipGetLastError());
+    return SAVAD_OK;
+}
+
 SAVAD_EXPORT int savad_logmel_span_samples(long n_samples, int frame_first, int frame_count, long* first, long* count) {
     if (!first || !count || n_samples < 1 || frame_first < 0 || frame_count < 1 || frame_first + (long)frame_count > 1 + n_samples / mel::HOP)
         return fail(SAVAD_E_INVALID, "bad frame span [%d, +%d) of %ld samples", frame_first, frame_count, n_samples);

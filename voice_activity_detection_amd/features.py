@@ -114,12 +114,27 @@ def load_wav_mono16k(path) -> np.ndarray:
 _HOP, _N_FFT = 160, 512  # savad_logmel.h: HOP, N_FFT (frames = 1 + n // hop; workspace = padded signal + slack)
 
 
+def pcm16_to_f32(pcm: torch.Tensor) -> torch.Tensor:
+    """int16 PCM samples on a HIP device -> float32 in [-1, 1) (sample / 32768, savad_pcm16_to_f32): the conversion soundfile does for
+    the reference (vad/data_models/audio_data.py:21-24,32), on the device -- so that an upload moves 2 bytes per sample"""
+    if not (isinstance(pcm, torch.Tensor) and pcm.dtype == torch.int16 and pcm.dim() == 1 and pcm.device.type == "cuda" and pcm.is_contiguous()):
+        raise ValueError("pcm must be a contiguous 1-D int16 tensor on a HIP device")
+    with torch.cuda.device(pcm.device):
+        out = torch.empty(pcm.numel(), dtype=torch.float32, device=pcm.device)
+        _lib.check(_lib.load().savad_pcm16_to_f32(ctypes.c_void_p(pcm.data_ptr()), pcm.numel(), ctypes.c_void_p(out.data_ptr()),
+                                                 ctypes.c_void_p(torch.cuda.current_stream(pcm.device).cuda_stream)))
+    return out
+
+
 def log_mel(audio, device="cuda") -> torch.Tensor:
-    """audio: 1-D float32 samples @16 kHz (numpy or tensor) -> device tensor [N, 80] float32, N = 1 + len // 160.
+    """audio: 1-D float32 samples @16 kHz (numpy or tensor; int16 PCM is uploaded as it is and converted on the device) -> device
+    tensor [N, 80] float32, N = 1 + len // 160.
     (Host side kept thin on purpose: for a 10 s clip the two kernels take ~25 us, the Python around them used to
     take longer.)"""
     lib = _lib.load()
     dev = device if isinstance(device, torch.device) else torch.device(device)
+    if getattr(audio, "dtype", None) in (torch.int16, np.dtype("int16")):
+        audio = pcm16_to_f32(torch.as_tensor(audio).to(dev).contiguous())
     y = audio if (isinstance(audio, torch.Tensor) and audio.dtype == torch.float32 and audio.device == dev and audio.is_contiguous()) \
         else torch.as_tensor(audio, dtype=torch.float32).to(dev).contiguous()
     if y.dim() != 1 or y.numel() < 1:

@@ -288,6 +288,72 @@ class VADFromScratchPredictor:
             self.graph_stats["replays"] += 1
         return entry["probs"], entry["mean"]
 
+    @torch.no_grad()
+    def predict_audio_host(self, audio, frames_per_chunk: int = 65536):
+        """The reference's mode END TO END from host memory: `audio` = the whole recording on the host, mono 16 kHz, 16-bit PCM
+        (uploaded as it is, converted on the device) or float32, numpy array or CPU tensor (pinned: asynchronous uploads) ->
+        (probs [N, W], mean [N]) on the device.  Output frames are produced in chunks of `frames_per_chunk`; chunk c needs the feature
+        frames within 2 x half of its own (every window that reaches one of its frames, vad/predictor.py:186-258), whose samples are
+        uploaded on a copy stream while chunk c - 1 runs.  A chunk's first window keeps its place modulo the packed block (a multiple
+        of 32 // W windows), so the results are predict_audio_device's bits."""
+        from .features import log_mel_span, pcm16_to_f32, span_samples
+
+        if self.device.type != "cuda":
+            raise _lib.SavadError("the MI355X predictor needs a HIP device (no CPU fallback)")
+        src = StreamingPredictor._host_source(audio)
+        n = int(src.shape[0])
+        N = 1 + n // 160
+        half, jump, Wn = self.context_window_half_frames, self.context_window_jump_frames, self.context_window_frames
+        G = max(32 // Wn, 1)
+        per = max(int(frames_per_chunk), 4 * half)
+        plan = []
+        starts = list(range(0, N, per))
+        if len(starts) > 1 and N - starts[-1] < per // 2:   # a short tail rides with the chunk before it
+            starts.pop()
+        for k, f0 in enumerate(starts):
+            f1 = starts[k + 1] if k + 1 < len(starts) else N
+            g0, g1 = max(0, f0 - 2 * half) // G * G, min(N, f1 + 2 * half)
+            first, count = span_samples(n, g0, g1 - g0)
+            plan.append((f0, f1, g0, g1, first, count))
+        self.model.eval()
+        dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != dev:
+                self._copy_stream = torch.cuda.Stream(dev)
+            cs = self._copy_stream
+            dev_audio = torch.empty(n, dtype=src.dtype, device=dev)
+            dev_audio.record_stream(cs)
+            cs.wait_stream(cur)
+            probs = torch.empty((N, Wn), dtype=torch.float32, device=dev)
+            mean = torch.empty((N,), dtype=torch.float32, device=dev)
+            uploaded = 0
+
+            def upload(c):
+                nonlocal uploaded
+                end = plan[c][4] + plan[c][5]
+                ev = torch.cuda.Event()
+                with torch.cuda.stream(cs):
+                    if end > uploaded:
+                        dev_audio[uploaded:end].copy_(src[uploaded:end], non_blocking=True)
+                        uploaded = end
+                    ev.record(cs)
+                return ev
+
+            ev = upload(0)
+            for c, (f0, f1, g0, g1, first, count) in enumerate(plan):
+                nxt = upload(c + 1) if c + 1 < len(plan) else None
+                cur.wait_event(ev)
+                sl = dev_audio[first:first + count]
+                if sl.dtype == torch.int16:
+                    sl = pcm16_to_f32(sl)
+                feat = log_mel_span(sl, first, n, g0, g1 - g0)
+                p, mu = self.model.predict_windows(feat, half, jump, self.chunk_size)
+                probs[f0:f1].copy_(p[f0 - g0:f1 - g0])
+                mean[f0:f1].copy_(mu[f0 - g0:f1 - g0])
+                ev = nxt
+        return probs, mean
+
     def _capture(self, key, n: int, dev: torch.device) -> dict:
         from .features import log_mel
 
@@ -394,7 +460,7 @@ class StreamingPredictor:
                                                ctypes.c_void_p(probs.data_ptr()), stream))
         return probs
 
-    def _windows_logp(self, feat, frame0, n_total, lo, hi, stream):
+    def _windows_logp(self, feat, frame0, n_total, lo, hi, stream, out=None, join=True):
         """log-probs [hi - lo, T, 2] of windows [lo, hi) of an n_total-frame recording, from `feat` = its frames [frame0,
         frame0 + len(feat)): windows that lie inside the recording are read IN PLACE (model.forward_windows, sequences hop * F
         elements apart: no copies); the last window of a recording that does not end on a window boundary is zero-padded
@@ -402,7 +468,7 @@ class StreamingPredictor:
         lib = _lib.load()
         T, hop, F = self.T, self.hop, feat.shape[1]
         n_local = feat.shape[0]
-        local = torch.empty((hi - lo, T, 2), dtype=torch.float32, device=self.device)
+        local = out if out is not None else torch.empty((hi - lo, T, 2), dtype=torch.float32, device=self.device)
         full_end = min(hi, (n_total - T) // hop + 1 if n_total >= T else 0)   # windows [lo, full_end) end inside the recording
         for first in range(lo, full_end, self.max_batch):
             count = min(self.max_batch, full_end - first)
@@ -417,7 +483,8 @@ class StreamingPredictor:
                 _lib.check(lib.savad_gather_strided(ctypes.c_void_p(feat.data_ptr()), n_local, F, T, hop, w - frame0 // hop, 1,
                                                     ctypes.c_void_p(win.data_ptr()), stream))
             self._pipe.submit(win, out=local[w - lo:w - lo + 1])
-        self._pipe.join()
+        if join:
+            self._pipe.join()
         return local
 
     @staticmethod
@@ -486,6 +553,90 @@ class StreamingPredictor:
             probs = torch.empty((N,), dtype=torch.float32, device=self.device)
             _lib.check(lib.savad_overlap_merge(ctypes.c_void_p(logp.data_ptr()), W, N, self.T, self.hop,
                                                ctypes.c_void_p(probs.data_ptr()), stream))
+        return probs
+
+    @staticmethod
+    def _host_source(audio):
+        """host audio (numpy array or CPU tensor, int16 PCM or float32) as a CPU tensor without a copy"""
+        src = audio if isinstance(audio, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(audio))
+        if src.device.type != "cpu" or src.dim() != 1 or src.dtype not in (torch.int16, torch.float32) or not src.is_contiguous():
+            raise ValueError("audio must be a contiguous 1-D int16 or float32 array on the host")
+        return src
+
+    @torch.no_grad()
+    def predict_audio_host(self, audio, windows_per_chunk: Optional[int] = None):
+        """configs[4] END TO END from host memory on one GPU: `audio` = the whole recording on the host, mono 16 kHz, as 16-bit PCM
+        (AudioData's source format, vad/data_models/audio_data.py:21-24: uploaded as it is -- half the bytes of the float signal --
+        and converted on the device) or float32; a numpy array or a CPU tensor (pinned memory makes the uploads asynchronous).
+        The recording is cut into spans of `windows_per_chunk` windows (default max_batch: the batches predict_device runs, so the
+        results are ITS bits); the next span is uploaded on a copy stream while a span's log-mel frames and forwards run.  The SHORT
+        span (the recording's last W mod windows_per_chunk windows) goes first: the upload nothing can hide is the smallest one.
+        Returns the per-frame probabilities [N] on the device."""
+        from .features import log_mel_span, pcm16_to_f32, span_samples
+
+        lib = _lib.load()
+        src = self._host_source(audio)
+        n = int(src.shape[0])
+        N = 1 + n // 160
+        T, hop = self.T, self.hop
+        W = lib.savad_stream_window_count(N, T, hop)
+        if W < 0:
+            _lib.check(W)
+        per = int(windows_per_chunk or self.max_batch)
+        plan = []
+        for lo in range(0, W, per):
+            hi = min(W, lo + per)
+            f0, f1 = hop * lo, min(N, hop * (hi - 1) + T)
+            first, count = span_samples(n, f0, f1 - f0)
+            plan.append((lo, hi, f0, f1, first, count))
+        if len(plan) > 1 and plan[-1][1] - plan[-1][0] < per:
+            plan.insert(0, plan.pop())
+        self.model.eval()
+        dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            stream = ctypes.c_void_p(cur.cuda_stream)
+            if self._pipe is None or self._pipe.model is not self.model or self._pipe.depth != max(self.in_flight, 1):
+                from .pipeline import PipelinedVAD
+                self._pipe = PipelinedVAD(self.model, depth=max(self.in_flight, 1))
+            if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != dev:
+                self._copy_stream = torch.cuda.Stream(dev)
+            cs = self._copy_stream
+            dev_audio = torch.empty(n, dtype=src.dtype, device=dev)
+            dev_audio.record_stream(cs)
+            cs.wait_stream(cur)
+            logp = torch.empty((W, T, 2), dtype=torch.float32, device=dev)
+            uploaded, tail_from = 0, n   # on the device so far: samples [0, uploaded) and [tail_from, n)
+
+            def upload(c):   # everything span c reads that is not on the device yet
+                nonlocal uploaded, tail_from
+                a, b = plan[c][4], plan[c][4] + plan[c][5]
+                ev = torch.cuda.Event()
+                with torch.cuda.stream(cs):
+                    if uploaded == 0 and a > 0 and c == 0:   # the short last span, taken first
+                        dev_audio[a:b].copy_(src[a:b], non_blocking=True)
+                        tail_from = a
+                    else:
+                        a, b = max(a, uploaded), min(b, tail_from)
+                        if b > a:
+                            dev_audio[a:b].copy_(src[a:b], non_blocking=True)
+                        uploaded = max(uploaded, b)
+                    ev.record(cs)
+                return ev
+
+            ev = upload(0)
+            for c, (lo, hi, f0, f1, first, count) in enumerate(plan):
+                nxt = upload(c + 1) if c + 1 < len(plan) else None   # (pageable memory: this call stages synchronously -- while span c - 1 still runs)
+                cur.wait_event(ev)
+                sl = dev_audio[first:first + count]
+                if sl.dtype == torch.int16:
+                    sl = pcm16_to_f32(sl)
+                feat = log_mel_span(sl, first, n, f0, f1 - f0)
+                self._windows_logp(feat, f0, N, lo, hi, stream, out=logp[lo:hi], join=False)   # (spans overlap on the pipeline's streams)
+                ev = nxt
+            self._pipe.join()
+            probs = torch.empty((N,), dtype=torch.float32, device=dev)
+            _lib.check(lib.savad_overlap_merge(ctypes.c_void_p(logp.data_ptr()), W, N, T, hop, ctypes.c_void_p(probs.data_ptr()), stream))
         return probs
 
     def predict(self, feature) -> np.ndarray:
