@@ -171,15 +171,16 @@ def fault_asm(tmp_path_factory):
 
     from voice_activity_detection_amd.build import hipcc
 
-    out = tmp_path_factory.mktemp("fault") / "fault7.s"
-    subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "--cuda-device-only", "-S", "-DSAVAD_FAULT_INJECT=7",
+    out = tmp_path_factory.mktemp("fault") / "fault23.s"
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "--cuda-device-only", "-S", "-DSAVAD_FAULT_INJECT=23",
                     str(REPO / "voice_activity_detection_amd" / "csrc" / "savad.hip"), "-o", str(out)], check=True)
     return out
 
 
 def test_deliberately_broken_builds_fail_the_check(fault_asm):
     """NEGATIVE test on the real sources: one wwait removed from the single-launch fp32 forward (bit 1), the bf16 ring GEMMs waiting
-    for one LDS fragment too few (bit 2), the bf16 weight ring without its workgroup barrier (bit 4).  Each must show up, in the
+    for one LDS fragment too few (bit 2), the bf16 weight ring without its workgroup barrier (bit 4), ring block 2 of the bf16 row chain
+    handed over at its barrier without the counted wait (bit 16; bits 1 and 16 are what the GPU suite's negative test runs).  Each must show up, in the
     kernel it was planted in and as the kind of hazard it is."""
     chk = _checker()
     report = chk.check_file(fault_asm)
@@ -189,6 +190,7 @@ def test_deliberately_broken_builds_fail_the_check(fault_asm):
     row = by("15row_kernel_bf16ILb0ELi4E")
     assert any(h[1].startswith("v_mfma") and h[3].startswith("ds_read_b128") for h in row)   # a fragment used before it landed
     assert any(h[1].startswith("global_load_lds") for h in row)                              # a ring slot re-targeted without the barrier
+    assert any(h[1].startswith("global_load_lds") and "published before it has landed" in h[3] for h in row)   # bit 16: block 2 handed over unwaited
     packed = by("26packed_forward_kernel_bf16ILi4ELi2ELi0E")
     assert any(h[1].startswith("v_mfma") and h[3].startswith("ds_read_b128") for h in packed) and any(h[1].startswith("global_load_lds") for h in packed)
 

@@ -9,9 +9,9 @@ fused fp32, the bf16 ring kernels with their hand-issued LDS reads, the log-mel 
 
 Round 5: seen green on hardware (it XPASSed 3/3 in the driver's round-4 tier), so the xfail marker is gone; the all-families sweep of
 scripts/ubench/l2_pressure_stress.py is folded in; and a NEGATIVE test runs the same loop on a deliberately broken build
-(SAVAD_FAULT_INJECT=1: the single-launch fp32 forward uses layer 0's query block without waiting for it; tests/fault/, built by
-__graft_entry__.build)
--- which the static checker must flag in any case (CPU suite) and which this loop is expected to catch."""
+(tests/fault/, built by __graft_entry__.build) -- which the static checker must flag in any case (CPU suite).  Round 6: the planted
+faults are deterministic (the load cannot have landed when its registers / its LDS block are read), the negative test is strict, and
+it covers one register-level and one LDS-DMA publication fault; the fp32s kernels joined the pressure cases."""
 import json
 import os
 import subprocess
@@ -23,7 +23,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parent.parent
 
-CASES = [("fp32", (8, 200, 80)), ("fp32", (2, 800, 80)), ("fp32", (500, 7, 80)), ("fp32", (64, 20, 80)), ("fp32", (32, 800, 80)),
+CASES = [("fp32s", (32, 800, 80)), ("fp32s", (500, 7, 80)), ("fp32s", (3000, 7, 80)), ("fp32s", (8, 200, 80)), ("fp32", (8, 200, 80)), ("fp32", (2, 800, 80)), ("fp32", (500, 7, 80)), ("fp32", (64, 20, 80)), ("fp32", (32, 800, 80)),
          ("fp32", (512, 50, 80)), ("bf16", (40, 264, 80)), ("bf16", (500, 7, 80)), ("bf16", (2000, 7, 80)), ("bf16", (9000, 7, 80)), ("bf16", (64, 800, 80))]
 # (the three bf16 T = 7 shapes: one block per workgroup with weights hand-streamed from L2; four blocks + four mover waves; the 2-slot ring)
 
@@ -127,60 +127,53 @@ import numpy as np
 sys.path.insert(0, {repo!r})
 import torch
 from voice_activity_detection_amd import SelfAttentiveVAD, seeded_state_dict, seeded_features, _lib
-assert str(_lib.LIB_PATH).endswith("libsavad_fault1.so")
+assert str(_lib.LIB_PATH).endswith("libsavad_fault17.so")
 m = SelfAttentiveVAD(80, 3, 128, 0.5)
 m.load_state_dict({{k: torch.from_numpy(v) for k, v in seeded_state_dict(1234).items()}})
 m = m.cuda().eval()
-want = torch.from_numpy(np.load({want!r})).cuda()     # the PRODUCT library's bits for the same input
-x = torch.from_numpy(seeded_features(5, (500, 7, 80))).cuda()
-a = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
-sides = [torch.cuda.Stream() for _ in range(4)]
-n = a.numel() // 4
-bad = []
-for rnd in range(200):
-    quiet = rnd < 20
-    if not quiet:
-        for k, side in enumerate(sides):
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    b[k * n:(k + 1) * n].copy_(a[k * n:(k + 1) * n], non_blocking=True)
-                    a[k * n:(k + 1) * n].copy_(b[k * n:(k + 1) * n], non_blocking=True)
-    with torch.no_grad():
-        outs = [m(features=x).clone() for _ in range(4)]
-    for o in outs:
-        if not torch.equal(o, want):
-            bad.append((rnd, "quiet" if quiet else "pressure", float((o - want).abs().max())))
-    for side in sides:
-        torch.cuda.current_stream().wait_stream(side)
-    if len(bad) >= 3:
-        break
-print("RESULT " + json.dumps(bad[:4]))
+want = np.load({want!r})     # the PRODUCT library's bits for the same inputs
+res = {{}}
+for tag, prec, shape in (("fp32_packed", "fp32", (500, 7, 80)), ("bf16_row", "bf16", (40, 264, 80)), ("fp32_long", "fp32", (2, 800, 80))):
+    m.precision, m.row_mode = prec, (4 if tag == "fp32_packed" else 0)   # (4: the single-launch forward, whatever the automatic choice at this size)
+    x = torch.from_numpy(seeded_features(5, shape)).cuda()
+    w = torch.from_numpy(want[tag]).cuda()
+    bad = 0
+    for rnd in range(5):
+        with torch.no_grad():
+            bad += not torch.equal(m(features=x), w)
+    res[tag] = bad
+print("RESULT " + json.dumps(res))
 """
 
 
 def test_a_deliberately_broken_build_is_caught(torch_cuda, model, tmp_path):
-    """NEGATIVE test: libsavad built with SAVAD_FAULT_INJECT=1 (the single-launch fp32 forward uses layer 0's query block, requested one
-    LayerNorm earlier, without its wwait: registers read while their load is in flight, round 4's bug class) run in a process of its own
-    against the PRODUCT library's bits for the same input: 20 quiet rounds, then 180 under four thrashing streams.  Caught = any
-    output that differs.  Not provoking it on some box is reported as xfail, never as a pass -- the static checker flags the
-    build regardless (tests/test_async_load_hazards.py)."""
+    """NEGATIVE test, strict since round 6: libsavad built with SAVAD_FAULT_INJECT=17 run in a process of its own against the PRODUCT
+    library's bits for the same inputs.  Bit 1: the single-launch fp32 forward re-targets the query block's registers with a new request
+    while the query GEMM still reads them (registers touched while a load to them is in flight, round 4's bug class).
+    Bit 16: the bf16 row chain hands ring block 2 over at its barrier without the counted wait, the DMA issued right in front of it (an
+    LDS-DMA publication fault: every wave reads block 0's bytes).  Both are planted so that no cache state, clock or box decides (the load lands INSIDE the
+    64-MFMA GEMM that reads its registers; the DMA is issued a few cycles before its block is read): every forward through a faulty kernel must differ, every forward through an untouched kernel (the fused
+    fp32 long-sequence launches) must not.  The static checker flags the same build (tests/test_async_load_hazards.py)."""
     import numpy as np
 
     from voice_activity_detection_amd import build
     from voice_activity_detection_amd.seeded import seeded_features
 
     torch = torch_cuda
-    lib = build.build_variant(build.FAULT_LIB, ["SAVAD_FAULT_INJECT=1"])   # (rebuilt only when missing or older than the sources)
-    with torch.no_grad():
-        want = model(features=torch.from_numpy(seeded_features(5, (500, 7, 80))).cuda()).cpu().numpy()
-    np.save(tmp_path / "want.npy", want)
+    lib = build.build_variant(build.FAULT_LIB, build.FAULT_DEFINES)   # (rebuilt only when missing or older than the sources)
+    want = {}
+    try:
+        for tag, prec, shape in (("fp32_packed", "fp32", (500, 7, 80)), ("bf16_row", "bf16", (40, 264, 80)), ("fp32_long", "fp32", (2, 800, 80))):
+            model.precision, model.row_mode = prec, (4 if tag == "fp32_packed" else 0)
+            with torch.no_grad():
+                want[tag] = model(features=torch.from_numpy(seeded_features(5, shape)).cuda()).cpu().numpy()
+    finally:
+        model.precision, model.row_mode = "fp32", 0
+    np.savez(tmp_path / "want.npz", **want)
     env = dict(os.environ, SAVAD_LIB=str(lib))
-    out = subprocess.run([sys.executable, "-c", _CHILD.format(repo=str(REPO), want=str(tmp_path / "want.npy"))], env=env,
+    out = subprocess.run([sys.executable, "-c", _CHILD.format(repo=str(REPO), want=str(tmp_path / "want.npz"))], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     differing = json.loads(line[len("RESULT "):])
-    if not differing:
-        pytest.xfail("the injected race was not provoked in 200 rounds on this box (the static checker flags the build regardless)")
-    assert differing
+    assert differing == {"fp32_packed": 5, "bf16_row": 5, "fp32_long": 0}, differing

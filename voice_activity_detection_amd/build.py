@@ -51,7 +51,8 @@ def build_variant(out: Path, defines=(), force: bool = False, verbose: bool = Fa
     return out
 
 
-FAULT_LIB = PKG.parent / "tests" / "fault" / "libsavad_fault1.so"  # SAVAD_FAULT_INJECT=1: tests/test_gpu_cache_pressure.py
+FAULT_LIB = PKG.parent / "tests" / "fault" / "libsavad_fault17.so"  # SAVAD_FAULT_INJECT=17 (bits 1 and 16): tests/test_gpu_cache_pressure.py
+FAULT_DEFINES = ["SAVAD_FAULT_INJECT=17"]
 
 
 if __name__ == "__main__":

@@ -365,8 +365,10 @@ __device__ long long g_savad_dbg[64];
     } while (0)
 #endif
 // Fault injection for the NEGATIVE tests of the hazard checkers (tests/test_async_load_hazards.py, tests/test_gpu_cache_pressure.py;
-// never defined in the product build): bit 1 = the single-launch fp32 forward uses layer 0's query block without waiting
-// for it (requested one LayerNorm earlier: an L2 hit usually makes it, a miss does not), bit 2 = the bf16
+// never defined in the product build): bit 1 = the single-launch fp32 forward re-targets the query block's registers (a request
+// for the key block) while the query GEMM still reads them: the load lands inside the GEMM on any box, whatever the caches hold
+// (until round 6 the fault was a missing wait behind a request one LayerNorm earlier, which an L2 hit survived), bit 16 = the bf16 row chain hands ring
+// block 2 over at a barrier without its wait, the DMA issued right in front of it (every wave then reads block 0's bytes), bit 2 = the bf16
 // ring GEMMs wait for one LDS fragment too few, bit 4 = the bf16 weight ring skips its workgroup barrier, bit 8 = the ring waits that
 // leave a wave's own stores in flight allow one operation too many (the newest DMA piece may not have landed at the barrier).
 #ifndef SAVAD_FAULT_INJECT
@@ -1041,7 +1043,10 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel(const float* __r
         SAVAD_STAMP(50);
         wload_frag(wb, frag, 4 + w, voff);
         f32x16 qb = bias_block(lbn + 32 * w, h);
-        if (!(SAVAD_FAULT_INJECT & 1) || l > 0) wwait<16>(wa);
+        wwait<16>(wa);
+        // the planted fault (bit 1): the buffer is re-targeted (the key block) while the query GEMM still reads it -- the load lands
+        // somewhere inside the GEMM's 64 MFMAs (4 096 cycles) whatever the caches hold, and the MFMAs behind it read key weights
+        if (SAVAD_FAULT_INJECT & 1) wload_frag(wa, frag, 4 + w, voff);
         wmma_k128(qb, wa, xg);
         wload_frag(wa, frag, 8 + w, voff);
         f32x16 kb = bias_block(lbn + D + 32 * w, h);

@@ -833,8 +833,13 @@ __device__ __forceinline__ void row_stage_bf16(const RowArgsBf16& A, char* smem,
     };
     // acquire block t (wave-uniform t), then keep the DMA DEPTH blocks ahead
     auto advance = [&](int t, int stores_after = 0) {
-        ring.acquire(NBLK - 1 - t < R::DEPTH - 1 ? NBLK - 1 - t : R::DEPTH - 1, stores_after);
-        if (t + R::DEPTH < NBLK) issue(t + R::DEPTH);
+        if ((SAVAD_FAULT_INJECT & 16) && R::DEPTH == 1 && t == 2) {   // the planted publication fault: block 2 requested HERE, handed over unwaited
+            issue(2);
+            __syncthreads();
+        } else {
+            ring.acquire(NBLK - 1 - t < R::DEPTH - 1 ? NBLK - 1 - t : R::DEPTH - 1, stores_after);
+        }
+        if (t + R::DEPTH < NBLK && !((SAVAD_FAULT_INJECT & 16) && R::DEPTH == 1 && t + R::DEPTH == 2)) issue(t + R::DEPTH);
     };
 #pragma unroll
     for (int t = 0; t < R::DEPTH; ++t) issue(t);
