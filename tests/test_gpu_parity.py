@@ -38,10 +38,16 @@ def model(torch_cuda, state1234):
 
 
 # The fp32-parity modes: "fp32" = exact-fp32 MFMA, "fp32s" = the same arithmetic on the bf16 matrix pipe (three-piece operands, six
-# products, fp32 accumulation: csrc/savad_kernels_f32s.h).  Every golden / oracle test that takes the `fp32_mode` fixture runs under
-# both, at the SAME tolerances.
-FP32_MODES = ["fp32", "fp32s"]
+# products, fp32 accumulation: csrc/savad_kernels_f32s.h) under the automatic schedule -- which hands batches of at most one 32-row
+# block per CU to the exact-fp32 kernels (faster there) --, "fp32s-kernels" = precision fp32s with row_mode 3: the split-bf16 kernels
+# at EVERY size.  Every golden / oracle test that takes the `fp32_mode` fixture runs under all three, at the SAME tolerances.
+FP32_MODES = ["fp32", "fp32s", "fp32s-kernels"]
 _MODE = "fp32"
+
+
+def mode_knobs(mode):
+    """fixture value -> (model.precision, the row_mode that stands for "automatic" under it)"""
+    return ("fp32s", 3) if mode == "fp32s-kernels" else (mode, 0)
 
 
 @pytest.fixture(params=FP32_MODES)
@@ -53,9 +59,10 @@ def fp32_mode(request):
 
 
 def run(torch, model, x, splits=0, row_mode=0, precision=None):
+    prec, rm = mode_knobs(precision or _MODE)
     model.attention_splits = splits
-    model.row_mode = row_mode
-    model.precision = precision or _MODE
+    model.row_mode = row_mode or rm
+    model.precision = prec
     try:
         with torch.no_grad():
             y = model(features=torch.from_numpy(x).to("cuda"))
@@ -219,7 +226,7 @@ def test_fused_attention_row_launches(torch_cuda, model, golden, state1234, fp32
     # workspace poisoning: a second call on a recycled workspace full of NaNs must not leak them through the
     # over-read V rows behind the batch
     torch = torch_cuda
-    model.row_mode, model.attention_splits, model.precision = 3, 1, fp32_mode
+    model.row_mode, model.attention_splits, model.precision = 3, 1, mode_knobs(fp32_mode)[0]
     try:
         xt = torch.from_numpy(feats(77, (3, 801, 80))).cuda()
         with torch.no_grad():
@@ -522,7 +529,7 @@ def test_weight_update_is_seen(torch_cuda, state1234, fp32_mode):
 def test_predictor_level_golden(torch_cuda, model, golden, tag, n, seed, fp32_mode):
     from voice_activity_detection_amd import VADFromScratchPredictor
 
-    model.precision = fp32_mode
+    model.precision, model.row_mode = mode_knobs(fp32_mode)
     try:
         pred = VADFromScratchPredictor(model, "cuda")
         assert pred.context_window_frames == 7
@@ -535,7 +542,7 @@ def test_predictor_level_golden(torch_cuda, model, golden, tag, n, seed, fp32_mo
         # chunking is an implementation detail: one big chunk gives the same answer
         big = VADFromScratchPredictor(model, "cuda", chunk_size=1 << 20)
         assert np.abs(big.predict_probabilities(feat) - probs).max() < 1e-6
-        if fp32_mode == "fp32s":   # ... and so is the kernel: both variants of the fp32s single launch (automatic: by the window count)
+        if fp32_mode != "fp32":   # ... and so is the kernel: both variants of the fp32s single launch (automatic: by the window count)
             for rm in (7, 8):
                 model.row_mode = rm
                 forced = VADFromScratchPredictor(model, "cuda").predict_probabilities(feat)
@@ -688,11 +695,11 @@ def test_streaming_long_form(torch_cuda, model, state1234, n, T, hop, fp32_mode)
 
     feat = feats(1000 + n, (n, 80))
     ref, _ = oracle.predict_streaming(state1234, feat, T, hop)
-    model.precision = fp32_mode
+    model.precision, model.row_mode = mode_knobs(fp32_mode)
     try:
         got = StreamingPredictor(model, "cuda", T, hop, max_batch=3).predict(feat)
     finally:
-        model.precision = "fp32"
+        model.precision, model.row_mode = "fp32", 0
     assert got.shape == (n,) and np.abs(got - ref).max() < TIGHT
 
 
@@ -713,7 +720,7 @@ def test_streaming_shapes_without_an_in_place_kernel(torch_cuda, d_model, F, T, 
         pytest.skip("the generic-width kernels are exact fp32 only")
     feat = feats(2000 + n, (n, F))
     ref, _ = oracle.predict_streaming(st, feat, T, hop)
-    m.precision = fp32_mode
+    m.precision, m.row_mode = mode_knobs(fp32_mode)
     try:
         for in_flight in (2, 1):
             got = StreamingPredictor(m, "cuda", T, hop, max_batch=5, in_flight=in_flight).predict(feat)

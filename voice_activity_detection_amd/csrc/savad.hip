@@ -419,10 +419,21 @@ bool packed_f32s_applies(const savad_model* m, int B, int T) {
     const long nblk = ((long)B + 32 / T - 1) / (32 / T);
     return m->row_mode >= 4 || (m->row_mode == 0 && nblk >= SAVAD_F32S_PACKED_MIN_BLOCKS);
 }
-// precision 2 shapes that run the exact-fp32 kernels: T <= 32 below the single launch's break-even (row_mode 1 - 3 force the fp32s
-// per-layer launches: the tests' cross-check)
+// precision 2 shapes that run the exact-fp32 kernels under the automatic schedule ("fp32s" promises the fp32 result at the best speed
+// the library has, not a particular instruction): sequences longer than 32 frames in batches of at most SAVAD_F32S_MIN_BLOCKS_PER_CU
+// 32-row blocks per CU.  There a forward's time is the latency of ONE block's chain, and the exact-fp32 kernels split a block's
+// GEMMs over the four waves of a workgroup where the fp32s fused launch gives a block to one wave: same-box sweep
+// (scripts/ubench/f32s_vs_f32_sweep.py, us, exact fp32 / fp32s): [1,800] 208 / 295, [8,800] 253 / 300, [12,800] 371 / 301,
+// [2,3200] 403 / 668, [4,3200] 747 / 673, [64,100] 187 / 203, [24,400] 340 / 246 -- the crossing sits at one block per CU for every T.
+// Any non-zero row_mode keeps the fp32s kernels (3: its fused launches at every size -- the tests' way to reach them, and the way
+// to results that do not depend on the batch a sequence arrives in: the two kernel families agree to fp32 rounding, not bit for bit).
+#ifndef SAVAD_F32S_MIN_BLOCKS_PER_CU
+#define SAVAD_F32S_MIN_BLOCKS_PER_CU 1
+#endif
 bool f32s_uses_exact_fp32(const savad_model* m, int B, int T) {
-    return T <= 32 && m->row_mode == 0 && !packed_f32s_applies(m, B, T);
+    if (m->row_mode != 0) return false;
+    if (T <= 32) return !packed_f32s_applies(m, B, T);
+    return (long)B * ((T + 31) / 32) <= (long)SAVAD_F32S_MIN_BLOCKS_PER_CU * m->n_cu;
 }
 int pack_frags3(savad_model* m, hipStream_t st, const float* W, int N, int K, size_t off) {
     const size_t total = (size_t)N * K;
