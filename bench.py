@@ -107,7 +107,9 @@ def measured_traffic(name: str, precision: str, B: int, T: int):
     if (precision, B, T) == ("fp32", 32, 800):
         files = [f for f in sorted((REPO / "profiles").glob("*_traffic.json")) if not any(t in f.name for t in ("bf16", "t7", "t50", "logmel", "fp32s"))]
     elif (precision, B, T) == ("fp32s", 32, 800):
-        files = sorted((REPO / "profiles").glob("*fp32s_traffic.json"))
+        files = [f for f in sorted((REPO / "profiles").glob("*fp32s_traffic.json")) if "t7" not in f.name]
+    elif (precision, B, T) == ("fp32s", 1000, 7):
+        files = sorted((REPO / "profiles").glob("*t7_fp32s_traffic.json"))
     elif (precision, B, T) == ("bf16", 256, 800):
         files = sorted((REPO / "profiles").glob("*bf16_b256_traffic.json"))
     elif (precision, B, T) == ("fp32", 1000, 7):
@@ -186,7 +188,9 @@ def rocprof_averages(precision, B, T):
     if (precision, B, T) == ("fp32", 32, 800):
         files = [f for f in sorted((REPO / "profiles").glob("*_kernel_avg.json")) if not any(t in f.name for t in ("bf16", "_t7_", "_t50_", "logmel", "fp32s"))]
     elif (precision, B, T) == ("fp32s", 32, 800):
-        files = sorted((REPO / "profiles").glob("*fp32s_kernel_avg.json"))
+        files = [f for f in sorted((REPO / "profiles").glob("*fp32s_kernel_avg.json")) if "t7" not in f.name]
+    elif (precision, B, T) == ("fp32s", 1000, 7):
+        files = sorted((REPO / "profiles").glob("*t7_fp32s_kernel_avg.json"))
     elif (precision, B, T) == ("bf16", 256, 800):
         files = [f for f in sorted((REPO / "profiles").glob("*bf16_kernel_avg.json")) if "t7" not in f.name]
     elif (precision, B, T) == ("fp32", 1000, 7):
@@ -208,7 +212,7 @@ def rocprof_averages(precision, B, T):
 
 ROCPROF_NAMES = {  # bench launch label -> kernel short name in the rocprofv3 stats (fp32 M-split / fused regime, bf16 4-wave kernels)
     "attention_row_f32s": "attention_row_kernel_f32s<false, false>", "attention_row_last_f32s": "attention_row_kernel_f32s<true, false>",
-    "input_qkv_f32s": "input_qkv_kernel_f32s", "packed_forward_f32s": "packed_forward_kernel_f32s",
+    "input_qkv_f32s": "input_qkv_kernel_f32s", "packed_forward_f32s": ("packed_forward_kernel_f32s_ns", "packed_forward_kernel_f32s"),
     "attention_row": "attention_row_kernel<false>", "attention_row_last": "attention_row_kernel<true>",
     "input_qkv": "input_qkv_kernel_m", "packed_forward": "packed_forward_kernel",
     "attention_bf16": ("attention_pw_kernel_bf16", "attention_kernel_bf16<4>"), "row_bf16": "row_kernel_bf16<false, 4>", "row_last_bf16": "row_kernel_bf16<true, 4>",

@@ -13,7 +13,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 
 # profile name pattern -> (precision, B, T, bytes per element of q / k / v / ctx)
-WORKLOADS = [("fp32s", ("fp32s", 32, 800, 6)), ("bf16_b256", ("bf16", 256, 800, 2)), ("t7_bf16_big", ("bf16", 65536, 7, 2)), ("t7_bf16", ("bf16", 1000, 7, 2)), ("t7", ("fp32", 1000, 7, 4)),
+WORKLOADS = [("t7_fp32s_big", ("fp32s", 65536, 7, 6)), ("t7_fp32s", ("fp32s", 1000, 7, 6)), ("fp32s", ("fp32s", 32, 800, 6)), ("bf16_b256", ("bf16", 256, 800, 2)), ("t7_bf16_big", ("bf16", 65536, 7, 2)), ("t7_bf16", ("bf16", 1000, 7, 2)), ("t7", ("fp32", 1000, 7, 4)),
              ("t50", ("fp32", 512, 50, 4)), ("logmel", ("logmel", 57_600_000, 360_001, 4)), ("", ("fp32", 32, 800, 4))]
 # rocprofv3 kernel name (as scripts/summarize_profile.py shortens it) -> bench.py launch label
 LABELS = {
@@ -27,12 +27,16 @@ LABELS = {
     "packed_forward_kernel_bf16_ns": "packed_forward_bf16",
     "logmel_fft_kernel": "logmel",
     "attention_row_kernel_f32s<false, false>": "attention_row_f32s", "attention_row_kernel_f32s<true, false>": "attention_row_last_f32s",
-    "input_qkv_kernel_f32s": "input_qkv_f32s",
+    "input_qkv_kernel_f32s": "input_qkv_f32s", "packed_forward_kernel_f32s_ns": "packed_forward_f32s", "packed_forward_kernel_f32s": "packed_forward_f32s",
 }
 # explained excesses: kernel -> (bound, why)
 KNOWN = {
     "packed_forward_kernel_bf16<4, 4, 4>": (12.0, "[1000,7,80]: 2.3 MB algorithmic; the 1.2 MB of bf16 weight fragments are fetched once per XCD L2 (and the biases): benign"),
     "packed_forward_kernel_bf16_ns": (12.0, "as packed_forward_kernel_bf16<4, 4, 4>: [1000,7,80], weights once per XCD L2"),
+    "packed_forward_kernel_f32s_ns": (16.0, "[1000,7,80]: 2.3 MB algorithmic; each of the 8 XCD L2s fetches the 3.5 MB of weight triples once (250 workgroups x 3.4 MB "
+                                             "come out of the L2s, not out of HBM): 28 MB + x, 0.5 % of the HBM roof at this launch's duration"),
+    "packed_forward_kernel_f32s": (1.6, "[65536,7,80]: 147 MB of features in, 3.7 MB of log-probs out; the weight triples (3.5 MB) re-fetched by the XCD L2s as "
+                                        "the 16 rounds of workgroups pass: explained, 0.6 % of the HBM roof"),
     "packed_forward_kernel": (12.0, "[1000,7,80]: 2.3 MB algorithmic; each of the 8 XCD L2s fetches the 2.4 MB of packed weights once: 0.3 % of the HBM roof"),
     "attention_pw_kernel_bf16": (1.65, "T = 800: the key-split tail item's workgroup starts its full group 0.55 item-times behind the sequence's other two "
                                        "groups and fetches K / V^T a second time (+105 MB); T = 768, no tail group: 1.00x (DESIGN section 4b-3)"),

@@ -326,8 +326,10 @@ __device__ __forceinline__ void qkv_slot(const char* slot, const Tri (&xp)[8], c
 }
 
 // features f0..f0+3 and f0+8..f0+11 of one input row -> the triple of an input K-step
+// (non-temporal: the features are read once; the 3.5 MB of weight triples every workgroup streams fill an XCD's 4 MB L2 almost alone,
+// and a feature stream allocated beside them kept evicting them -- [65536,7,80]: 558 MB fetched per launch against 151 MB algorithmic)
 __device__ __forceinline__ Tri load_x_tri(const float* p, bool valid) {
-    f32x4 a = ld4(p), b = ld4(p + 8);
+    f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 8));
     if (!valid) a = b = f32x4{0.f, 0.f, 0.f, 0.f};
     float t[8];
 #pragma unroll
@@ -1165,9 +1167,11 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s_ns(const fl
                                                                         PackedF32sModel M, float qscale, float* __restrict__ out,
                                                                         WindowOffsets wo, int win_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xb0 = reinterpret_cast<float*>(smem);
-    float* xb1 = xb0 + NSF_XB_FLOATS;
-    char* tbuf = smem + 2 * NSF_XB_FLOATS * 4;
+    char* xtri = smem;                                           // the eight triples of a LayerNorm's output (24 KiB) ...
+    float* xb0 = reinterpret_cast<float*>(smem);                 // ... and, behind the last layer, the final LayerNorm's fp32 rows
+    f32x2* stat2 = reinterpret_cast<f32x2*>(smem + 8 * TFRAG_BYTES);   // [wave 4][row 32] (mean, M2) of a wave's 32 features
+    char* tbuf = smem + 2 * NSF_XB_FLOATS * 4;                   // hidden triples [0, 96 K); partial scores [0, 16 K); context triples [16 K, 40 K)
+    char* ctri = tbuf + 16384;
     float* lbias = reinterpret_cast<float*>(tbuf + NSF_TRI_BYTES);
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1282,10 +1286,43 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s_ns(const fl
         layernorm_regs(full, xg);
         if (split) split_row(xg, xp);
     };
+    // LayerNorm of rows whose features are spread over the four waves WITHOUT every wave redoing all of it: a wave's two-pass (mean, M2)
+    // over its own 32 features, the four partials of a row combined exactly (equal counts: mean = average of the means, M2 = sum of
+    // the M2s + 32 sum (mean_w - mean)^2), the wave's 32 normalised features split into their two triples, all eight read back.
+    // (Two barriers instead of one, and the phase itself is no shorter -- 2.1 k against 1.5 k cycles -- but 470 VALU instructions per
+    // LayerNorm leave the stream: [1000,7,80] 73 -> 70 us, same box.)
+    auto ln_shared = [&](const f32x16& mine) {
+        float s1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1 += mine[r];
+        const float mw = half_sum(s1) * (1.0f / 32.0f);
+        float q2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = mine[r] - mw;
+            q2 = __builtin_fmaf(d, d, q2);
+        }
+        q2 = half_sum(q2);
+        if (h == 0) stat2[w * 32 + m] = f32x2{mw, q2};
+        __syncthreads();
+        const f32x2 p0 = stat2[m], p1 = stat2[32 + m], p2 = stat2[64 + m], p3 = stat2[96 + m];
+        const float mean = 0.25f * ((p0[0] + p1[0]) + (p2[0] + p3[0]));
+        const float d0 = p0[0] - mean, d1 = p1[0] - mean, d2 = p2[0] - mean, d3 = p3[0] - mean;
+        const float M2 = ((p0[1] + p1[1]) + (p2[1] + p3[1])) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        const float rstd = 1.0f / sqrtf(M2 * (1.0f / D) + LN_EPS);
+        f32x16 xn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xn[r] = (mine[r] - mean) * rstd;
+        sttri(xtri + (2 * w + 0) * TFRAG_BYTES + lane * 16, split_half(xn, 0));
+        sttri(xtri + (2 * w + 1) * TFRAG_BYTES + lane * 16, split_half(xn, 1));
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xp[ks] = ldtri(xtri + ks * TFRAG_BYTES + lane * 16);
+    };
 #pragma unroll 1
     for (int l = 0; l < L; ++l) {
         static_for<0, NSF_AHEAD>([&](auto c) { SAVAD_NSF_REQ(l, decltype(c)::value); });   // (their round trip to L2 runs under the LayerNorm)
-        rows_ln(xb0, own, true);   // (its barrier also retires the previous layer's hidden triples' readers)
+        ln_shared(own);   // (its barriers also retire the previous layer's hidden triples' readers)
         SAVAD_STAMP(42);
         const float* lb = lbias + l * LBIAS;
         const float *lb1 = lb, *lb2 = lb + DFF, *lbn = lb + DFF + D, *lbo = lb + DFF + 4 * D;
@@ -1315,29 +1352,40 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s_ns(const fl
                 }
             });
             aq *= qscale;
-            sttri(tbuf + (2 * w + 0) * TFRAG_BYTES + lane * 16, split_half(aq, 0));
-            sttri(tbuf + (2 * w + 1) * TFRAG_BYTES + lane * 16, split_half(aq, 1));
-            sttri(tbuf + (8 + 2 * w + 0) * TFRAG_BYTES + lane * 16, split_half(ak, 0));
-            sttri(tbuf + (8 + 2 * w + 1) * TFRAG_BYTES + lane * 16, split_half(ak, 1));
+            const Tri q0 = split_half(aq, 0), q1 = split_half(aq, 1), k0 = split_half(ak, 0), k1 = split_half(ak, 1);
             vt0 = split_half(av, 0);
             vt1 = split_half(av, 1);
+            // ---- this wave's 32-feature share of the score tile (12 MFMAs), the four shares summed through LDS
+            f32x16 sa = zero16(), sb = zero16();
+#define SAVAD_NSF_QK(kk, qq)                  \
+    sa = SAVAD_MF((kk).h, (qq).l, sa);        \
+    sb = SAVAD_MF((kk).l, (qq).h, sb);        \
+    sa = SAVAD_MF((kk).m, (qq).m, sa);        \
+    sb = SAVAD_MF((kk).h, (qq).m, sb);        \
+    sa = SAVAD_MF((kk).m, (qq).h, sa);        \
+    sb = SAVAD_MF((kk).h, (qq).h, sb);
+            SAVAD_NSF_QK(k0, q0)
+            SAVAD_NSF_QK(k1, q1)
+#undef SAVAD_NSF_QK
+            const f32x16 sp = sa + sb;
+            float* pb = reinterpret_cast<float*>(tbuf);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) st4(pb + ((w * 4 + g) * 64 + lane) * 4, f32x4{sp[4 * g], sp[4 * g + 1], sp[4 * g + 2], sp[4 * g + 3]});
         }
         SAVAD_STAMP(43);
-        __syncthreads();  // Q and K triples of all four waves
+        __syncthreads();  // the four partial score tiles
         SAVAD_STAMP(44);
-        // ---- the whole score tile in every wave (same operands, same order: the same bits), softmax, this wave's O^T block
-        f32x16 sa = zero16(), sb = zero16();
+        f32x16 sc;
+        {
+            const float* pb = reinterpret_cast<const float*>(tbuf);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const Tri kk = ldtri(tbuf + (8 + ks) * TFRAG_BYTES + lane * 16), qq = ldtri(tbuf + ks * TFRAG_BYTES + lane * 16);
-            sa = SAVAD_MF(kk.h, qq.l, sa);
-            sb = SAVAD_MF(kk.l, qq.h, sb);
-            sa = SAVAD_MF(kk.m, qq.m, sa);
-            sb = SAVAD_MF(kk.h, qq.m, sb);
-            sa = SAVAD_MF(kk.m, qq.h, sa);
-            sb = SAVAD_MF(kk.h, qq.h, sb);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 s4 = (ld4(pb + ((0 * 4 + g) * 64 + lane) * 4) + ld4(pb + ((1 * 4 + g) * 64 + lane) * 4)) +
+                                 (ld4(pb + ((2 * 4 + g) * 64 + lane) * 4) + ld4(pb + ((3 * 4 + g) * 64 + lane) * 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc[4 * g + e] = s4[e];
+            }
         }
-        f32x16 sc = sa + sb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = keyok[r] ? sc[r] : NEG_BIG;
         float l_run;
@@ -1362,13 +1410,12 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s_ns(const fl
             mf6(O, vt1, p1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[r] = valid ? O[r] * inv : 0.0f;
-            __syncthreads();  // every wave has read the Q / K triples: the context triples may take their place
-            sttri(tbuf + (2 * w + 0) * TFRAG_BYTES + lane * 16, split_half(O, 0));
-            sttri(tbuf + (2 * w + 1) * TFRAG_BYTES + lane * 16, split_half(O, 1));
+            sttri(ctri + (2 * w + 0) * TFRAG_BYTES + lane * 16, split_half(O, 0));   // (a region of its own: no barrier for the partial scores' readers)
+            sttri(ctri + (2 * w + 1) * TFRAG_BYTES + lane * 16, split_half(O, 1));
         }
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) xp[ks] = ldtri(tbuf + ks * TFRAG_BYTES + lane * 16);
+        for (int ks = 0; ks < 8; ++ks) xp[ks] = ldtri(ctri + ks * TFRAG_BYTES + lane * 16);
         SAVAD_STAMP(45);
         // ---- h1 = h + bo + ctx Wo^T (this wave's block), LN2
         f32x16 h1 = own;
@@ -1380,30 +1427,44 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s_ns(const fl
             for (int j = 0; j < 2; ++j) mf6(h1, wc_tri(ring[(12 + s2) % NSF_RING], j), xp[2 * s2 + j]);
         });
         SAVAD_STAMP(46);
-        rows_ln(xb1, h1, true);  // (its barrier also retires the context triples' readers)
+        ln_shared(h1);  // (its barriers also retire the context triples' readers)
         SAVAD_STAMP(47);
-        // ---- FFN1: hidden units [128 w, 128 w + 128) as two pairs of blocks, ReLU'd triples 8 w .. 8 w + 7 of the exchange
-        static_for<0, 2>([&](auto pc_) {
-            constexpr int pr = decltype(pc_)::value;
-            f32x16 a0 = bias_block(lb1 + 128 * w + 32 * (2 * pr), h), a1 = bias_block(lb1 + 128 * w + 32 * (2 * pr + 1), h);
+        // ---- FFN1: hidden units [128 w, 128 w + 128) as two pairs of blocks, ReLU'd triples 8 w .. 8 w + 7 of the exchange; the first
+        // pair's ReLU / split / stores are written behind the second pair's first waits (hipcc still emits them in one piece, 223
+        // instructions between two MFMAs -- __builtin_amdgcn_sched_group_barrier patterns did not move it either; -0.8 %, same box)
+        {
+            auto hidden_out = [&](f32x16& a0, f32x16& a1, int pr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    a0[r] = fmaxf(a0[r], 0.0f);
+                    a1[r] = fmaxf(a1[r], 0.0f);
+                }
+                sttri(tbuf + (8 * w + 4 * pr + 0) * TFRAG_BYTES + lane * 16, split_half(a0, 0));
+                sttri(tbuf + (8 * w + 4 * pr + 1) * TFRAG_BYTES + lane * 16, split_half(a0, 1));
+                sttri(tbuf + (8 * w + 4 * pr + 2) * TFRAG_BYTES + lane * 16, split_half(a1, 0));
+                sttri(tbuf + (8 * w + 4 * pr + 3) * TFRAG_BYTES + lane * 16, split_half(a1, 1));
+            };
+            f32x16 a0 = bias_block(lb1 + 128 * w, h), a1 = bias_block(lb1 + 128 * w + 32, h);
             static_for<0, 4>([&](auto sc_) {
-                constexpr int s2 = decltype(sc_)::value, c0 = 16 + 8 * pr + 2 * s2;
+                constexpr int s2 = decltype(sc_)::value, c0 = 16 + 2 * s2;
                 SAVAD_NSF_GET(l, c0);
                 SAVAD_NSF_GET(l, c0 + 1);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     mf6x2(a0, a1, wc_tri(ring[c0 % NSF_RING], j), xp[2 * s2 + j], wc_tri(ring[(c0 + 1) % NSF_RING], j), xp[2 * s2 + j]);
             });
+            f32x16 b0 = bias_block(lb1 + 128 * w + 64, h), b1 = bias_block(lb1 + 128 * w + 96, h);
+            static_for<0, 4>([&](auto sc_) {
+                constexpr int s2 = decltype(sc_)::value, c0 = 24 + 2 * s2;
+                SAVAD_NSF_GET(l, c0);
+                SAVAD_NSF_GET(l, c0 + 1);
+                if constexpr (s2 == 0) hidden_out(a0, a1, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                a0[r] = fmaxf(a0[r], 0.0f);
-                a1[r] = fmaxf(a1[r], 0.0f);
-            }
-            sttri(tbuf + (8 * w + 4 * pr + 0) * TFRAG_BYTES + lane * 16, split_half(a0, 0));
-            sttri(tbuf + (8 * w + 4 * pr + 1) * TFRAG_BYTES + lane * 16, split_half(a0, 1));
-            sttri(tbuf + (8 * w + 4 * pr + 2) * TFRAG_BYTES + lane * 16, split_half(a1, 0));
-            sttri(tbuf + (8 * w + 4 * pr + 3) * TFRAG_BYTES + lane * 16, split_half(a1, 1));
-        });
+                for (int j = 0; j < 2; ++j)
+                    mf6x2(b0, b1, wc_tri(ring[c0 % NSF_RING], j), xp[2 * s2 + j], wc_tri(ring[(c0 + 1) % NSF_RING], j), xp[2 * s2 + j]);
+            });
+            hidden_out(b0, b1, 1);
+        }
         SAVAD_STAMP(48);
         __syncthreads();
         SAVAD_STAMP(49);
