@@ -35,8 +35,9 @@ KNOWN = {
     "packed_forward_kernel_bf16_ns": (12.0, "as packed_forward_kernel_bf16<4, 4, 4>: [1000,7,80], weights once per XCD L2"),
     "packed_forward_kernel_f32s_ns": (16.0, "[1000,7,80]: 2.3 MB algorithmic; each of the 8 XCD L2s fetches the 3.5 MB of weight triples once (250 workgroups x 3.4 MB "
                                              "come out of the L2s, not out of HBM): 28 MB + x, 0.5 % of the HBM roof at this launch's duration"),
-    "packed_forward_kernel_f32s": (1.6, "[65536,7,80]: 147 MB of features in, 3.7 MB of log-probs out; the weight triples (3.5 MB) re-fetched by the XCD L2s as "
-                                        "the 16 rounds of workgroups pass: explained, 0.6 % of the HBM roof"),
+    "packed_forward_kernel_f32s": (2.0, "[65536,7,80]: 147 MB of features in, 3.7 MB of log-probs out; the 3.5 MB of weight triples every workgroup streams all but "
+                                        "fill an XCD's 4 MB L2, and whatever else passes through evicts some of them: 131 MB re-fetched over a 2.9 ms launch "
+                                        "(558 MB before the features were read non-temporally) -- 1.2 % of the HBM roof, served by the Infinity Cache"),
     "packed_forward_kernel": (12.0, "[1000,7,80]: 2.3 MB algorithmic; each of the 8 XCD L2s fetches the 2.4 MB of packed weights once: 0.3 % of the HBM roof"),
     "attention_pw_kernel_bf16": (1.65, "T = 800: the key-split tail item's workgroup starts its full group 0.55 item-times behind the sequence's other two "
                                        "groups and fetches K / V^T a second time (+105 MB); T = 768, no tail group: 1.00x (DESIGN section 4b-3)"),
