@@ -84,7 +84,6 @@ struct savad_model {
     bool frag_dirty = true;
     bool lds_attrs_set = false;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the bf16 kernels
     int n_cu = 256;              // compute units of the handle's device (launch-shape decisions)
-    long xbs_override = 0;       // savad_forward_strided: elements between consecutive sequences of x (0: T * F)
     size_t f_win = 0;
     struct LayerFrag {
         size_t wqkv, wo, w1, w2;
@@ -980,7 +979,7 @@ void launch_packed_forward_bf16(savad_model* m, hipStream_t st, const float* x, 
 
 // bf16-operand forward: input_qkv -> [attention -> row] x L on fragment-major buffers
 int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, float* out, void* workspace,
-                 size_t workspace_bytes, hipStream_t st) {
+                 size_t workspace_bytes, hipStream_t st, long xbs_in = 0 /* elements between consecutive sequences of x; 0: T * F (savad_forward_strided) */) {
     const BlockPlan bp = plan_blocks(m, B, T);
     if (workspace_bytes < bp.total) return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, bp.total);
     int rc;
@@ -1004,7 +1003,8 @@ int forward_bf16(savad_model* m, const void* x, int x_is_bf16, int B, int T, flo
         x_is_bf16 = 0;
         F = m->FP;
     }
-    const long xbs = m->xbs_override > 0 ? m->xbs_override : (long)T * F;  // (strided input and padding exclude each other: savad_forward_strided)
+    if (xbs_in > 0 && (m->FP != m->cfg.feature_size || packed_bf16_applies(m, T))) return fail(SAVAD_E_UNSUPPORTED, "strided input: no kernel takes the stride for this shape");
+    const long xbs = xbs_in > 0 ? xbs_in : (long)T * F;
     const float c = (float)(1.4426950408889634 / sqrt((double)D));
     const float* R = m->d_raw;
     const float* P = m->d_packed;
@@ -1202,7 +1202,8 @@ void launch_packed_forward_f32s(savad_model* m, hipStream_t st, const float* x, 
 }
 
 // fp32s forward (precision 2): input_qkv -> [attention + row chain] x L, every GEMM as six bf16 MFMA products of three-piece operands
-int forward_f32s(savad_model* m, const float* x, int B, int T, float* out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+int forward_f32s(savad_model* m, const float* x, int B, int T, float* out, void* workspace, size_t workspace_bytes, hipStream_t st,
+                 long xbs_in = 0 /* elements between consecutive sequences of x; 0: T * F (savad_forward_strided) */) {
     const BlockPlan3 bp = plan_blocks3(m, B, T);
     if (workspace_bytes < bp.total) return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, bp.total);
     int rc;
@@ -1222,13 +1223,14 @@ int forward_f32s(savad_model* m, const float* x, int B, int T, float* out, void*
         x = xp;
         F = m->FP;
     }
-    const long xbs = m->xbs_override > 0 ? m->xbs_override : (long)T * F;
+    if (xbs_in > 0 && (m->FP != m->cfg.feature_size || T <= 32)) return fail(SAVAD_E_UNSUPPORTED, "strided input: no kernel takes the stride for this shape");
+    const long xbs = xbs_in > 0 ? xbs_in : (long)T * F;
     const float c = (float)(1.4426950408889634 / sqrt((double)D));
     const float* R = m->d_raw;
     const float* P = m->d_packed;
     const char* Fr = m->d_frag3;
     Prof prof(m, st);
-    if (packed_f32s_applies(m, B, T) && m->xbs_override == 0) {
+    if (packed_f32s_applies(m, B, T)) {
         WindowOffsets none;
         none.w = 0;
         launch_packed_forward_f32s(m, st, x, B, T, F, out, none, 0);
@@ -1327,6 +1329,8 @@ SAVAD_EXPORT int savad_forward_ex(savad_handle m, const void* x, int x_dtype, in
     return forward_bf16(m, x, x_dtype, B, T, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int forward_any(savad_handle m, const void* xv, int x_dtype, int B, int T, long xbs_in, float* out, void* workspace, size_t workspace_bytes,
+                void* stream);
 SAVAD_EXPORT int savad_forward_strided(savad_handle m, const void* x, int x_dtype, int B, int T, long x_batch_stride, float* out,
                                        void* workspace, size_t workspace_bytes, void* stream) {
     if (!m) return fail(SAVAD_E_INVALID, "null handle");
@@ -1336,14 +1340,20 @@ SAVAD_EXPORT int savad_forward_strided(savad_handle m, const void* x, int x_dtyp
     const long F = m->cfg.feature_size;
     if (x_batch_stride <= 0 || x_batch_stride % 4 || x_batch_stride % F)
         return fail(SAVAD_E_INVALID, "x_batch_stride=%ld (a positive multiple of feature_size and of 4 elements)", x_batch_stride);
-    m->xbs_override = x_batch_stride;
-    const int rc = savad_forward_ex(m, x, x_dtype, B, T, out, workspace, workspace_bytes, stream);
-    m->xbs_override = 0;
-    return rc;
+    if (x_dtype < 0 || x_dtype > 1 || (x_dtype == 1 && m->precision != 1)) return fail(SAVAD_E_INVALID, "x_dtype %d (bf16 features need savad_set_precision(h, 1))", x_dtype);
+    return forward_any(m, x, x_dtype, B, T, x_batch_stride, out, workspace, workspace_bytes, stream);
 }
 
 SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, float* out, void* workspace,
                                size_t workspace_bytes, void* stream) {
+    return forward_any(m, x, 0, B, T, 0, out, workspace, workspace_bytes, stream);
+}
+
+// every forward entry point ends here.  xbs_in: elements between consecutive sequences of x (savad_forward_strided), 0 = T * F; it
+// travels as an ARGUMENT to the one kernel per precision that reads the features, and every path that cannot honour it refuses
+int forward_any(savad_handle m, const void* xv, int x_dtype, int B, int T, long xbs_in, float* out, void* workspace, size_t workspace_bytes,
+                void* stream) {
+    const float* x = (const float*)xv;
     if (!m) return fail(SAVAD_E_INVALID, "null handle");
     if (B < 0 || T < 0) return fail(SAVAD_E_INVALID, "negative shape B=%d T=%d", B, T);
     if (B == 0 || T == 0) return SAVAD_OK;
@@ -1352,9 +1362,10 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)workspace) & 15)
         return fail(SAVAD_E_INVALID, "x, out and workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (m->generic) return forward_generic(m, x, B, T, out, workspace, workspace_bytes, st);
-    if (m->precision == 1) return forward_bf16(m, x, 0, B, T, out, workspace, workspace_bytes, st);
-    if (m->precision == 2 && !f32s_uses_exact_fp32(m, B, T)) return forward_f32s(m, x, B, T, out, workspace, workspace_bytes, st);
+    if (m->generic) return xbs_in > 0 ? fail(SAVAD_E_UNSUPPORTED, "strided input needs the d_model=128 kernels") : forward_generic(m, x, B, T, out, workspace, workspace_bytes, st);
+    if (m->precision == 1) return forward_bf16(m, xv, x_dtype, B, T, out, workspace, workspace_bytes, st, xbs_in);
+    if (m->precision == 2 && !f32s_uses_exact_fp32(m, B, T)) return forward_f32s(m, x, B, T, out, workspace, workspace_bytes, st, xbs_in);
+    if (xbs_in > 0 && (m->FP != m->cfg.feature_size || T <= 32)) return fail(SAVAD_E_UNSUPPORTED, "strided input: no kernel takes the stride for this shape");
     const Workspace ws = plan(m, B, T);
     if (workspace_bytes < ws.total * sizeof(float))
         return fail(SAVAD_E_INVALID, "workspace too small: %zu < %zu bytes", workspace_bytes, ws.total * sizeof(float));
@@ -1373,7 +1384,7 @@ SAVAD_EXPORT int savad_forward(savad_handle m, const float* x, int B, int T, flo
         x = xp;
         F = m->FP;
     }
-    const long xbs = m->xbs_override > 0 ? m->xbs_override : (long)T * F;
+    const long xbs = xbs_in > 0 ? xbs_in : (long)T * F;
     const int tiles = (int)(ws.rows_pad / TILE);
     const float c = (float)(1.4426950408889634 / sqrt((double)D));  // log2(e) / sqrt(d_head)
     const float* R = m->d_raw;
