@@ -340,6 +340,50 @@ __device__ __forceinline__ Tri load_x_tri(const float* p, bool valid) {
     return split8(t);
 }
 
+// h0[nb] += Win[n-block nb] . x^T for one 32-row block: the input Linear (vad/models/self_attention.py:12-16) of the wave-per-block kernels.
+// Every feature piece of the row is requested up front and the four weight triples of a K-step one K-step ahead of their MFMAs: read
+// where they are used (round 6's first version) each of the F / 16 K-steps paid its own L2 round trip before a single MFMA could issue
+// -- [32,800,80] input stage 34.6 us for 11.6 us of MFMAs.
+__device__ __forceinline__ void input_gemm_f32s(f32x16 (&h0)[4], const float* xr, bool valid, const char* win, int KS, int lane, int h) {
+    constexpr int KSMAX = 8;   // feature pieces requested up front (F <= 128; the tail loop takes what is beyond)
+    f32x4 xa[KSMAX], xc[KSMAX];
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ++ks) {
+        const int kc = ks < KS ? ks : KS - 1;
+        const float* px = xr + 32 * (kc >> 1) + 16 * (kc & 1) + 4 * h;
+        xa[ks] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(px));
+        xc[ks] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(px + 8));
+    }
+    auto wtri = [&](int nb, int ks) { return ldtri(win + (size_t)(nb * KS + (ks < KS ? ks : KS - 1)) * TFRAG_BYTES + lane * 16); };
+    Tri wn[4] = {wtri(0, 0), wtri(1, 0), wtri(2, 0), wtri(3, 0)};
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ++ks)
+        if (ks < KS) {
+            const Tri w0 = wn[0], w1 = wn[1], w2 = wn[2], w3 = wn[3];
+            if (ks + 1 < KSMAX) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) wn[nb] = wtri(nb, ks + 1);
+            }
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                t[e] = valid ? xa[ks][e] : 0.0f;
+                t[4 + e] = valid ? xc[ks][e] : 0.0f;
+            }
+            const Tri xf = split8(t);
+            mfma6x2<false>(h0[0], h0[1], w0, w1, xf);
+            mfma6x2<false>(h0[2], h0[3], w2, w3, xf);
+        }
+    for (int ks = KSMAX; ks < KS; ++ks) {
+        const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
+        const Tri xf = load_x_tri(xr + f0, valid);
+#pragma unroll
+        for (int nb = 0; nb < 4; nb += 2)
+            mfma6x2<false>(h0[nb], h0[nb + 1], ldtri(win + (size_t)(nb * KS + ks) * TFRAG_BYTES + lane * 16),
+                           ldtri(win + (size_t)((nb + 1) * KS + ks) * TFRAG_BYTES + lane * 16), xf);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Kernel 1 (fp32s): input Linear + PE -> h -> LN -> Q, K, V^T triples.  4 waves = 4 blocks.
 // (vad/models/self_attention.py:12-16,24; vad/modeling/transformer.py:281-284,392-401)
@@ -374,18 +418,7 @@ __global__ __launch_bounds__(256, 1) void input_qkv_kernel_f32s(const float* __r
         add_bias(h0[nb], bin + 32 * nb, h);
         add_block(h0[nb], pe + (size_t)t_frame * D + 32 * nb, h);
     }
-    const int KS = F / 16;
-    const float* xr = x + x_row_offset(row, T, F, xbs);
-    for (int ks = 0; ks < KS; ++ks) {
-        const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
-        const Tri xf = load_x_tri(xr + f0, valid);
-#pragma unroll
-        for (int nb = 0; nb < 4; nb += 2) {
-            const Tri w0 = ldtri(win_frag + (size_t)(nb * KS + ks) * TFRAG_BYTES + lane * 16);
-            const Tri w1 = ldtri(win_frag + (size_t)((nb + 1) * KS + ks) * TFRAG_BYTES + lane * 16);
-            mfma6x2<false>(h0[nb], h0[nb + 1], w0, w1, xf);
-        }
-    }
+    input_gemm_f32s(h0, x + x_row_offset(row, T, F, xbs), valid, win_frag, F / 16, lane, h);
     const bool live = blk < nblk;
     if (live) store_hblock32(hbuf + (size_t)blk * (32 * D), h0, lane);
     f32x4 xg[16];
@@ -949,18 +982,7 @@ __global__ __launch_bounds__(256, 1) void packed_forward_kernel_f32s(const float
     }
     {
         const size_t src_row = wo.w > 0 ? (size_t)win_base + (valid ? seq : 0) + wo.off[valid ? t_frame : 0] : row;
-        const float* xr = x + src_row * (size_t)F;
-        const int KS = F / 16;
-        for (int ks = 0; ks < KS; ++ks) {
-            const int f0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
-            const Tri xf = load_x_tri(xr + f0, valid);
-#pragma unroll
-            for (int nb = 0; nb < 4; nb += 2) {
-                const Tri w0 = ldtri(M.win + (size_t)(nb * KS + ks) * TFRAG_BYTES + lane * 16);
-                const Tri w1 = ldtri(M.win + (size_t)((nb + 1) * KS + ks) * TFRAG_BYTES + lane * 16);
-                mfma6x2<false>(hres[nb], hres[nb + 1], w0, w1, xf);
-            }
-        }
+        input_gemm_f32s(hres, x + src_row * (size_t)F, valid, M.win, F / 16, lane, h);
     }
     f32x4 xg[16];
     layernorm_regs(hres, xg);
