@@ -304,3 +304,28 @@ def test_pipelined_wrapper_host_logic(state1234):
     with pytest.raises(SavadError, match="no CPU fallback"):
         pipe.submit(torch.zeros(1, 7, 80))
     pipe.join()  # nothing in flight: a no-op
+
+
+def test_reference_mode_host_chunk_plan_covers_every_window():
+    """VADFromScratchPredictor.host_chunk_plan (the chunking of predict_audio_host): for every output frame of every chunk, the windows
+    the whole recording gives that frame (vad/predictor.py:238-258: window i of the N - 2 half, centred at half + i, reaches frame
+    half + i + off) are exactly the windows of the chunk's feature slice that reach it -- nothing missing at a seam, nothing extra at a
+    clipped end --, every slice starts on a multiple of 32 // W windows, chunks tile [0, N) and no tail is shorter than half a chunk."""
+    from voice_activity_detection_amd.predictor import VADFromScratchPredictor, window_offsets
+
+    for half, jump in ((19, 9), (3, 1), (8, 4)):
+        off = [int(o) for o in window_offsets(half, jump)]
+        W = len(off)
+        G = max(32 // W, 1)
+        for N, per in ((1001, 300), (1001, 250), (5000, 4096), (77, 1000), (2 * half, 100), (2 * half + 1, 100), (640, 160), (1, 10)):
+            plan = VADFromScratchPredictor.host_chunk_plan(N, half, W, per)
+            assert plan[0][0] == 0 and plan[-1][1] == N and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+            if len(plan) > 1:
+                assert plan[-1][1] - plan[-1][0] >= max(per, 4 * half) // 2
+            for f0, f1, g0, g1 in plan:
+                assert 0 <= g0 <= f0 < f1 <= g1 <= N and g0 % G == 0
+                n_local = g1 - g0
+                for n in {f0, f0 + 1, (f0 + f1) // 2, f1 - 1} & set(range(f0, f1)):
+                    whole = {j for j, o in enumerate(off) if 0 <= n - half - o < N - 2 * half}
+                    local = {j for j, o in enumerate(off) if 0 <= (n - g0) - half - o < n_local - 2 * half}
+                    assert whole == local, (half, N, per, n, whole, local)

@@ -288,6 +288,26 @@ class VADFromScratchPredictor:
             self.graph_stats["replays"] += 1
         return entry["probs"], entry["mean"]
 
+    @staticmethod
+    def host_chunk_plan(N: int, half: int, W: int, frames_per_chunk: int):
+        """[(f0, f1, g0, g1)]: output frames [f0, f1) of an N-frame recording are computed from feature frames [g0, g1).  A frame's W
+        probabilities come from the windows centred within `half` of it (vad/predictor.py:238-258), a window reads the frames within
+        `half` of its centre (:186-212): 2 x half frames of halo per side, clipped to the recording -- where the slice is clipped, the
+        windows that are missing are exactly the ones the whole recording lacks there (the 0.5 placeholders).  g0 is a multiple of
+        32 // W, so that every window keeps its slot in a packed 32-row block (the single-launch kernels sum a slot's keys in slot order);
+        a tail shorter than half a chunk rides with the chunk before it (a tiny last chunk would run another kernel variant).
+        Host-side arithmetic only."""
+        G = max(32 // W, 1)
+        per = max(int(frames_per_chunk), 4 * half)
+        starts = list(range(0, N, per))
+        if len(starts) > 1 and N - starts[-1] < per // 2:
+            starts.pop()
+        plan = []
+        for k, f0 in enumerate(starts):
+            f1 = starts[k + 1] if k + 1 < len(starts) else N
+            plan.append((f0, f1, max(0, f0 - 2 * half) // G * G, min(N, f1 + 2 * half)))
+        return plan
+
     @torch.no_grad()
     def predict_audio_host(self, audio, frames_per_chunk: int = 65536):
         """The reference's mode END TO END from host memory: `audio` = the whole recording on the host, mono 16 kHz, 16-bit PCM
@@ -304,17 +324,8 @@ class VADFromScratchPredictor:
         n = int(src.shape[0])
         N = 1 + n // 160
         half, jump, Wn = self.context_window_half_frames, self.context_window_jump_frames, self.context_window_frames
-        G = max(32 // Wn, 1)
-        per = max(int(frames_per_chunk), 4 * half)
-        plan = []
-        starts = list(range(0, N, per))
-        if len(starts) > 1 and N - starts[-1] < per // 2:   # a short tail rides with the chunk before it
-            starts.pop()
-        for k, f0 in enumerate(starts):
-            f1 = starts[k + 1] if k + 1 < len(starts) else N
-            g0, g1 = max(0, f0 - 2 * half) // G * G, min(N, f1 + 2 * half)
-            first, count = span_samples(n, g0, g1 - g0)
-            plan.append((f0, f1, g0, g1, first, count))
+        plan = [(f0, f1, g0, g1) + tuple(span_samples(n, g0, g1 - g0))
+                for f0, f1, g0, g1 in self.host_chunk_plan(N, half, Wn, frames_per_chunk)]
         self.model.eval()
         dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(dev):
