@@ -570,8 +570,8 @@ class StreamingPredictor:
     def _host_source(audio):
         """host audio (numpy array or CPU tensor, int16 PCM or float32) as a CPU tensor without a copy"""
         src = audio if isinstance(audio, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(audio))
-        if src.device.type != "cpu" or src.dim() != 1 or src.dtype not in (torch.int16, torch.float32) or not src.is_contiguous():
-            raise ValueError("audio must be a contiguous 1-D int16 or float32 array on the host")
+        if src.device.type != "cpu" or src.dim() != 1 or src.numel() < 1 or src.dtype not in (torch.int16, torch.float32) or not src.is_contiguous():
+            raise ValueError("audio must be a non-empty contiguous 1-D int16 or float32 array on the host")
         return src
 
     @torch.no_grad()
