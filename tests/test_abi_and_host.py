@@ -329,3 +329,58 @@ def test_reference_mode_host_chunk_plan_covers_every_window():
                     whole = {j for j, o in enumerate(off) if 0 <= n - half - o < N - 2 * half}
                     local = {j for j, o in enumerate(off) if 0 <= (n - g0) - half - o < n_local - 2 * half}
                     assert whole == local, (half, N, per, n, whole, local)
+
+
+def test_audio_loader_reads_what_the_stdlib_can_decode(tmp_path):
+    """features.load_wav_mono16k (AudioData.load, vad/data_models/audio_data.py:18-34, without soundfile): integer PCM WAV of every width,
+    IEEE-float and WAVE_FORMAT_EXTENSIBLE WAVs (which the stdlib `wave` refuses), AIFF and Sun AU (big-endian PCM), headerless .pcm,
+    stereo averaged to mono; a compressed or foreign container is refused with a clear message."""
+    import struct
+    import warnings
+    import wave
+
+    from voice_activity_detection_amd.features import load_wav_mono16k
+
+    rng = np.random.default_rng(5)
+    x = np.clip(rng.standard_normal(4000) * 0.2, -0.99, 0.99).astype(np.float32)
+    i16 = np.round(x * 32767).astype(np.int16)
+    want16 = i16.astype(np.float32) / 32768.0
+
+    def riff(fmt_body, data):
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt_body)) + fmt_body + b"LIST" + struct.pack("<I", 4) + b"abcd" + \
+               b"data" + struct.pack("<I", len(data)) + data
+        return b"RIFF" + struct.pack("<I", len(body)) + body
+
+    with wave.open(str(tmp_path / "a16.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(i16.tobytes())
+    assert np.array_equal(load_wav_mono16k(tmp_path / "a16.wav"), want16)
+    (tmp_path / "f32.wav").write_bytes(riff(struct.pack("<HHIIHH", 3, 1, 16000, 64000, 4, 32), x.astype("<f4").tobytes()))
+    assert np.array_equal(load_wav_mono16k(tmp_path / "f32.wav"), x)
+    (tmp_path / "f64.wav").write_bytes(riff(struct.pack("<HHIIHH", 3, 1, 16000, 128000, 8, 64), x.astype("<f8").tobytes()))
+    assert np.array_equal(load_wav_mono16k(tmp_path / "f64.wav"), x)
+    ext = struct.pack("<HHIIHH", 0xFFFE, 2, 16000, 64000, 4, 16) + struct.pack("<HHI", 22, 16, 3) + struct.pack("<H", 1) + b"\\x00" * 14
+    stereo = np.stack([i16, -i16], axis=1)
+    (tmp_path / "ext.wav").write_bytes(riff(ext, stereo.astype("<i2").tobytes()))
+    assert np.abs(load_wav_mono16k(tmp_path / "ext.wav")).max() < 1e-6     # L + (-L) averages to (almost) nothing
+    i24 = (np.round(x * 8388607).astype(np.int32))
+    b24 = np.stack([(i24 >> s) & 0xFF for s in (0, 8, 16)], axis=1).astype(np.uint8).tobytes()
+    (tmp_path / "a24.wav").write_bytes(riff(struct.pack("<HHIIHH", 1, 1, 16000, 48000, 3, 24), b24))
+    assert np.abs(load_wav_mono16k(tmp_path / "a24.wav") - i24.astype(np.float32) / 8388608.0).max() == 0
+    i16.tofile(tmp_path / "raw.pcm")
+    assert np.array_equal(load_wav_mono16k(tmp_path / "raw.pcm"), want16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        import aifc
+        import sunau
+    with aifc.open(str(tmp_path / "a.aiff"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(i16.astype(">i2").tobytes())
+    assert np.array_equal(load_wav_mono16k(tmp_path / "a.aiff"), want16)
+    with sunau.open(str(tmp_path / "a.au"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.setcomptype("NONE", "not compressed"); w.writeframes(i16.astype(">i2").tobytes())
+    assert np.array_equal(load_wav_mono16k(tmp_path / "a.au"), want16)
+    (tmp_path / "x.wav").write_bytes(riff(struct.pack("<HHIIHH", 85, 1, 16000, 4000, 1, 0), b"\\x00" * 64))   # MP3-in-WAV
+    with pytest.raises(ValueError, match="format code 85"):
+        load_wav_mono16k(tmp_path / "x.wav")
+    (tmp_path / "y.wav").write_bytes(b"fLaC" + b"\\x00" * 64)
+    with pytest.raises(ValueError, match="not a RIFF/WAVE"):
+        load_wav_mono16k(tmp_path / "y.wav")

@@ -4,6 +4,7 @@ for its only shipped transform (log-mel, n_fft 512, hop 10 ms, window 25 ms, 80 
 from __future__ import annotations
 
 import ctypes
+from pathlib import Path
 
 import numpy as np
 import torch
@@ -81,33 +82,86 @@ def resample_to_16k(audio: np.ndarray, sample_rate: int) -> np.ndarray:
     return y
 
 
+def _riff_wave(path):
+    """(rate, channels, width, is_float, raw little-endian sample bytes) of a RIFF/WAVE file: PCM (format 1), IEEE float (3) and
+    WAVE_FORMAT_EXTENSIBLE (0xFFFE) wrapping either -- the stdlib `wave` module refuses the last two, soundfile (the reference's reader,
+    vad/data_models/audio_data.py:32) reads them"""
+    import struct
+
+    data = Path(path).read_bytes()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, raw = 12, None, None
+    while pos + 8 <= len(data):
+        tag, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if tag == b"fmt ":
+            fmt = body
+        elif tag == b"data":
+            raw = body
+            break
+        pos += 8 + size + (size & 1)
+    if fmt is None or raw is None or len(fmt) < 16:
+        raise ValueError(f"{path}: no fmt / data chunk")
+    code, ch, rate, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if code == 0xFFFE and len(fmt) >= 26:   # extensible: the sub-format GUID starts with the plain format code
+        code = struct.unpack("<H", fmt[24:26])[0]
+    if code not in (1, 3):
+        raise ValueError(f"{path}: unsupported WAVE format code {code} (PCM and IEEE float are read)")
+    return rate, ch, bits // 8, code == 3, raw
+
+
+def _pcm_to_float(raw: bytes, width: int, big_endian: bool = False, unsigned8: bool = True) -> np.ndarray:
+    """interleaved integer PCM bytes -> float32 in [-1, 1) (divide by 2^(bits - 1), as soundfile does)"""
+    e = ">" if big_endian else "<"
+    if width == 2:
+        return np.frombuffer(raw, dtype=e + "i2").astype(np.float32) / 32768.0
+    if width == 1:
+        if unsigned8:   # WAV
+            return (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        return np.frombuffer(raw, dtype=np.int8).astype(np.float32) / 128.0   # AIFF / AU
+    if width == 3:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        if big_endian:
+            b = b[:, ::-1]
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        return (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    if width == 4:
+        return (np.frombuffer(raw, dtype=e + "i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    raise ValueError(f"unsupported PCM sample width {width}")
+
+
 def load_wav_mono16k(path) -> np.ndarray:
     """Audio file -> float32 mono @16 kHz in [-1, 1): the reference's AudioData.load (vad/data_models/audio_data.py:
-    18-34) with the stdlib instead of soundfile: ``.pcm`` = headerless 16-bit mono @16 kHz (:21-24); otherwise a PCM
-    WAV of 8 / 16 / 24 / 32 bits, any channel count (averaged, :26) and any rate (resampled, :27-30)."""
-    import wave
-    from pathlib import Path
-
+    18-34) with the stdlib instead of soundfile: ``.pcm`` = headerless 16-bit mono @16 kHz (:21-24); WAV with integer PCM of
+    8 / 16 / 24 / 32 bits or IEEE float 32 / 64 (plain or WAVE_FORMAT_EXTENSIBLE); AIFF / AIFF-C (uncompressed) and Sun AU (linear PCM)
+    through the stdlib readers; any channel count (averaged, :26) and any rate (resampled, :27-30).  Compressed containers (FLAC,
+    OGG, MP3 ...) need a decoder this image does not have: convert them first."""
     path = Path(path)
-    if path.suffix == ".pcm":
+    suffix = path.suffix.lower()
+    if suffix == ".pcm":
         return (np.fromfile(path, dtype=np.int16).astype(np.float32) / 32768.0).astype(np.float32)
-    with wave.open(str(path)) as w:
-        rate, width, ch = w.getframerate(), w.getsampwidth(), w.getnchannels()
-        raw = w.readframes(w.getnframes())
-    if width == 2:
-        pcm = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-    elif width == 1:  # unsigned
-        pcm = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
-    elif width == 3:
-        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
-        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
-        pcm = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
-    elif width == 4:
-        pcm = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    if suffix in (".aiff", ".aif", ".aifc", ".au", ".snd"):
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", DeprecationWarning)   # (both readers leave the stdlib in Python 3.13)
+            mod = __import__("aifc" if suffix.startswith(".aif") else "sunau")
+        with mod.open(str(path), "rb") as r:
+            if r.getcomptype() not in (b"NONE", "NONE"):
+                raise ValueError(f"{path}: compressed {suffix} audio ({r.getcomptype()!r}) is not read")
+            rate, width, ch = r.getframerate(), r.getsampwidth(), r.getnchannels()
+            pcm = _pcm_to_float(r.readframes(r.getnframes()), width, big_endian=True, unsigned8=False)
     else:
-        raise ValueError(f"{path}: unsupported PCM sample width {width}")
+        rate, ch, width, is_float, raw = _riff_wave(path)
+        if is_float:
+            if width not in (4, 8):
+                raise ValueError(f"{path}: IEEE float samples of {8 * width} bits")
+            pcm = np.frombuffer(raw[:len(raw) // width * width], dtype="<f4" if width == 4 else "<f8").astype(np.float32)
+        else:
+            pcm = _pcm_to_float(raw[:len(raw) // width * width], width)
     if ch > 1:
-        pcm = pcm.reshape(-1, ch).mean(axis=1).astype(np.float32)
+        pcm = pcm[:pcm.size // ch * ch].reshape(-1, ch).mean(axis=1).astype(np.float32)
     return resample_to_16k(pcm, rate)
 
 
