@@ -1279,6 +1279,9 @@ def test_end_to_end_from_host_audio(torch_cuda, model, precision):
                 assert got.shape == want.shape and torch.equal(got, want), (n, type(src), getattr(src, "dtype", None))
             if precision != "bf16":   # (bf16: another batching may run another attention kernel; fp32 / fp32s: a window's result does not depend on its batch)
                 assert torch.equal(sp.predict_audio_host(pinned, windows_per_chunk=2), want)
+                # ramped spans (32, 64 ... windows): other batches, hence possibly another launch schedule -- equal to fp32 rounding
+                ramped = StreamingPredictor(model, "cuda", 800, 400, max_batch=256).predict_audio_host(pinned, ramp=True)
+                assert float((ramped - want).abs().max()) < 2e-6
         # the reference's mode
         n = 16000 * 75 + 321
         pcm = np.clip(np.round(_chirp(n, 11) * 32768.0), -32768, 32767).astype(np.int16)

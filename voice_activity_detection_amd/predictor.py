@@ -575,14 +575,18 @@ class StreamingPredictor:
         return src
 
     @torch.no_grad()
-    def predict_audio_host(self, audio, windows_per_chunk: Optional[int] = None):
+    def predict_audio_host(self, audio, windows_per_chunk: Optional[int] = None, ramp: bool = False):
         """configs[4] END TO END from host memory on one GPU: `audio` = the whole recording on the host, mono 16 kHz, as 16-bit PCM
         (AudioData's source format, vad/data_models/audio_data.py:21-24: uploaded as it is -- half the bytes of the float signal --
         and converted on the device) or float32; a numpy array or a CPU tensor (pinned memory makes the uploads asynchronous).
         The recording is cut into spans of `windows_per_chunk` windows (default max_batch: the batches predict_device runs, so the
         results are ITS bits); the next span is uploaded on a copy stream while a span's log-mel frames and forwards run.  The SHORT
         span (the recording's last W mod windows_per_chunk windows) goes first: the upload nothing can hide is the smallest one.
-        Returns the per-frame probabilities [N] on the device."""
+        `ramp=True` starts with spans of 32, 64, 128 ... windows instead: the exposed upload shrinks to an eighth (1 h fp32s: 10.20 ->
+        9.96 ms against 9.75 device-resident; bf16: no gain, its small batches run the slower kernels -- scripts/ubench/
+        host_pipeline_parts.py), but the batches are no longer predict_device's: the same bits only where a window's result does
+        not depend on its batch (fp32 / fp32s: measured equal; bf16 needs model.batch_invariant).  Returns the per-frame
+        probabilities [N] on the device."""
         from .features import log_mel_span, pcm16_to_f32, span_samples
 
         lib = _lib.load()
@@ -594,13 +598,19 @@ class StreamingPredictor:
         if W < 0:
             _lib.check(W)
         per = int(windows_per_chunk or self.max_batch)
+        bounds, lo = [], 0
+        if ramp:   # spans of 32, 64, 128 ... windows up to `per`: the first upload -- the one nothing hides -- is an eighth of a full span's
+            step = 32
+            while lo < W and step < per:
+                bounds.append((lo, min(W, lo + step)))
+                lo, step = lo + step, 2 * step
+        bounds += [(b, min(W, b + per)) for b in range(lo, W, per)]
         plan = []
-        for lo in range(0, W, per):
-            hi = min(W, lo + per)
+        for lo, hi in bounds:
             f0, f1 = hop * lo, min(N, hop * (hi - 1) + T)
             first, count = span_samples(n, f0, f1 - f0)
             plan.append((lo, hi, f0, f1, first, count))
-        if len(plan) > 1 and plan[-1][1] - plan[-1][0] < per:
+        if not ramp and len(plan) > 1 and plan[-1][1] - plan[-1][0] < per:
             plan.insert(0, plan.pop())
         self.model.eval()
         dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
