@@ -343,7 +343,10 @@ __device__ __forceinline__ Tri load_x_tri(const float* p, bool valid) {
 // h0[nb] += Win[n-block nb] . x^T for one 32-row block: the input Linear (vad/models/self_attention.py:12-16) of the wave-per-block kernels.
 // Every feature piece of the row is requested up front and the four weight triples of a K-step one K-step ahead of their MFMAs: read
 // where they are used (round 6's first version) each of the F / 16 K-steps paid its own L2 round trip before a single MFMA could issue
-// -- [32,800,80] input stage 34.6 us for 11.6 us of MFMAs.
+// -- [32,800,80] input stage 38 -> 34 us.  (What bounds the stage now is not this GEMM: it moves 800 KiB per workgroup -- ring 288, input
+// weights 60 per wave-copy, positional rows 64, features 40, 352 of Q / K / V^T triples and residual written -- 160 MB per launch in
+// 27 us = 5.9 TB/s, the rate a copy kernel reaches here.  One copy of the input weights per workgroup through LDS instead of one per
+// wave, and all of a wave's weight triples requested up front, both measured: 34.2 / 34.1 us, no change; scripts/ubench/phase_timing_input_f32s.py.)
 __device__ __forceinline__ void input_gemm_f32s(f32x16 (&h0)[4], const float* xr, bool valid, const char* win, int KS, int lane, int h) {
     constexpr int KSMAX = 8;   // feature pieces requested up front (F <= 128; the tail loop takes what is beyond)
     f32x4 xa[KSMAX], xc[KSMAX];
@@ -401,9 +404,11 @@ __global__ __launch_bounds__(256, 1) void input_qkv_kernel_f32s(const float* __r
     const int blk = blockIdx.x * 4 + w;
     const Ring3 ring(smem, w, lane);
     auto job = [&](int t) { return ring.job(t, wqkv_frag + (size_t)(2 * t) * BLK3_BYTES, wqkv_frag + (size_t)(2 * t + 1) * BLK3_BYTES); };
+    SAVAD_STAMP(57);
     ring.issue_all(job(0));
     ring.issue_all(job(1));
     stage_bias(lbq, bqkv, 3 * D);
+    SAVAD_STAMP(58);
     size_t row;
     int t_frame;
     const bool valid = (blk < nblk) && slot_row(B, T, blk, m, row, t_frame);
@@ -419,17 +424,24 @@ __global__ __launch_bounds__(256, 1) void input_qkv_kernel_f32s(const float* __r
         add_block(h0[nb], pe + (size_t)t_frame * D + 32 * nb, h);
     }
     input_gemm_f32s(h0, x + x_row_offset(row, T, F, xbs), valid, win_frag, F / 16, lane, h);
+    SAVAD_STAMP(59);
     const bool live = blk < nblk;
     if (live) store_hblock32(hbuf + (size_t)blk * (32 * D), h0, lane);
     f32x4 xg[16];
     layernorm_regs(h0, xg);
     Tri xp[8];
     split_row(xg, xp);
+    SAVAD_STAMP(60);
     const DmaJob none{nullptr, 0u};
 #define SAVAD_IQ_STEP(T_)                                                                                                      \
     ring.acquire<((T_) + 1 < 6) ? 1 : 0>();                                                                                    \
     qkv_slot<T_, ((T_) + 2 < 6)>(ring.slot(T_), xp, lbq, qf, kf, vtf, blk, ring, (T_) + 2 < 6 ? job((T_) + 2) : none, qscale, live);
-    SAVAD_IQ_STEP(0) SAVAD_IQ_STEP(1) SAVAD_IQ_STEP(2) SAVAD_IQ_STEP(3) SAVAD_IQ_STEP(4) SAVAD_IQ_STEP(5)
+    SAVAD_IQ_STEP(0) SAVAD_IQ_STEP(1)
+    SAVAD_STAMP(61);
+    SAVAD_IQ_STEP(2) SAVAD_IQ_STEP(3)
+    SAVAD_STAMP(62);
+    SAVAD_IQ_STEP(4) SAVAD_IQ_STEP(5)
+    SAVAD_STAMP(63);
 #undef SAVAD_IQ_STEP
 }
 
