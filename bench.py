@@ -817,12 +817,13 @@ def stream_one_hour_sharded(state, dev, rank, world, min_seconds):
     model = SelfAttentiveVAD(F_MEL, N_LAYERS, D_MODEL, 0.5)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     model = model.to(dev).eval()
-    audio = np.random.default_rng(0).standard_normal(16000 * seconds, dtype=np.float32) * np.float32(0.1)
+    # 16-bit PCM on every rank's host (AudioData's source format): a rank uploads its own samples as they are, 2 bytes each
+    audio = np.clip(np.round(np.random.default_rng(0).standard_normal(16000 * seconds, dtype=np.float32) * (0.1 * 32768.0)), -32768, 32767).astype(np.int16)
     plan = StreamingPredictor.audio_shard_plan(len(audio), 800, 400, rank, world)
     res = {"workload": f"BASELINE configs[4] on {world} GPU(s): {seconds} s of 16 kHz audio on the host -> per rank: its samples -> log-mel of its frames -> its "
                        "windows T=800 hop=400 in place -> forward; one all_gather; overlap merge", "audio_seconds": seconds,
            "rank0_share": {"windows": [int(plan[1]), int(plan[2])], "frames": [int(plan[3]), int(plan[4])], "samples": int(plan[6])},
-           "note": "wall time from HOST audio: includes each rank's host -> device copy of its own samples (230 MB / world over PCIe); the "
+           "note": "wall time from HOST audio (16-bit PCM, pageable): includes each rank's host -> device copy of its own samples (115 MB / world over PCIe); the "
                    "device-resident figure of one GPU is secondary.configs4_stream_1h.*.from_audio_ms of the N = 1 line"}
     for prec in ("bf16", "fp32"):
         model.precision = prec

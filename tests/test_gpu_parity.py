@@ -1273,6 +1273,7 @@ def test_end_to_end_from_host_audio(torch_cuda, model, precision):
             assert torch.equal(log_mel(pcm), log_mel(fd)) and torch.equal(log_mel(torch.from_numpy(pcm).cuda()), log_mel(fd))
             sp = StreamingPredictor(model, "cuda", 800, 400, max_batch=3, in_flight=2)
             want = sp.predict_audio_device(fd)
+            assert torch.equal(sp.predict_audio_device(pcm), want) and torch.equal(sp.predict_audio_device(torch.from_numpy(pcm).cuda()), want)   # (the sharded entry point takes PCM16 too)
             pinned = torch.from_numpy(pcm).pin_memory()
             for src in (pcm, pinned, as_float, torch.from_numpy(as_float).pin_memory()):
                 got = sp.predict_audio_host(src)

@@ -537,14 +537,19 @@ class StreamingPredictor:
                 self._pipe = PipelinedVAD(self.model, depth=max(self.in_flight, 1))
             sl = audio[first:first + count]
             if not isinstance(sl, torch.Tensor):
-                sl = torch.from_numpy(np.ascontiguousarray(sl, dtype=np.float32))
-            sl = sl.to(self.device, torch.float32).contiguous()
+                sl = torch.from_numpy(np.ascontiguousarray(sl) if sl.dtype == np.int16 else np.ascontiguousarray(sl, dtype=np.float32))
+            if sl.dtype == torch.int16:   # 16-bit PCM goes up as it is (half the bytes) and is converted on the device
+                from .features import pcm16_to_f32
+                sl = pcm16_to_f32(sl.to(self.device).contiguous())
+            else:
+                sl = sl.to(self.device, torch.float32).contiguous()
             feat = log_mel_span(sl, first, n, f0, f1 - f0)
             return self._windows_logp(feat, f0, 1 + n // 160, lo, hi, stream)
 
     @torch.no_grad()
     def predict_audio_device(self, audio):
-        """configs[4] from the AUDIO: `audio` = the whole recording, float32 mono 16 kHz, on the HOST (numpy) or the device.  With
+        """configs[4] from the AUDIO: `audio` = the whole recording, mono 16 kHz, float32 or 16-bit PCM (uploaded as it is, converted on the
+        device), on the HOST (numpy) or the device.  With
         torch.distributed initialised every rank computes the log-mel features of ITS window span only (audio_shard_plan), runs
         its windows in place on them, and ONE all_gather of the log-probs + the overlap merge give every rank the per-frame
         probabilities.  Same bits as predict_device(log_mel(audio)) on one GPU (tests/test_gpu_parity.py)."""
